@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec for one optimiser step (forward with training-mode BN + loss + backward + gradient
+all-reduce + Adam) of the reference's UNet-family hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload C3|C2|C5|tiny]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Default workload = the configuration BASELINE.json's metric is quoted on: UNet++ depth-5 width-64 with deep
+supervision, 256x256x3, batch 16 per GPU (config C3 of SURVEY.md 8d); weak scaling (per-GPU batch fixed).
+Synthetic data (x ~ U[0,1), seed 1234+rank; Bernoulli(0.5) masks replicated to every DS output), random-init
+weights (seed 0, identical on every rank).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+PKG = "tf-1d-2d-segmentation-end2endpipelines_amd"
+PEAK_TFLOPS_F16 = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (builder kwargs, H, W, Cin, batch/GPU, loss, description)
+    "C3": (dict(decoder_name="UNetPP", model_width=64, model_depth=5, ds=1), 256, 256, 3, 16, "mse",
+           "UNet++ d5 w64 +DS 256x256x3 bs16/GPU (BASELINE.json configs[2], the config the metric is quoted on)"),
+    "C2": (dict(decoder_name="UNet", model_width=64, model_depth=5, output_nums=4, final_activation="softmax"), 256, 256, 3, 16,
+           "cce", "UNet d5 w64 256x256x3 4-class bs16 (BASELINE.json configs[1])"),
+    "C5": (dict(decoder_name="UNet", model_width=64, model_depth=4, lstm=1), 256, 256, 1, 8, "bce",
+           "UNet + ConvLSTM skip ('BCDUNet') d4 w64 256x256x1 bs8/GPU (BASELINE.json configs[4])"),
+    "tiny": (dict(decoder_name="UNetPP", model_width=16, model_depth=3, ds=1), 64, 64, 3, 4, "mse", "UNet++ d3 w16 64x64 bs4 (plumbing check)"),
+}
+
+
+def make_batch(model, N, H, W, Cin, loss, rank):
+    gen = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand((N, H, W, Cin), generator=gen, dtype=torch.float32)
+    targets = []
+    first = None
+    for h in model.out_heads:
+        shp = tuple(h.y.shape)
+        if loss == "cce":
+            lab = torch.randint(0, shp[-1], shp[:-1], generator=gen)
+            t = torch.nn.functional.one_hot(lab, shp[-1]).float()
+        else:
+            if first is not None and first.shape == shp:
+                t = first                      # UNet++ DS rule: the same mask for every output (helper_functions.py:376)
+            else:
+                t = (torch.rand(shp, generator=gen) > 0.5).float()
+                if first is None:
+                    first = t
+        targets.append(t)
+    return x.cuda(), [t.cuda() for t in targets]
+
+
+def cpu_baseline(workload, sample_batch=2, steps=2):
+    """The oracle (torch-CPU fp32 restatement of the reference graph, kind 'port') timed on the host cores:
+    forward + backward + Keras Adam on a bounded sample (smaller batch, same model and resolution)."""
+    from oracle.keras_ref import Layers
+    from oracle.models_ref import unet2d_forward
+    from oracle.train_ref import KerasAdam, loss_and_grads
+    kw, H, W, Cin, _bs, loss, _d = WORKLOADS[workload]
+    kw = dict(kw)
+    dec, w, d = kw.pop("decoder_name"), kw.pop("model_width"), kw.pop("model_depth")
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    L = Layers(2, seed=0)
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.rand((sample_batch, H, W, Cin), generator=gen)
+    fwd = lambda: unet2d_forward(L, x, dec, w, d, **kw)
+    with torch.no_grad():
+        L.update_moving = False
+        outs = fwd()          # creates the parameters
+        L.update_moving = True
+    if loss == "cce":
+        tg = [torch.nn.functional.one_hot(torch.randint(0, o.shape[-1], o.shape[:-1], generator=gen), o.shape[-1]).float() for o in outs]
+    else:
+        tg = [(torch.rand(o.shape, generator=gen) > 0.5).float() for o in outs]
+    opt = KerasAdam({k: v for k, v in L.params.items() if L.trainable[k]}, lr=2e-4)
+
+    def step():
+        _l, _p, _o, grads = loss_and_grads(L, fwd, tg, loss)
+        opt.step(grads)
+    step()                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": sample_batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement, not TensorFlow): {steps} optimiser steps of batch {sample_batch} "
+                      f"after 1 warm-up, same model/resolution as the GPU workload, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's own)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    pkg = importlib.import_module(PKG)
+    modelmod = importlib.import_module(PKG + ".model")
+    dp = importlib.import_module(PKG + ".dp")
+    if world > 1:
+        dp.init_process_group_from_env("nccl")
+    import torch.distributed as dist
+
+    kw, H, W, Cin, bs, loss, desc = WORKLOADS[args.workload]
+    if args.batch:
+        bs = args.batch
+    model = pkg.unet_model_builder(length=H, width=W, num_channels=Cin, train_mode="from_scratch", **kw).ResNet50()
+    model.build(bs)
+    model.compile(loss=loss, lr=2e-4)
+    dpm = dp.DataParallel(model)
+    x, targets = make_batch(model, bs, H, W, Cin, loss, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step(x, targets)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(x, targets)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(model.loss_buf.cpu())
+    ms = dt / args.steps * 1e3
+    value = world * bs * args.steps / dt
+
+    macs = model.graph.macs()
+    first = next(n for n in (model.graph.nodes[i] for i in model.graph.live_nodes()) if n.kind in ("conv", "convT"))
+    first_macs = first.shape[0] * first.shape[1] * first.attrs["kernel"][0] * first.attrs["kernel"][1] * Cin * first.shape[2]
+    flop_img = 2.0 * macs * 3 - 2.0 * first_macs          # fwd + dgrad + wgrad, no dgrad into the image
+
+    roofline = None
+    if not args.no_profile and rank == 0:
+        KP = modelmod.KernelProfile
+        KP.records.clear()
+        KP.on = True
+        model.train_step(x, targets)
+        KP.on = False
+        summ = KP.summary()
+        gemm = {k: v for k, v in summ.items() if k in ("seg_igemm_fwd", "seg_igemm_wgrad")}
+        dom = max(gemm, key=lambda k: gemm[k]["seconds"])
+        d_ = gemm[dom]
+        ach = d_["flops"] / d_["seconds"] / 1e12
+        tot_s = sum(v["seconds"] for v in summ.values())
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_TFLOPS_F16, "traffic": None, "launches": d_["launches"],
+                    "avg_launch_us": d_["seconds"] / d_["launches"] * 1e6,
+                    "algorithmic_flops_per_launch": d_["flops"] / d_["launches"],
+                    "step_share": d_["seconds"] / tot_s,
+                    "kernel_seconds_per_step": {k: round(v["seconds"], 6) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])},
+                    "whole_step_tflops": flop_img * bs / (ms * 1e-3) / 1e12}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "tiny":
+        try:
+            cpu = cpu_baseline(args.workload)
+        except Exception as e:          # the oracle is a reported baseline, never a dependency of the GPU number
+            cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        line = {"metric": "images/sec fwd+bwd, UNet++ depth-5 256x256 bs=16/GPU" if args.workload == "C3" else f"images/sec fwd+bwd ({args.workload})",
+                "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+                "data": "synthetic", "config": {"workload": f"{args.workload}: {desc}", "global_batch": world * bs,
+                                               "per_gpu_batch": bs, "parallelism": f"dp{world}", "loss": loss,
+                                               "optimizer": "adam", "gflop_per_image_fwd_bwd": flop_img / 1e9,
+                                               "final_loss": loss_val},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,217 @@
+/* seg_hip.h - C ABI of the MI355X (gfx950) UNet-family hot path.
+ *
+ * The reference (Sakib1263/TF-1D-2D-Segmentation-End2EndPipelines) has NO plugin / operator / FFI interface: its
+ * hot path is the graph of tf.keras layers built in TensorFlow/2DCNN/models/unet_variants.py:7-154,277-343,
+ * 459-487,750-792,936-1115 (1D: TensorFlow/1DCNN/Models/unet_variants.py:53-319,544-645, BCDUNet.py:6-174) and
+ * executed by Keras fit/predict (2DCNN/Train.py:394-415, 2DCNN/Test.py:153,161).  Each entry point below
+ * replaces the TensorFlow-runtime kernel(s) behind one of those Keras layers; the layer is cited per function.
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative SEG_ERR_* otherwise; seg_last_error() gives the message
+ *     (thread-local).  No allocation, no synchronisation, no ownership transfer inside: every call only
+ *     enqueues kernels on `stream` (a hipStream_t), so calls may be captured into a hipGraph.
+ *   - activations are NHWC fp16 with a channel stride `cs` (elements per pixel, multiple of 8); channels beyond
+ *     the logical channel count are zero.  A 1D signal is H = 1.
+ *   - "virtual concat": a conv input is a list of up to SEG_MAX_SEG tensors of identical N,H,W; the K loop walks
+ *     them, the concatenated tensor is never materialised (Concat_Block, unet_variants.py:27-32).
+ *   - GEMM weights are [rows][T][Kpad] (rows = GEMM N extent, T = taps in the kernel window, Kpad = sum of the
+ *     segment channel counts each rounded up to 32); fp16 for the MFMA operand, fp32 for master copy / gradient.
+ */
+#ifndef SEG_HIP_H
+#define SEG_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* seg_stream_t; /* hipStream_t */
+
+enum { SEG_OK = 0, SEG_ERR_ARG = -1, SEG_ERR_LAUNCH = -2, SEG_ERR_UNSUPPORTED = -3 };
+enum { SEG_ACT_NONE = 0, SEG_ACT_RELU = 1, SEG_ACT_LEAKY = 2, SEG_ACT_SIGMOID = 3, SEG_ACT_SOFTMAX = 4 };
+enum { SEG_LOSS_MSE = 0, SEG_LOSS_BCE = 1, SEG_LOSS_CCE = 2 };
+
+#define SEG_MAX_SEG 8
+#define SEG_MAX_TAPS 16
+#define SEG_MAX_CLS 4
+
+const char* seg_last_error(void);
+int seg_abi_version(void);
+
+/* Geometry of one (transposed / strided) convolution as an implicit GEMM over "logical pixels" (n, i, j),
+ * i < Hl, j < Wl, evaluated for ncls output classes (1 for a convolution, 4 = sub-pixel parity classes of a
+ * 4x4/s2 transposed conv, 2 for the 1D k2/s2 one).  For class c and tap t (entry e = c*ntaps + t):
+ *   input  pixel = (i*isy + tap_dy[e], j*isx + tap_dx[e])   (zero outside [0,Hin) x [0,Win))
+ *   output pixel = (i*osy + oy[c],     j*osx + ox[c])       (always inside [0,Hout) x [0,Wout))
+ *   weight slice = tap_w[e]  (index into the T_total taps of the weight tensor)                                */
+typedef struct seg_geom {
+  int32_t N, Hin, Win;
+  int32_t Hl, Wl;
+  int32_t isy, isx;
+  int32_t Hout, Wout;
+  int32_t osy, osx;
+  int32_t ncls, ntaps;
+  int32_t T_total;
+  int32_t oy[SEG_MAX_CLS], ox[SEG_MAX_CLS];
+  int32_t tap_dy[SEG_MAX_TAPS], tap_dx[SEG_MAX_TAPS], tap_w[SEG_MAX_TAPS];
+} seg_geom;
+
+/* ---- implicit-GEMM forward: Conv1D/2D (unet_variants.py:9), Conv1D/2DTranspose (:19), the ConvLSTM input conv
+ * (:148) and - with transposed weights - every data gradient of those layers.
+ *   out[pix][n] (+)= act( sum_{seg,tap,c} in_seg[pix+tap][c] * w[n][tap_w][woff_seg + c] + bias[n] )
+ * MFMA v_mfma_f32_32x32x16_f16, fp32 accumulate.  Optional per-channel partial sums of the pre-activation
+ * value (sum, sum of squares) for training-mode BatchNormalization (:11).                                       */
+typedef struct seg_igemm_fwd_args {
+  seg_geom g;
+  int32_t nseg;
+  int32_t seg_c[SEG_MAX_SEG];    /* channels of segment s taking part (multiple of 8)                      */
+  int32_t seg_cs[SEG_MAX_SEG];   /* channel stride of segment s                                            */
+  int32_t seg_woff[SEG_MAX_SEG]; /* first K column of segment s in the weight (multiple of 32)             */
+  const void* seg_ptr[SEG_MAX_SEG];
+  const void* w;                 /* fp16 [n_rows][T_total][Kpad]                                           */
+  int32_t Kpad;
+  int32_t n_rows;                /* GEMM N extent (multiple of 8)                                          */
+  int32_t n_valid;               /* outputs n >= n_valid are written as 0 (channel padding)                */
+  void* out;                     /* fp16 [N][Hout][Wout][out_cs], columns out_coff .. out_coff+n_rows      */
+  int32_t out_cs, out_coff;
+  const float* bias;             /* [n_rows] or NULL                                                       */
+  int32_t act;                   /* SEG_ACT_NONE / RELU / LEAKY / SIGMOID                                  */
+  float alpha;
+  int32_t accumulate;            /* out += result instead of out = result                                  */
+  float* stats;                  /* NULL or fp32 [nparts][2][n_rows], nparts = ncls * ceil(M / tile_m)     */
+  int32_t tile_m, tile_n;        /* 128 or 64                                                              */
+} seg_igemm_fwd_args;
+int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
+
+/* ---- implicit-GEMM weight gradient of the same layers:
+ *   dw[n][tap_w][woff_seg + c] += scale * (*scale_ptr) * sum_pix dz[outpix][n] * in_seg[pix+tap][c]
+ * reduction over pixels split `splitk` ways, fp32 atomics into dw.                                              */
+typedef struct seg_igemm_wgrad_args {
+  seg_geom g;
+  int32_t nseg;
+  int32_t seg_c[SEG_MAX_SEG], seg_cs[SEG_MAX_SEG], seg_woff[SEG_MAX_SEG];
+  const void* seg_ptr[SEG_MAX_SEG];
+  const void* dz;                /* fp16 [N][Hout][Wout][dz_cs], columns dz_coff .. dz_coff+n_rows         */
+  int32_t dz_cs, dz_coff;
+  float* dw;                     /* fp32 [n_rows][T_total][Kpad]                                           */
+  int32_t Kpad, n_rows;
+  int32_t splitk;
+  float scale;
+  const float* scale_ptr;        /* device scalar or NULL                                                  */
+  int32_t tile_m, tile_n;        /* rows (n) x K-columns tile: 128 or 64                                   */
+  int32_t variant;               /* 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores         */
+} seg_igemm_wgrad_args;
+int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
+
+/* ---- BatchNormalization() (unet_variants.py:11,70,72,76,96,99), eps 1e-3, momentum 0.99 ------------------ */
+/* per-channel partial sums of an existing tensor: stats[part][0][c] = sum x, [1][c] = sum x^2 over the part   */
+int seg_bn_stats(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts,
+                 int32_t stats_ld, int32_t stats_coff, seg_stream_t stream);
+/* reduce the partials -> batch mean / biased var; scale = gamma*rsqrt(var+eps), shift = beta - mean*scale;
+ * moving stats update (unbiased variance when unbiased_moving != 0: the fused 4-D Keras path).  training == 0:
+ * scale/shift from the moving statistics, nothing else touched.                                               */
+int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, int64_t count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                    int32_t unbiased_moving, int32_t training, float* mean, float* invstd, float* scale,
+                    float* shift, seg_stream_t stream);
+/* y = act(x*scale + shift) (channels >= c_valid -> 0); optional fused MaxPooling2D(ph,pw) second output
+ * (unet_variants.py:790).                                                                                     */
+int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff,
+                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
+                     const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
+                     seg_stream_t stream);
+/* backward, pass 1: g = dy * act'(y), y = x*scale+shift; partial[part][0][c] = sum g, [1][c] = sum g*xhat       */
+int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                          int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, int32_t act, float alpha, float* partial,
+                          int32_t nparts, seg_stream_t stream);
+/* pass 1b: dgamma += gs * sum g*xhat, dbeta += gs * sum g (gs = gscale * *gscale_ptr); c1 = sum g / count,
+ * c2 = sum g*xhat / count                                                                                     */
+int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma,
+                        float* dbeta, float gscale, const float* gscale_ptr, float* c1, float* c2,
+                        seg_stream_t stream);
+/* pass 2: dx = scale * (g - c1 - xhat*c2)   (training)   or   dx = scale * g   (c1 == NULL: inference BN)     */
+int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                         int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C,
+                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate,
+                         seg_stream_t stream);
+
+/* ---- Activation layers without BN (unet_variants.py:23 LeakyReLU after Conv2DTranspose):
+ * dx = dy * act'(y) given the activation OUTPUT y; optional bias gradient dbias[c] += gs * sum_pix dx          */
+int seg_act_bwd(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act,
+                float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream);
+
+/* ---- MaxPooling1D/2D (unet_variants.py:790), stride = pool size ------------------------------------------- */
+int seg_maxpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw,
+                    seg_stream_t stream);
+/* dx (+)= dy routed to the first maximum of each window (TensorFlow MaxPoolGrad tie rule)                      */
+int seg_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W,
+                    int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream);
+
+/* ---- UpSampling2D(bilinear) (unet_variants.py:37, half-pixel centres, edge clamp) / UpSampling1D nearest     */
+int seg_upsample_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
+                     int32_t bilinear, seg_stream_t stream);
+int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh,
+                     int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream);
+
+/* ---- add([..]) / Add() (+ optional activation) (unet_variants.py:55,73,97,112): y = act(sum_i x_i), n <= 4   */
+int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha,
+                    seg_stream_t stream);
+/* dx_i (+)= dy * act'(y) for every i with dxs[i] != NULL; accumulate is a bit mask over i                      */
+int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
+                    float alpha, int32_t accumulate_mask, seg_stream_t stream);
+
+/* ---- attention gating multiply (unet_variants.py:81): y[p][c] = a[p][c] * r[p][0]                           */
+int seg_mul_bcast_fwd(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs,
+                      seg_stream_t stream);
+/* da (+)= dy * r ; dr[p][0] (+)= sum_c dy*a                                                                   */
+int seg_mul_bcast_bwd(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs,
+                      int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream);
+
+/* ---- ConvLSTM2D/1D, sequence length 1, zero state (unet_variants.py:148): z = [i|f|c|o] (4F channels),
+ * h = hs(o) * tanh(hs(i) * tanh(c)), hs(x) = clip(0.2x+0.5, 0, 1).                                           */
+int seg_convlstm_gate_fwd(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F,
+                          seg_stream_t stream);
+int seg_convlstm_gate_bwd(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix,
+                          int32_t F, seg_stream_t stream);
+
+/* ---- output heads: Conv2D(output_nums, 1x1, activation=final_activation, name='out') (unet_variants.py:1106)
+ * and the deep-supervision Conv2D(1, 1x1, name='level{k}') heads (:136, :282, :340).  Cout <= 8.
+ * y fp32 [npix][Cout] = act(x[p][:Cin] . w[co][:] + b[co]);  w fp32 [Cout][w_ld], input stride (sy, sx).       */
+int seg_head_fwd(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx,
+                 const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y,
+                 seg_stream_t stream);
+/* dy fp32 = gradient wrt the activated output; dx fp16 (+)= (*gs_ptr) * dpre . w ; dw, db += exact fp32 sums   */
+int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H,
+                 int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act,
+                 void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream);
+
+/* ---- losses used by the training harness (2DCNN/Train.py:322, utils/tf_losses.py:4-44): mean reduction.
+ * loss_out[0] += loss ; dpred = d loss / d pred                                                               */
+int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C,
+                     float* loss_out, float* dpred, seg_stream_t stream);
+/* amax[0] = max(amax[0], max |x|)  (amax must be zeroed by the caller)                                         */
+int seg_absmax(const float* x, int64_t n, float* amax, seg_stream_t stream);
+/* gs[0] = 2^k with amax*2^k in [target/2, target), gs[1] = 1/gs[0]  (gs[0] = 1 when amax is 0 or not finite)   */
+int seg_grad_scale(const float* amax, float target, float* gs, seg_stream_t stream);
+
+/* ---- Keras Adam (utils/tf_optimizers.py:11): m,v update; p -= alpha_t * m / (sqrt(v) + eps); alpha_t is
+ * lr*sqrt(1-b2^t)/(1-b1^t) computed by the host.  g is multiplied by gmul first (1/world_size for data
+ * parallel).  Also refreshes the fp16 operand copy p16 (same indexing).  Non-finite gradients are skipped.     */
+int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1,
+                  float b2, float eps, float gmul, seg_stream_t stream);
+/* fp32 [rows][T][K] -> fp16 [K][T][rows_pad] (the data-gradient operand of the same layer)                     */
+int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
+                    seg_stream_t stream);
+/* fp32 -> fp16 cast of n elements                                                                              */
+int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream);
+/* fp32 NHWC [npix][C] -> fp16 [npix][cs] zero padded (model input)                                             */
+int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
+/* fp16 [npix][cs] columns [coff, coff+C) -> fp32 [npix][C]                                                     */
+int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEG_HIP_H */

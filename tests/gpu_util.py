@@ -1,0 +1,189 @@
+"""Helpers for the GPU parity tests: direct C-ABI calls on torch device tensors, and per-node comparison of a
+SegModel against the oracle (torch-CPU fp32)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import keras_ref as K
+from oracle.train_ref import LOSSES
+from ir_interp import run_graph
+
+PKG = "tf-1d-2d-segmentation-end2endpipelines_amd"
+M = importlib.import_module(PKG + ".model")
+ffi = importlib.import_module(PKG + "._ffi")
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def r8(v):
+    return (v + 7) // 8 * 8
+
+
+def r32(v):
+    return (v + 31) // 32 * 32
+
+
+def to_dev_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """fp32 NHWC CPU -> fp16 NHWC cuda with the channel stride padded to 8."""
+    N, H, W, Cc = x.shape
+    t = torch.zeros((N, H, W, r8(Cc)), dtype=torch.float16, device="cuda")
+    t[..., :Cc] = x.to("cuda", torch.float16)
+    return t
+
+
+def h16(x: torch.Tensor) -> torch.Tensor:
+    """round to fp16 and back (the values the GPU kernels actually see)."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0, want_stats=False, tile=None,
+               accumulate_into=None):
+    """xs: list of fp32 NHWC CPU tensors (virtual concat); kern: Keras layout numpy.  Returns (out fp32 NHWC CPU, stats)."""
+    N, H, W, _ = xs[0].shape
+    kh, kw = kern.shape[:2]
+    transposed = kind == "convT"
+    cout = kern.shape[2] if transposed else kern.shape[3]
+    n_rows = r8(cout)
+    devs = [to_dev_nhwc(x) for x in xs]
+    cin_l = [x.shape[3] for x in xs]
+    woff, k = [], 0
+    for d in devs:
+        woff.append(k)
+        k += r32(d.shape[3])
+    Kpad = k
+    E = M.pack_gemm_weight(kern, cin_l, woff, n_rows, Kpad, transposed)
+    w16 = torch.from_numpy(E).to("cuda", torch.float16).contiguous()
+    g = M.geom_convT(N, H, W, kh, kw, *strides) if transposed else M.geom_conv(N, H, W, kh, kw, *strides)
+    Ho, Wo = g.Hout, g.Wout
+    a = ffi.IgemmFwdArgs()
+    a.g = g
+    a.nseg = len(xs)
+    for s, d in enumerate(devs):
+        a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s] = d.shape[3], d.shape[3], woff[s], d.data_ptr()
+    a.w, a.Kpad, a.n_rows, a.n_valid = w16.data_ptr(), Kpad, n_rows, cout
+    if accumulate_into is not None:
+        out = to_dev_nhwc(accumulate_into)
+        a.accumulate = 1
+    else:
+        out = torch.full((N, Ho, Wo, n_rows), 7.0, dtype=torch.float16, device="cuda")
+    a.out, a.out_cs, a.out_coff = out.data_ptr(), n_rows, 0
+    bdev = None
+    if bias is not None:
+        bdev = torch.zeros(n_rows, dtype=torch.float32, device="cuda")
+        bdev[:cout] = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
+        a.bias = bdev.data_ptr()
+    a.act, a.alpha = ffi.ACT[act], alpha
+    Mtot = N * g.Hl * g.Wl
+    tm, tn = tile if tile else M.pick_tile_fwd(Mtot, n_rows, g.ncls)
+    a.tile_m, a.tile_n = tm, tn
+    stats = None
+    if want_stats:
+        nparts = g.ncls * (-(-Mtot // tm))
+        stats = torch.zeros((nparts, 2, n_rows), dtype=torch.float32, device="cuda")
+        a.stats = stats.data_ptr()
+    ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    torch.cuda.synchronize()
+    res = out[..., :cout].float().cpu()
+    pad = out[..., cout:].float().abs().max().item() if n_rows > cout else 0.0
+    return res, (stats.sum(0).cpu() if stats is not None else None), pad
+
+
+def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None):
+    """Returns dW in Keras layout (numpy)."""
+    N, H, W, _ = xs[0].shape
+    kh, kw = kshape[:2]
+    transposed = kind == "convT"
+    cout = kshape[2] if transposed else kshape[3]
+    n_rows = r8(cout)
+    devs = [to_dev_nhwc(x) for x in xs]
+    cin_l = [x.shape[3] for x in xs]
+    woff, k = [], 0
+    for d in devs:
+        woff.append(k)
+        k += r32(d.shape[3])
+    Kpad = k
+    T = kh * kw
+    g = M.geom_convT(N, H, W, kh, kw, *strides) if transposed else M.geom_conv(N, H, W, kh, kw, *strides)
+    dzd = to_dev_nhwc(dz)
+    dw = torch.zeros(n_rows * T * Kpad, dtype=torch.float32, device="cuda")
+    a = ffi.IgemmWgradArgs()
+    a.g = g
+    a.nseg = len(xs)
+    for s, d in enumerate(devs):
+        a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s] = d.shape[3], d.shape[3], woff[s], d.data_ptr()
+    a.dz, a.dz_cs, a.dz_coff = dzd.data_ptr(), dzd.shape[3], 0
+    a.dw, a.Kpad, a.n_rows = dw.data_ptr(), Kpad, n_rows
+    Mtot = N * g.Hl * g.Wl
+    tm, tn, sk = M.pick_tile_wgrad(Mtot, n_rows, [d.shape[3] for d in devs], g.ncls * g.ntaps)
+    if tile:
+        tm, tn = tile
+    a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)
+    a.scale, a.scale_ptr, a.variant = 1.0, None, variant
+    ffi.call("seg_igemm_wgrad", C.byref(a), stream())
+    torch.cuda.synchronize()
+    return M.unpack_gemm_weight(dw.cpu().numpy(), kshape, cin_l, woff, n_rows, Kpad, transposed)
+
+
+def ref_conv(xs, kern, bias, kind, strides):
+    x = torch.cat([h16(t) for t in xs], -1)
+    k = h16(torch.from_numpy(np.asarray(kern, np.float32)))
+    b = torch.from_numpy(np.asarray(bias, np.float32)) if bias is not None else None
+    if kind == "convT":
+        return K.conv2d_transpose_same(x, k, b, strides)
+    return K.conv2d_same(x, k, b, strides)
+
+
+# ------------------------------------------------------------------------------------------------ whole-model compare
+def compare_model(model, x, targets, loss, verbose=False):
+    """Runs forward(training) + loss + backward on the GPU model and on the oracle primitives wired by the same
+    graph (the wiring itself is checked against the independent oracle wiring in test_graph_builders.py).
+    Returns dict with per-node forward errors (max abs), loss pair and per-parameter relative gradient errors."""
+    g = model.graph
+    w_np = model.get_weights()
+    W = {k: torch.from_numpy(v.copy()).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
+         for k, v in w_np.items()}
+    outs_ref, vals = run_graph(g, x, W, training=True, return_all=True)
+    lossf = LOSSES[loss]
+    ref_loss = sum(lossf(o, t) for o, t in zip(outs_ref, targets))
+    ref_loss.backward()
+    outs = model.forward(x, training=True)
+    lv = model.compute_loss(targets, loss)
+    model.backward(None)
+    torch.cuda.synchronize()
+    res = {"nodes": [], "loss": (float(lv.cpu()), float(ref_loss.detach())), "grads": {}, "outs": []}
+    for name, t in model.tensors.items():
+        key = name[:-2] if name.endswith(":z") else name
+        if key not in vals:
+            continue
+        ref = vals[key].detach()
+        got = t.buf[..., :t.C].float().cpu()
+        if got.shape != ref.shape:
+            res["nodes"].append((name, float("nan"), float(ref.abs().max())))
+            continue
+        res["nodes"].append((name, float((got - ref).abs().max()), float(ref.abs().max())))
+    for o, r in zip(outs, outs_ref):
+        res["outs"].append(float((o.cpu() - r.detach()).abs().max()))
+    grads = model.get_grads()
+    for k, t in W.items():
+        if t.grad is None or k not in grads:
+            continue
+        gr = t.grad.numpy()
+        den = float(np.abs(gr).max())
+        res["grads"][k] = (float(np.abs(grads[k] - gr).max()), den)
+    if verbose:
+        for n, e, mag in res["nodes"]:
+            print(f"   node {n:34s} max|err| {e:.3e}  (ref max {mag:.3e})")
+        print("   outs", ["%.3e" % e for e in res["outs"]], "loss", res["loss"])
+        worst = sorted(res["grads"].items(), key=lambda kv: -(kv[1][0] / (kv[1][1] + 1e-20)))
+        for k, (e, d) in worst[:12]:
+            print(f"   grad {k:40s} abs err {e:.3e} / max {d:.3e} = {e / (d + 1e-20):.3e}")
+    return res

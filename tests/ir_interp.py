@@ -9,7 +9,7 @@ import torch
 from oracle import keras_ref as K
 
 
-def run_graph(g, x: torch.Tensor, weights: Dict[str, torch.Tensor], training=True) -> List[torch.Tensor]:
+def run_graph(g, x: torch.Tensor, weights: Dict[str, torch.Tensor], training=True, return_all=False):
     if g.ndim == 1 and x.dim() == 3:
         x = x.unsqueeze(1)
     vals = {}
@@ -53,4 +53,6 @@ def run_graph(g, x: torch.Tensor, weights: Dict[str, torch.Tensor], training=Tru
     outs = [vals[i] for i in g.outputs]
     if g.ndim == 1:
         outs = [o.squeeze(1) for o in outs]
+    if return_all:
+        return outs, {g.nodes[i].name: v for i, v in vals.items()}
     return outs

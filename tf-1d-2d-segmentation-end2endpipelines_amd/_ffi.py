@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/seg_hip.h (libseg_hip.so, built in-tree by build_ext.py).
+
+There is deliberately no fallback: if the shared library is missing or a symbol cannot be resolved the
+import of the *engine* fails loudly (graph construction does not need this module)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseg_hip.so")
+
+MAX_SEG, MAX_TAPS, MAX_CLS = 8, 16, 4
+ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "leaky_relu": 2, "sigmoid": 3, "softmax": 4}
+LOSS = {"mse": 0, "bce": 1, "cce": 2}
+
+
+class Geom(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hl", C.c_int32), ("Wl", C.c_int32),
+                ("isy", C.c_int32), ("isx", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+                ("osy", C.c_int32), ("osx", C.c_int32), ("ncls", C.c_int32), ("ntaps", C.c_int32),
+                ("T_total", C.c_int32), ("oy", C.c_int32 * MAX_CLS), ("ox", C.c_int32 * MAX_CLS),
+                ("tap_dy", C.c_int32 * MAX_TAPS), ("tap_dx", C.c_int32 * MAX_TAPS), ("tap_w", C.c_int32 * MAX_TAPS)]
+
+
+class IgemmFwdArgs(C.Structure):
+    _fields_ = [("g", Geom), ("nseg", C.c_int32), ("seg_c", C.c_int32 * MAX_SEG), ("seg_cs", C.c_int32 * MAX_SEG),
+                ("seg_woff", C.c_int32 * MAX_SEG), ("seg_ptr", C.c_void_p * MAX_SEG), ("w", C.c_void_p),
+                ("Kpad", C.c_int32), ("n_rows", C.c_int32), ("n_valid", C.c_int32), ("out", C.c_void_p),
+                ("out_cs", C.c_int32), ("out_coff", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
+                ("alpha", C.c_float), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("tile_m", C.c_int32),
+                ("tile_n", C.c_int32)]
+
+
+class IgemmWgradArgs(C.Structure):
+    _fields_ = [("g", Geom), ("nseg", C.c_int32), ("seg_c", C.c_int32 * MAX_SEG), ("seg_cs", C.c_int32 * MAX_SEG),
+                ("seg_woff", C.c_int32 * MAX_SEG), ("seg_ptr", C.c_void_p * MAX_SEG), ("dz", C.c_void_p),
+                ("dz_cs", C.c_int32), ("dz_coff", C.c_int32), ("dw", C.c_void_p), ("Kpad", C.c_int32),
+                ("n_rows", C.c_int32), ("splitk", C.c_int32), ("scale", C.c_float), ("scale_ptr", C.c_void_p),
+                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("variant", C.c_int32)]
+
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+_PROTOS = {
+    "seg_abi_version": ([], C.c_int),
+    "seg_igemm_fwd": ([C.POINTER(IgemmFwdArgs), vp], C.c_int),
+    "seg_igemm_wgrad": ([C.POINTER(IgemmWgradArgs), vp], C.c_int),
+    "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
+    "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
+    "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),
+    "seg_bn_act_bwd_reduce": ([vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, f32, vp, i32, vp], C.c_int),
+    "seg_bn_bwd_finalize": ([vp, i32, i32, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),
+    "seg_bn_act_bwd_apply": ([vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp], C.c_int),
+    "seg_act_bwd": ([vp, vp, vp, i64, i32, i32, i32, f32, vp, f32, vp, vp], C.c_int),
+    "seg_maxpool_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], C.c_int),
+    "seg_maxpool_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
+    "seg_upsample_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
+    "seg_upsample_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
+    "seg_add_act_fwd": ([C.POINTER(vp), i32, vp, i64, i32, f32, vp], C.c_int),
+    "seg_add_act_bwd": ([vp, vp, C.POINTER(vp), i32, i64, i32, f32, i32, vp], C.c_int),
+    "seg_mul_bcast_fwd": ([vp, vp, vp, i64, i32, i32, vp], C.c_int),
+    "seg_mul_bcast_bwd": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp], C.c_int),
+    "seg_convlstm_gate_fwd": ([vp, i32, vp, i32, i64, i32, vp], C.c_int),
+    "seg_convlstm_gate_bwd": ([vp, i32, vp, i32, vp, i64, i32, vp], C.c_int),
+    "seg_head_fwd": ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp], C.c_int),
+    "seg_head_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], C.c_int),
+    "seg_loss_fwd_bwd": ([i32, vp, vp, i64, i32, vp, vp, vp], C.c_int),
+    "seg_absmax": ([vp, i64, vp, vp], C.c_int),
+    "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),
+    "seg_adam_step": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp], C.c_int),
+    "seg_transpose_w": ([vp, vp, i32, i32, i32, i32, vp], C.c_int),
+    "seg_cast_f32_f16": ([vp, vp, i64, vp], C.c_int),
+    "seg_pack_input": ([vp, vp, i64, i32, i32, vp], C.c_int),
+    "seg_unpack_f32": ([vp, vp, i64, i32, i32, i32, vp], C.c_int),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS) + ("seg_last_error",)
+
+_lib = None
+
+
+class SegHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libseg_hip.so once.  Raises (never falls back) when the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (argt, rest) in _PROTOS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing -> loud failure
+            fn.argtypes = argt
+            fn.restype = rest
+        L.seg_last_error.argtypes = []
+        L.seg_last_error.restype = C.c_char_p
+        if L.seg_abi_version() != 1:
+            raise ImportError("libseg_hip.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().seg_last_error()
+        raise SegHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)

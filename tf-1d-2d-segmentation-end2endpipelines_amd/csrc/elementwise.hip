@@ -1,0 +1,1297 @@
+// HBM-bound kernels of the UNet-family hot path for gfx950: BatchNormalization (statistics, apply + activation
+// [+ fused max-pool], backward), activations, pooling, up-sampling, add / gating multiply, ConvLSTM(T=1) gates,
+// 1x1 output heads, losses, Adam, weight repacking.  All tensors NHWC fp16 with 16-B (8-channel) vector access:
+// consecutive lanes read consecutive 16-B chunks of a pixel row, so every wave instruction touches whole
+// 128-B lines.  Per-channel reductions use a (rows x chunk-columns) thread layout with register partials,
+// an LDS cross-row reduction and one deterministic partial row per block.
+#include "seg_common.h"
+#include <stdarg.h>
+
+// ------------------------------------------------------------------------------------------------ error state
+static thread_local char g_err[512] = "";
+void seg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* seg_last_error(void) { return g_err; }
+extern "C" int seg_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAX_BLOCKS = 2048;
+
+inline int grid_for(int64_t items) {
+  int64_t b = (items + TPB - 1) / TPB;
+  if (b < 1) b = 1;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  return (int)b;
+}
+inline int pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// (rows x chunk-columns) layout for per-channel reductions over pixels.
+struct ColLayout {
+  int CH;    // 16-B chunks per pixel that take part
+  int CHP;   // chunk columns per block pass (power of two, <= 256)
+  int RP;    // pixel rows per block pass = 256 / CHP
+  int ngrp;  // ceil(CH / CHP) column groups
+};
+inline ColLayout col_layout(int C) {
+  ColLayout l;
+  l.CH = C / 8;
+  l.CHP = pow2ceil(l.CH);
+  if (l.CHP > TPB) l.CHP = TPB;
+  l.RP = TPB / l.CHP;
+  l.ngrp = (l.CH + l.CHP - 1) / l.CHP;
+  return l;
+}
+
+// Reduce NV per-thread vectors of 8 floats across the RP row-groups of the block and hand the result for chunk
+// column `col` to thread row 0.  sm must hold TPB * 8 floats.
+template <int NV>
+__device__ __forceinline__ void block_col_reduce(float (&v)[NV][8], float* sm, int rowi, int col, int CHP, int RP) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sm[(rowi * CHP + col) * 8 + t] = v[k][t];
+    __syncthreads();
+    if (rowi == 0) {
+      for (int r = 1; r < RP; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[k][t] += sm[(r * CHP + col) * 8 + t];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN statistics
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const half_t* x, int64_t npix, int cs, int coff, int C, float* stats,
+                                                       int nparts, int stats_ld, int stats_coff, ColLayout L) {
+  __shared__ float sm[TPB * 8];
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int part = blockIdx.x;
+  int64_t per = (npix + nparts - 1) / nparts;
+  const int64_t p0 = part * per, p1 = min(npix, p0 + per);
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    float acc[2][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
+    if (ch < L.CH) {
+      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
+        float f[8];
+        unpack8(ld16(x + pix * cs + coff + ch * 8), f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { acc[0][t] += f[t]; acc[1][t] += f[t] * f[t]; }
+      }
+    }
+    block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
+    if (rowi == 0 && ch < L.CH) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        stats[((size_t)part * 2 + 0) * stats_ld + stats_coff + ch * 8 + t] = acc[0][t];
+        stats[((size_t)part * 2 + 1) * stats_ld + stats_coff + ch * 8 + t] = acc[1][t];
+      }
+    }
+  }
+}
+
+// fold parts {s, s+S, s+2S, ...} into part s, in place (deterministic order)
+__global__ __launch_bounds__(TPB) void bn_prereduce_kernel(float* stats, int nparts, int C, int S) {
+  __shared__ float sm[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5, s = blockIdx.y;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C)
+    for (int p = s + pl * S; p < nparts; p += 8 * S) {
+      a0 += stats[((size_t)p * 2 + 0) * C + c];
+      a1 += stats[((size_t)p * 2 + 1) * C + c];
+    }
+  sm[0][pl][threadIdx.x & 31] = a0;
+  sm[1][pl][threadIdx.x & 31] = a1;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    for (int k = 1; k < 8; ++k) { a0 += sm[0][k][threadIdx.x & 31]; a1 += sm[1][k][threadIdx.x & 31]; }
+    stats[((size_t)s * 2 + 0) * C + c] = a0;
+    stats[((size_t)s * 2 + 1) * C + c] = a1;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* stats, int nparts, int C, float inv_count, float unbias,
+                                                          const float* gamma, const float* beta, float eps, float momentum,
+                                                          float* mmean, float* mvar, int training, float* mean_o, float* invstd_o,
+                                                          float* scale_o, float* shift_o) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < nparts; ++p) { s += stats[((size_t)p * 2 + 0) * C + c]; q += stats[((size_t)p * 2 + 1) * C + c]; }
+    mean = s * inv_count;
+    var = fmaxf(q * inv_count - mean * mean, 0.f);
+    mmean[c] = mmean[c] * momentum + mean * (1.f - momentum);
+    mvar[c] = mvar[c] * momentum + var * unbias * (1.f - momentum);
+  } else {
+    mean = mmean[c];
+    var = mvar[c];
+  }
+  const float invstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  if (mean_o) mean_o[c] = mean;
+  if (invstd_o) invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] - mean * sc;
+}
+
+// ------------------------------------------------------------------------------------------------ BN apply (+pool)
+__global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const half_t* x, int x_cs, int x_coff, half_t* y, int y_cs, int y_coff,
+                                                           int64_t npix, int C, int c_valid, const float* scale, const float* shift,
+                                                           int act, float alpha) {
+  const int CH = C / 8;
+  const int64_t items = npix * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    const int64_t pix = it / CH;
+    const int ch = (int)(it - pix * CH);
+    float f[8];
+    unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = ch * 8 + t;
+      float v = seg_act(f[t] * scale[c] + shift[c], act, alpha);
+      f[t] = c < c_valid ? v : 0.f;
+    }
+    st16(y + pix * y_cs + y_coff + ch * 8, pack8(f));
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const half_t* x, int x_cs, int x_coff, half_t* y, int y_cs,
+                                                                int y_coff, int N, int H, int W, int C, int c_valid,
+                                                                const float* scale, const float* shift, int act, float alpha,
+                                                                half_t* pooled, int ph, int pw) {
+  const int CH = C / 8;
+  const int HP = H / ph, WP = W / pw;                  // pooled extent ('valid')
+  const int HB = (H + ph - 1) / ph, WB = (W + pw - 1) / pw;   // windows incl. ragged border (no pooled output there)
+  const int64_t items = (int64_t)N * HB * WB * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    int64_t r = it;
+    const int ch = (int)(r % CH); r /= CH;
+    const int wb = (int)(r % WB); r /= WB;
+    const int hb = (int)(r % HB);
+    const int n = (int)(r / HB);
+    float sc[8], sh[8], mx[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { sc[t] = scale[ch * 8 + t]; sh[t] = shift[ch * 8 + t]; mx[t] = -3.0e38f; }
+    for (int dy = 0; dy < ph; ++dy)
+      for (int dx = 0; dx < pw; ++dx) {
+        const int yy = hb * ph + dy, xx = wb * pw + dx;
+        if (yy >= H || xx >= W) continue;
+        const int64_t pix = ((int64_t)n * H + yy) * W + xx;
+        float f[8];
+        unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          float v = seg_act(f[t] * sc[t] + sh[t], act, alpha);
+          v = (ch * 8 + t) < c_valid ? v : 0.f;
+          f[t] = v;
+        }
+        const u4 pk = pack8(f);
+        st16(y + pix * y_cs + y_coff + ch * 8, pk);
+        float fr[8];
+        unpack8(pk, fr);   // pool the ROUNDED values so that pooled == max of the stored fp16 tensor
+#pragma unroll
+        for (int t = 0; t < 8; ++t) mx[t] = fmaxf(mx[t], fr[t]);
+      }
+    if (hb < HP && wb < WP) {
+      const int64_t pp = ((int64_t)n * HP + hb) * WP + wb;
+      st16(pooled + pp * y_cs + ch * 8, pack8(mx));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN backward
+__global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const half_t* dy, int dy_cs, int dy_coff, const half_t* x, int x_cs,
+                                                                int x_coff, int64_t npix, int C, const float* scale,
+                                                                const float* shift, const float* mean, const float* invstd, int act,
+                                                                float alpha, float* partial, int nparts, ColLayout L) {
+  __shared__ float sm[TPB * 8];
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int part = blockIdx.x;
+  const int64_t per = (npix + nparts - 1) / nparts;
+  const int64_t p0 = part * per, p1 = min(npix, p0 + per);
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    float acc[2][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
+    if (ch < L.CH) {
+      float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c = ch * 8 + t;
+        sc[t] = scale[c]; sh[t] = shift[c]; mu[t] = mean[c]; is[t] = invstd[c];
+      }
+      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
+        float g[8], xv[8];
+        unpack8(ld16(dy + pix * dy_cs + dy_coff + ch * 8), g);
+        unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), xv);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float yv = seg_act(xv[t] * sc[t] + sh[t], act, alpha);
+          const float gg = g[t] * seg_act_grad_from_out(yv, act, alpha);
+          acc[0][t] += gg;
+          acc[1][t] += gg * (xv[t] - mu[t]) * is[t];
+        }
+      }
+    }
+    block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
+    if (rowi == 0 && ch < L.CH) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        partial[((size_t)part * 2 + 0) * C + ch * 8 + t] = acc[0][t];
+        partial[((size_t)part * 2 + 1) * C + ch * 8 + t] = acc[1][t];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* partial, int nparts, int C, float inv_count, float* dgamma,
+                                                              float* dbeta, float gscale, const float* gscale_ptr, float* c1,
+                                                              float* c2) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int p = 0; p < nparts; ++p) { s += partial[((size_t)p * 2 + 0) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
+  float gs = gscale;
+  if (gscale_ptr) gs *= *gscale_ptr;
+  if (dbeta) dbeta[c] += s * gs;
+  if (dgamma) dgamma[c] += q * gs;
+  c1[c] = s * inv_count;
+  c2[c] = q * inv_count;
+}
+
+__global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const half_t* dy, int dy_cs, int dy_coff, const half_t* x, int x_cs,
+                                                               int x_coff, half_t* dx, int dx_cs, int dx_coff, int64_t npix, int C,
+                                                               const float* scale, const float* shift, const float* mean,
+                                                               const float* invstd, const float* c1, const float* c2, int act,
+                                                               float alpha, int accumulate) {
+  const int CH = C / 8;
+  const int64_t items = npix * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    const int64_t pix = it / CH;
+    const int ch = (int)(it - pix * CH);
+    float g[8], xv[8], o[8];
+    unpack8(ld16(dy + pix * dy_cs + dy_coff + ch * 8), g);
+    unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), xv);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = ch * 8 + t;
+      const float sc = scale[c];
+      const float yv = seg_act(xv[t] * sc + shift[c], act, alpha);
+      float gg = g[t] * seg_act_grad_from_out(yv, act, alpha);
+      if (c1 != nullptr) gg = gg - c1[c] - (xv[t] - mean[c]) * invstd[c] * c2[c];
+      o[t] = gg * sc;
+    }
+    half_t* dst = dx + pix * dx_cs + dx_coff + ch * 8;
+    if (accumulate) {
+      float old[8];
+      unpack8(ld16(dst), old);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] += old[t];
+    }
+    st16(dst, pack8(o));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ activation backward
+__global__ __launch_bounds__(TPB) void act_bwd_kernel(const half_t* dy, const half_t* y, half_t* dx, int64_t npix, int cs, int C,
+                                                      int act, float alpha, float* dbias, float gscale, const float* gscale_ptr,
+                                                      ColLayout L) {
+  __shared__ float sm[TPB * 8];
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  float gs = gscale;
+  if (gscale_ptr) gs *= *gscale_ptr;
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    float acc[1][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[0][t] = 0.f;
+    if (ch < L.CH) {
+      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
+        float g[8], yv[8];
+        unpack8(ld16(dy + pix * cs + ch * 8), g);
+        unpack8(ld16(y + pix * cs + ch * 8), yv);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          g[t] *= seg_act_grad_from_out(yv[t], act, alpha);
+          acc[0][t] += g[t];
+        }
+        st16(dx + pix * cs + ch * 8, pack8(g));
+      }
+    }
+    if (dbias != nullptr) {
+      block_col_reduce<1>(acc, sm, rowi, col, L.CHP, L.RP);
+      if (rowi == 0 && ch < L.CH) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (ch * 8 + t < C) atomicAdd(dbias + ch * 8 + t, acc[0][t] * gs);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ max pooling
+__global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int cs, int ph, int pw) {
+  const int CH = cs / 8, HP = H / ph, WP = W / pw;
+  const int64_t items = (int64_t)N * HP * WP * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    int64_t r = it;
+    const int ch = (int)(r % CH); r /= CH;
+    const int wp = (int)(r % WP); r /= WP;
+    const int hp = (int)(r % HP);
+    const int n = (int)(r / HP);
+    float mx[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mx[t] = -3.0e38f;
+    for (int dy = 0; dy < ph; ++dy)
+      for (int dx = 0; dx < pw; ++dx) {
+        float f[8];
+        unpack8(ld16(x + (((int64_t)n * H + hp * ph + dy) * W + wp * pw + dx) * cs + ch * 8), f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) mx[t] = fmaxf(mx[t], f[t]);
+      }
+    st16(y + it * 8, pack8(mx));
+  }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const half_t* dy, const half_t* x, const half_t* y, half_t* dx, int N, int H,
+                                                          int W, int cs, int ph, int pw, int accumulate) {
+  const int CH = cs / 8, HP = H / ph, WP = W / pw;
+  const int HB = (H + ph - 1) / ph, WB = (W + pw - 1) / pw;
+  const int64_t items = (int64_t)N * HB * WB * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    int64_t r = it;
+    const int ch = (int)(r % CH); r /= CH;
+    const int wb = (int)(r % WB); r /= WB;
+    const int hb = (int)(r % HB);
+    const int n = (int)(r / HB);
+    const bool full = hb < HP && wb < WP;
+    float g[8], mx[8];
+    bool done[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { g[t] = 0.f; mx[t] = 0.f; done[t] = false; }
+    if (full) {
+      const int64_t pp = ((int64_t)n * HP + hb) * WP + wb;
+      unpack8(ld16(dy + pp * cs + ch * 8), g);
+      unpack8(ld16(y + pp * cs + ch * 8), mx);
+    }
+    for (int dyy = 0; dyy < ph; ++dyy)
+      for (int dxx = 0; dxx < pw; ++dxx) {
+        const int yy = hb * ph + dyy, xx = wb * pw + dxx;
+        if (yy >= H || xx >= W) continue;
+        half_t* dst = dx + (((int64_t)n * H + yy) * W + xx) * cs + ch * 8;
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = 0.f;
+        if (full) {
+          float f[8];
+          unpack8(ld16(x + (((int64_t)n * H + yy) * W + xx) * cs + ch * 8), f);
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (!done[t] && f[t] == mx[t]) { o[t] = g[t]; done[t] = true; }
+        }
+        if (accumulate) {
+          float old[8];
+          unpack8(ld16(dst), old);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) o[t] += old[t];
+        }
+        st16(dst, pack8(o));
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ up-sampling
+__device__ __forceinline__ void bilin_src(int o, int f, int n_in, int& i0, int& i1, float& w1) {
+  const float src = (o + 0.5f) / (float)f - 0.5f;
+  const float fl = floorf(src);
+  w1 = src - fl;
+  int a = (int)fl;
+  i0 = min(max(a, 0), n_in - 1);
+  i1 = min(max(a + 1, 0), n_in - 1);
+}
+
+__global__ __launch_bounds__(TPB) void upsample_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int cs, int fh, int fw,
+                                                           int bilinear) {
+  const int CH = cs / 8, HO = H * fh, WO = W * fw;
+  const int64_t items = (int64_t)N * HO * WO * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    int64_t r = it;
+    const int ch = (int)(r % CH); r /= CH;
+    const int xo = (int)(r % WO); r /= WO;
+    const int yo = (int)(r % HO);
+    const int n = (int)(r / HO);
+    float o[8];
+    if (bilinear) {
+      int y0, y1, x0, x1;
+      float wy, wx;
+      bilin_src(yo, fh, H, y0, y1, wy);
+      bilin_src(xo, fw, W, x0, x1, wx);
+      float a[8], b[8], c[8], d[8];
+      const half_t* base = x + (int64_t)n * H * W * cs + ch * 8;
+      unpack8(ld16(base + ((int64_t)y0 * W + x0) * cs), a);
+      unpack8(ld16(base + ((int64_t)y0 * W + x1) * cs), b);
+      unpack8(ld16(base + ((int64_t)y1 * W + x0) * cs), c);
+      unpack8(ld16(base + ((int64_t)y1 * W + x1) * cs), d);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float top = a[t] + (b[t] - a[t]) * wx, bot = c[t] + (d[t] - c[t]) * wx;
+        o[t] = top + (bot - top) * wy;
+      }
+    } else {
+      unpack8(ld16(x + (((int64_t)n * H + yo / fh) * W + xo / fw) * cs + ch * 8), o);
+    }
+    st16(y + it * 8, pack8(o));
+  }
+}
+
+// gather form of the transpose: every input pixel sums the output pixels whose footprint contains it
+__global__ __launch_bounds__(TPB) void upsample_bwd_kernel(const half_t* dy, half_t* dx, int N, int H, int W, int cs, int fh, int fw,
+                                                           int bilinear, int accumulate) {
+  const int CH = cs / 8, HO = H * fh, WO = W * fw;
+  const int64_t items = (int64_t)N * H * W * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    int64_t r = it;
+    const int ch = (int)(r % CH); r /= CH;
+    const int xi = (int)(r % W); r /= W;
+    const int yi = (int)(r % H);
+    const int n = (int)(r / H);
+    float o[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = 0.f;
+    const half_t* base = dy + (int64_t)n * HO * WO * cs + ch * 8;
+    if (bilinear) {
+      const int ylo = max(0, (yi - 1) * fh), yhi = min(HO, (yi + 2) * fh);
+      const int xlo = max(0, (xi - 1) * fw), xhi = min(WO, (xi + 2) * fw);
+      for (int yo = ylo; yo < yhi; ++yo) {
+        int y0, y1; float wy;
+        bilin_src(yo, fh, H, y0, y1, wy);
+        const float cy = (y0 == yi ? 1.f - wy : 0.f) + (y1 == yi ? wy : 0.f);
+        if (cy == 0.f) continue;
+        for (int xo = xlo; xo < xhi; ++xo) {
+          int x0, x1; float wx;
+          bilin_src(xo, fw, W, x0, x1, wx);
+          const float cx = (x0 == xi ? 1.f - wx : 0.f) + (x1 == xi ? wx : 0.f);
+          if (cx == 0.f) continue;
+          float g[8];
+          unpack8(ld16(base + ((int64_t)yo * WO + xo) * cs), g);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) o[t] += g[t] * (cy * cx);
+        }
+      }
+    } else {
+      for (int a = 0; a < fh; ++a)
+        for (int b = 0; b < fw; ++b) {
+          float g[8];
+          unpack8(ld16(base + ((int64_t)(yi * fh + a) * WO + xi * fw + b) * cs), g);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) o[t] += g[t];
+        }
+    }
+    half_t* dst = dx + it * 8;
+    if (accumulate) {
+      float old[8];
+      unpack8(ld16(dst), old);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] += old[t];
+    }
+    st16(dst, pack8(o));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ add / mul
+struct Ptr4 { const half_t* p[4]; };
+struct MPtr4 { half_t* p[4]; };
+
+__global__ __launch_bounds__(TPB) void add_act_fwd_kernel(Ptr4 xs, int n, half_t* y, int64_t nchunks, int act, float alpha) {
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < nchunks; it += (int64_t)gridDim.x * TPB) {
+    float o[8];
+    unpack8(ld16(xs.p[0] + it * 8), o);
+    for (int k = 1; k < n; ++k) {
+      float f[8];
+      unpack8(ld16(xs.p[k] + it * 8), f);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] += f[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = seg_act(o[t], act, alpha);
+    st16(y + it * 8, pack8(o));
+  }
+}
+
+__global__ __launch_bounds__(TPB) void add_act_bwd_kernel(const half_t* dy, const half_t* y, MPtr4 dxs, int n, int64_t nchunks, int act,
+                                                          float alpha, int accmask) {
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < nchunks; it += (int64_t)gridDim.x * TPB) {
+    float g[8];
+    unpack8(ld16(dy + it * 8), g);
+    if (act != SEG_ACT_NONE) {
+      float yv[8];
+      unpack8(ld16(y + it * 8), yv);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) g[t] *= seg_act_grad_from_out(yv[t], act, alpha);
+    }
+    for (int k = 0; k < n; ++k) {
+      if (dxs.p[k] == nullptr) continue;
+      float o[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] = g[t];
+      if (accmask & (1 << k)) {
+        float old[8];
+        unpack8(ld16(dxs.p[k] + it * 8), old);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] += old[t];
+      }
+      st16(dxs.p[k] + it * 8, pack8(o));
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void mul_bcast_fwd_kernel(const half_t* a, const half_t* r, half_t* y, int64_t npix, int cs, int r_cs) {
+  const int CH = cs / 8;
+  const int64_t items = npix * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    const int64_t pix = it / CH;
+    const float rv = (float)r[pix * r_cs];
+    float f[8];
+    unpack8(ld16(a + it * 8), f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] *= rv;
+    st16(y + it * 8, pack8(f));
+  }
+}
+
+// one group of LPP lanes per pixel (LPP = power of two <= 64); dr needs the sum over all channels of the pixel
+__global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const half_t* dy, const half_t* a, const half_t* r, half_t* da, half_t* dr,
+                                                            int64_t npix, int cs, int r_cs, int acc_a, int acc_r, int LPP) {
+  const int CH = cs / 8;
+  const int gpb = TPB / LPP;
+  const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+  for (int64_t pix0 = (int64_t)blockIdx.x * gpb; pix0 < npix; pix0 += (int64_t)gridDim.x * gpb) {
+    const int64_t pix = pix0 + grp;
+    const bool ok = pix < npix;
+    float dot = 0.f;
+    const float rv = ok ? (float)r[pix * r_cs] : 0.f;
+    for (int ch = sub; ch < CH; ch += LPP) {
+      if (!ok) break;
+      float g[8], av[8], o[8];
+      unpack8(ld16(dy + pix * cs + ch * 8), g);
+      unpack8(ld16(a + pix * cs + ch * 8), av);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { dot += g[t] * av[t]; o[t] = g[t] * rv; }
+      if (da != nullptr) {
+        half_t* dst = da + pix * cs + ch * 8;
+        if (acc_a) {
+          float old[8];
+          unpack8(ld16(dst), old);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) o[t] += old[t];
+        }
+        st16(dst, pack8(o));
+      }
+    }
+    for (int o = LPP >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (ok && sub == 0 && dr != nullptr) {
+      float f[8] = {dot, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      half_t* dst = dr + pix * r_cs;
+      if (acc_r) f[0] += (float)dst[0];
+      if (r_cs >= 8) st16(dst, pack8(f));
+      else dst[0] = (half_t)f[0];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ConvLSTM (T = 1) gates
+__device__ __forceinline__ float hsig(float v) { return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float hsig_grad(float v) { return (v > -2.5f && v < 2.5f) ? 0.2f : 0.f; }
+
+__global__ __launch_bounds__(TPB) void convlstm_gate_fwd_kernel(const half_t* z, int z_cs, half_t* h, int h_cs, int64_t npix, int F) {
+  const int CH = F / 8;
+  const int64_t items = npix * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    const int64_t pix = it / CH;
+    const int ch = (int)(it - pix * CH);
+    float zi[8], zc[8], zo[8], o[8];
+    const half_t* zp = z + pix * z_cs + ch * 8;
+    unpack8(ld16(zp), zi);
+    unpack8(ld16(zp + 2 * F), zc);
+    unpack8(ld16(zp + 3 * F), zo);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = hsig(zo[t]) * tanhf(hsig(zi[t]) * tanhf(zc[t]));
+    st16(h + pix * h_cs + ch * 8, pack8(o));
+  }
+}
+
+__global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const half_t* dh, int h_cs, const half_t* z, int z_cs, half_t* dz,
+                                                                int64_t npix, int F) {
+  const int CH = F / 8;
+  const int64_t items = npix * CH;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
+    const int64_t pix = it / CH;
+    const int ch = (int)(it - pix * CH);
+    float zi[8], zc[8], zo[8], g[8], di[8], dc[8], dO[8], zero[8];
+    const half_t* zp = z + pix * z_cs + ch * 8;
+    unpack8(ld16(zp), zi);
+    unpack8(ld16(zp + 2 * F), zc);
+    unpack8(ld16(zp + 3 * F), zo);
+    unpack8(ld16(dh + pix * h_cs + ch * 8), g);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float a = hsig(zi[t]), b = tanhf(zc[t]), u = a * b, tu = tanhf(u), o = hsig(zo[t]);
+      dO[t] = g[t] * tu * hsig_grad(zo[t]);
+      const float du = g[t] * o * (1.f - tu * tu);
+      di[t] = du * b * hsig_grad(zi[t]);
+      dc[t] = du * a * (1.f - b * b);
+      zero[t] = 0.f;
+    }
+    half_t* dp = dz + pix * z_cs + ch * 8;
+    st16(dp, pack8(di));
+    st16(dp + F, pack8(zero));
+    st16(dp + 2 * F, pack8(dc));
+    st16(dp + 3 * F, pack8(dO));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 1x1 heads (Cout <= 8)
+constexpr int HEAD_MAXC = 8;
+
+__global__ __launch_bounds__(TPB) void head_fwd_kernel(const half_t* x, int cs, int Cin, int N, int H, int W, int sy, int sx,
+                                                       const float* w, int w_ld, const float* b, int Cout, int act, float* y, int LPP) {
+  const int CH = (Cin + 7) / 8;
+  const int HO = (H + sy - 1) / sy, WO = (W + sx - 1) / sx;
+  const int64_t npix = (int64_t)N * HO * WO;
+  const int gpb = TPB / LPP;
+  const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+  for (int64_t pix0 = (int64_t)blockIdx.x * gpb; pix0 < npix; pix0 += (int64_t)gridDim.x * gpb) {
+    const int64_t pix = pix0 + grp;
+    const bool ok = pix < npix;
+    float acc[HEAD_MAXC];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k) acc[k] = 0.f;
+    if (ok) {
+      const int xo = (int)(pix % WO);
+      const int yo = (int)((pix / WO) % HO);
+      const int n = (int)(pix / ((int64_t)WO * HO));
+      const half_t* xp = x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+      for (int ch = sub; ch < CH; ch += LPP) {
+        float f[8];
+        unpack8(ld16(xp + ch * 8), f);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k)
+          if (k < Cout) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (ch * 8 + t < Cin) acc[k] += f[t] * w[k * w_ld + ch * 8 + t];
+          }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k)
+      for (int o = LPP >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (ok && sub == 0) {
+      float v[HEAD_MAXC];
+#pragma unroll
+      for (int k = 0; k < HEAD_MAXC; ++k) v[k] = (k < Cout) ? acc[k] + (b ? b[k] : 0.f) : -3.0e38f;
+      if (act == SEG_ACT_SOFTMAX) {
+        float mx = v[0];
+#pragma unroll
+        for (int k = 1; k < HEAD_MAXC; ++k) mx = fmaxf(mx, v[k]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k) { v[k] = (k < Cout) ? __expf(v[k] - mx) : 0.f; s += v[k]; }
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k) v[k] *= inv;
+      } else {
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k) v[k] = seg_act(v[k], act, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < HEAD_MAXC; ++k)
+        if (k < Cout) y[pix * Cout + k] = v[k];
+    }
+  }
+}
+
+// gradient of the pre-activation given dy (wrt activated y) and y
+__device__ __forceinline__ void head_dpre(const float* dy, const float* y, int Cout, int act, float* d) {
+  if (act == SEG_ACT_SOFTMAX) {
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k)
+      if (k < Cout) dot += dy[k] * y[k];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k) d[k] = (k < Cout) ? y[k] * (dy[k] - dot) : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k) d[k] = (k < Cout) ? dy[k] * seg_act_grad_from_out(y[k], act, 0.f) : 0.f;
+  }
+}
+
+// dx (+)= gs * dpre . w      (one LPP-lane group per pixel, like the forward)
+__global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const float* y, int cs, int Cin, int N, int H, int W, int sy,
+                                                          int sx, const float* w, int w_ld, int Cout, int act, half_t* dx,
+                                                          int accumulate, const float* gs_ptr, int LPP) {
+  const int CH = cs / 8;
+  const int HO = (H + sy - 1) / sy, WO = (W + sx - 1) / sx;
+  const int64_t npix = (int64_t)N * HO * WO;
+  const int gpb = TPB / LPP;
+  const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+  const float gs = gs_ptr ? *gs_ptr : 1.f;
+  for (int64_t pix0 = (int64_t)blockIdx.x * gpb; pix0 < npix; pix0 += (int64_t)gridDim.x * gpb) {
+    const int64_t pix = pix0 + grp;
+    if (pix >= npix) continue;
+    float dyv[HEAD_MAXC], yv[HEAD_MAXC], d[HEAD_MAXC];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k) {
+      dyv[k] = (k < Cout) ? dy[pix * Cout + k] : 0.f;
+      yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
+    }
+    head_dpre(dyv, yv, Cout, act, d);
+    const int xo = (int)(pix % WO);
+    const int yo = (int)((pix / WO) % HO);
+    const int n = (int)(pix / ((int64_t)WO * HO));
+    half_t* dp = dx + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+    for (int ch = sub; ch < CH; ch += LPP) {
+      float o[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float s = 0.f;
+        const int c = ch * 8 + t;
+        if (c < Cin) {
+#pragma unroll
+          for (int k = 0; k < HEAD_MAXC; ++k)
+            if (k < Cout) s += d[k] * w[k * w_ld + c];
+        }
+        o[t] = s * gs;
+      }
+      if (accumulate) {
+        float old[8];
+        unpack8(ld16(dp + ch * 8), old);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] += old[t];
+      }
+      st16(dp + ch * 8, pack8(o));
+    }
+  }
+}
+
+// dw[k][c] += sum_pix dpre[k] * x[c],  db[k] += sum_pix dpre[k]   ((rows x chunk-columns) layout + atomics)
+__global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const float* y, const half_t* x, int cs, int Cin, int N, int H,
+                                                          int W, int sy, int sx, int w_ld, int Cout, int act, float* dw, float* db,
+                                                          ColLayout L) {
+  __shared__ float sm[TPB * 8];
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int HO = (H + sy - 1) / sy, WO = (W + sx - 1) / sx;
+  const int64_t npix = (int64_t)N * HO * WO;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    float acc[HEAD_MAXC][8];
+    float accb[HEAD_MAXC];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXC; ++k) {
+      accb[k] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[k][t] = 0.f;
+    }
+    if (ch < L.CH) {
+      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
+        float dyv[HEAD_MAXC], yv[HEAD_MAXC], d[HEAD_MAXC];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k) {
+          dyv[k] = (k < Cout) ? dy[pix * Cout + k] : 0.f;
+          yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
+        }
+        head_dpre(dyv, yv, Cout, act, d);
+        const int xo = (int)(pix % WO);
+        const int yo = (int)((pix / WO) % HO);
+        const int n = (int)(pix / ((int64_t)WO * HO));
+        float f[8];
+        unpack8(ld16(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + ch * 8), f);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k)
+          if (k < Cout) {
+            accb[k] += d[k];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[k][t] += d[k] * f[t];
+          }
+      }
+    }
+    block_col_reduce<HEAD_MAXC>(acc, sm, rowi, col, L.CHP, L.RP);
+    if (rowi == 0 && ch < L.CH) {
+#pragma unroll
+      for (int k = 0; k < HEAD_MAXC; ++k)
+        if (k < Cout) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (ch * 8 + t < Cin) atomicAdd(dw + k * w_ld + ch * 8 + t, acc[k][t]);
+        }
+    }
+    if (grp == 0 && db != nullptr) {   // bias: column 0 threads of every row-group
+      __syncthreads();
+      if (col == 0) {
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXC; ++k) sm[rowi * HEAD_MAXC + k] = accb[k];
+      }
+      __syncthreads();
+      if (threadIdx.x < Cout) {
+        float s = 0.f;
+        for (int r = 0; r < L.RP; ++r) s += sm[r * HEAD_MAXC + threadIdx.x];
+        atomicAdd(db + threadIdx.x, s);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+__global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, const float* target, int64_t npix, int C, float inv_n,
+                                                   float* loss_out, float* dpred) {
+  const float EPS = 1e-7f;
+  float local = 0.f;
+  if (kind == SEG_LOSS_CCE) {
+    for (int64_t pix = (int64_t)blockIdx.x * TPB + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * TPB) {
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s += pred[pix * C + k];
+      const float invs = 1.f / s;
+      // L = -sum_k t_k log(clip(p_k / s));  dL/dp_j = -t_j m_j / p_j + sum_k t_k m_k / s   (m = 1 inside the clip range)
+      float corr = 0.f;
+      for (int k = 0; k < C; ++k) {
+        const float q = pred[pix * C + k] * invs;
+        const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
+        corr += target[pix * C + k] * m;
+        local -= target[pix * C + k] * __logf(fminf(fmaxf(q, EPS), 1.f - EPS));
+      }
+      for (int k = 0; k < C; ++k) {
+        const float pk = pred[pix * C + k];
+        const float q = pk * invs;
+        const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
+        dpred[pix * C + k] = ((m > 0.f ? -target[pix * C + k] / pk : 0.f) + corr * invs) * inv_n;
+      }
+    }
+  } else {
+    const int64_t n = npix * C;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+      const float p = pred[i], t = target[i];
+      if (kind == SEG_LOSS_MSE) {
+        const float d = p - t;
+        local += d * d;
+        dpred[i] = 2.f * d * inv_n;
+      } else {   // BCE on probabilities, clipped like Keras
+        const float pc = fminf(fmaxf(p, EPS), 1.f - EPS);
+        local -= t * __logf(pc) + (1.f - t) * __logf(1.f - pc);
+        const float inside = (p > EPS && p < 1.f - EPS) ? 1.f : 0.f;
+        dpred[i] = inside * (-(t / pc) + (1.f - t) / (1.f - pc)) * inv_n;
+      }
+    }
+  }
+  local = wave_sum(local);
+  __shared__ float sm[TPB / 64];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int k = 0; k < TPB / 64; ++k) s += sm[k];
+    atomicAdd(loss_out, s * inv_n);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void absmax_kernel(const float* x, int64_t n, float* amax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float v = fabsf(x[i]);
+    m = (v == v) ? fmaxf(m, v) : m;
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));   // m >= 0: bit order == value order
+}
+
+__global__ void grad_scale_kernel(const float* amax, float target, float* gs) {
+  const float a = amax[0];
+  float s = 1.f;
+  if (a > 0.f && a < 3.0e38f) {
+    int e;
+    frexpf(a, &e);                       // a = f * 2^e, f in [0.5, 1)
+    int et;
+    frexpf(target, &et);
+    s = ldexpf(1.f, (et - 1) - e);       // a*s in [target/2, target) for a power-of-two target
+  }
+  gs[0] = s;
+  gs[1] = 1.f / s;
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser / packing
+__global__ __launch_bounds__(TPB) void adam_kernel(float* p, const float* g, float* m, float* v, half_t* p16, int64_t n, float alpha_t,
+                                                   float b1, float b2, float eps, float gmul) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float gi = g[i] * gmul;
+    float pi = p[i];
+    if (gi == gi && fabsf(gi) < 3.0e38f) {
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      pi -= alpha_t * mi / (sqrtf(vi) + eps);
+      p[i] = pi;
+    }
+    if (p16) p16[i] = (half_t)pi;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, half_t* wt, int rows, int T, int K, int rows_pad) {
+  // out[k][t][r] = in[r][t][k];   grid-stride over the OUTPUT so that stores are coalesced
+  const int64_t n = (int64_t)K * T * rows_pad;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int r = (int)(i % rows_pad);
+    const int64_t q = i / rows_pad;
+    const int t = (int)(q % T);
+    const int k = (int)(q / T);
+    wt[i] = (r < rows) ? (half_t)w[((int64_t)r * T + t) * K + k] : (half_t)0.f;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void cast_kernel(const float* x, half_t* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) y[i] = (half_t)x[i];
+}
+
+__global__ __launch_bounds__(TPB) void pack_input_kernel(const float* x, half_t* y, int64_t npix, int C, int cs) {
+  const int64_t n = npix * cs;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int c = (int)(i % cs);
+    const int64_t pix = i / cs;
+    y[i] = (c < C) ? (half_t)x[pix * C + c] : (half_t)0.f;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void unpack_kernel(const half_t* x, float* y, int64_t npix, int C, int cs, int coff) {
+  const int64_t n = npix * C;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    y[i] = (float)x[pix * cs + coff + c];
+  }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int seg_bn_stats(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts,
+                            int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && stats && npix > 0 && C > 0 && (C & 7) == 0 && (cs & 7) == 0 && (coff & 7) == 0 && coff + C <= cs && nparts > 0 &&
+                    stats_coff + C <= stats_ld,
+                "seg_bn_stats: bad arguments (npix=%ld C=%d cs=%d coff=%d nparts=%d)", (long)npix, C, cs, coff, nparts);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts), dim3(TPB), 0, ST(stream), (const half_t*)x, npix, cs, coff, C, stats, nparts,
+                     stats_ld, stats_coff, col_layout(C));
+  SEG_CHECK_LAUNCH("seg_bn_stats");
+  return SEG_OK;
+}
+
+extern "C" int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, int64_t count, const float* gamma, const float* beta,
+                               float eps, float momentum, float* moving_mean, float* moving_var, int32_t unbiased_moving,
+                               int32_t training, float* mean, float* invstd, float* scale, float* shift, seg_stream_t stream) {
+  SEG_CHECK_ARG(C > 0 && gamma && beta && moving_mean && moving_var && scale && shift, "seg_bn_finalize: null pointer / C=%d", C);
+  SEG_CHECK_ARG(!training || (stats && nparts > 0 && count > 0), "seg_bn_finalize: training needs stats");
+  int np = nparts;
+  if (training && nparts > 64) {
+    const int S = 32;
+    hipLaunchKernelGGL(bn_prereduce_kernel, dim3((C + 31) / 32, S), dim3(TPB), 0, ST(stream), const_cast<float*>(stats), nparts, C, S);
+    np = S;
+  }
+  const float unbias = (unbiased_moving && count > 1) ? (float)((double)count / (double)(count - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, ST(stream), stats, np, C,
+                     training ? (float)(1.0 / (double)count) : 0.f, unbias, gamma, beta, eps, momentum, moving_mean, moving_var, training,
+                     mean, invstd, scale, shift);
+  SEG_CHECK_LAUNCH("seg_bn_finalize");
+  return SEG_OK;
+}
+
+extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H,
+                                int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha,
+                                void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && scale && shift && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (x_cs & 7) == 0 && (y_cs & 7) == 0 &&
+                    (x_coff & 7) == 0 && (y_coff & 7) == 0 && x_coff + C <= x_cs && y_coff + C <= y_cs,
+                "seg_bn_act_apply: bad arguments");
+  const int64_t npix = (int64_t)N * H * W;
+  if (pooled == nullptr) {
+    hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const half_t*)x, x_cs, x_coff,
+                       (half_t*)y, y_cs, y_coff, npix, C, c_valid, scale, shift, act, alpha);
+  } else {
+    SEG_CHECK_ARG(ph >= 1 && pw >= 1 && y_coff == 0 && C == y_cs, "seg_bn_act_apply: fused pooling needs a dense output (C == y_cs)");
+    const int64_t items = (int64_t)N * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (C / 8);
+    hipLaunchKernelGGL(bn_act_apply_pool_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)x, x_cs, x_coff,
+                       (half_t*)y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, (half_t*)pooled, ph, pw);
+  }
+  SEG_CHECK_LAUNCH("seg_bn_act_apply");
+  return SEG_OK;
+}
+
+extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
+                                     int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && x && scale && shift && mean && invstd && partial && npix > 0 && C > 0 && (C & 7) == 0 && nparts > 0 &&
+                    dy_coff + C <= dy_cs && x_coff + C <= x_cs,
+                "seg_bn_act_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nparts), dim3(TPB), 0, ST(stream), (const half_t*)dy, dy_cs, dy_coff, (const half_t*)x,
+                     x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C));
+  SEG_CHECK_LAUNCH("seg_bn_act_bwd_reduce");
+  return SEG_OK;
+}
+
+extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma, float* dbeta,
+                                   float gscale, const float* gscale_ptr, float* c1, float* c2, seg_stream_t stream) {
+  SEG_CHECK_ARG(partial && c1 && c2 && nparts > 0 && C > 0 && count > 0, "seg_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, ST(stream), partial, nparts, C,
+                     (float)(1.0 / (double)count), dgamma, dbeta, gscale, gscale_ptr, c1, c2);
+  SEG_CHECK_LAUNCH("seg_bn_bwd_finalize");
+  return SEG_OK;
+}
+
+extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx,
+                                    int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
+                                    const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha,
+                                    int32_t accumulate, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
+                    dx_coff + C <= dx_cs && (c1 == nullptr || (c2 && mean && invstd)),
+                "seg_bn_act_bwd_apply: bad arguments");
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const half_t*)dy, dy_cs, dy_coff,
+                     (const half_t*)x, x_cs, x_coff, (half_t*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
+                     accumulate);
+  SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply");
+  return SEG_OK;
+}
+
+extern "C" int seg_act_bwd(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,
+                           float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && y && dx && npix > 0 && cs > 0 && (cs & 7) == 0 && C > 0 && C <= cs, "seg_act_bwd: bad arguments");
+  int blocks = (int)((npix + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)y, (half_t*)dx, npix, cs, C,
+                     act, alpha, dbias, gscale, gscale_ptr, col_layout(cs));
+  SEG_CHECK_LAUNCH("seg_act_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_maxpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw,
+                               seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && N > 0 && H >= ph && W >= pw && ph >= 1 && pw >= 1 && (cs & 7) == 0, "seg_maxpool_fwd: bad arguments");
+  const int64_t items = (int64_t)N * (H / ph) * (W / pw) * (cs / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)x, (half_t*)y, N, H, W, cs, ph, pw);
+  SEG_CHECK_LAUNCH("seg_maxpool_fwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs,
+                               int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && x && y && dx && N > 0 && H >= ph && W >= pw && ph >= 1 && pw >= 1 && (cs & 7) == 0, "seg_maxpool_bwd: bad arguments");
+  const int64_t items = (int64_t)N * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (cs / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)x,
+                     (const half_t*)y, (half_t*)dx, N, H, W, cs, ph, pw, accumulate);
+  SEG_CHECK_LAUNCH("seg_maxpool_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_upsample_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
+                                int32_t bilinear, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && fh >= 1 && fw >= 1 && (cs & 7) == 0, "seg_upsample_fwd: bad arguments");
+  const int64_t items = (int64_t)N * H * fh * W * fw * (cs / 8);
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)x, (half_t*)y, N, H, W, cs, fh, fw,
+                     bilinear);
+  SEG_CHECK_LAUNCH("seg_upsample_fwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
+                                int32_t bilinear, int32_t accumulate, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && fh >= 1 && fw >= 1 && (cs & 7) == 0, "seg_upsample_bwd: bad arguments");
+  const int64_t items = (int64_t)N * H * W * (cs / 8);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)dy, (half_t*)dx, N, H, W, cs, fh,
+                     fw, bilinear, accumulate);
+  SEG_CHECK_LAUNCH("seg_upsample_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) {
+  SEG_CHECK_ARG(xs && y && n >= 1 && n <= 4 && nelem > 0 && (nelem & 7) == 0, "seg_add_act_fwd: bad arguments (n=%d)", n);
+  Ptr4 p;
+  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (const half_t*)xs[k] : nullptr;
+  hipLaunchKernelGGL(add_act_fwd_kernel, dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), p, n, (half_t*)y, nelem / 8, act, alpha);
+  SEG_CHECK_LAUNCH("seg_add_act_fwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha,
+                               int32_t accumulate_mask, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && dxs && n >= 1 && n <= 4 && nelem > 0 && (nelem & 7) == 0 && (act == SEG_ACT_NONE || y), "seg_add_act_bwd: bad arguments");
+  MPtr4 p;
+  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (half_t*)dxs[k] : nullptr;
+  hipLaunchKernelGGL(add_act_bwd_kernel, dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)y, p, n,
+                     nelem / 8, act, alpha, accumulate_mask);
+  SEG_CHECK_LAUNCH("seg_add_act_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_mul_bcast_fwd(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) {
+  SEG_CHECK_ARG(a && r && y && npix > 0 && (cs & 7) == 0 && r_cs >= 1, "seg_mul_bcast_fwd: bad arguments");
+  hipLaunchKernelGGL(mul_bcast_fwd_kernel, dim3(grid_for(npix * (cs / 8))), dim3(TPB), 0, ST(stream), (const half_t*)a, (const half_t*)r,
+                     (half_t*)y, npix, cs, r_cs);
+  SEG_CHECK_LAUNCH("seg_mul_bcast_fwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_mul_bcast_bwd(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs,
+                                 int32_t acc_a, int32_t acc_r, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && a && r && npix > 0 && (cs & 7) == 0 && r_cs >= 1, "seg_mul_bcast_bwd: bad arguments");
+  int LPP = pow2ceil(cs / 8);
+  if (LPP > 64) LPP = 64;
+  const int gpb = TPB / LPP;
+  int64_t blocks = (npix + gpb - 1) / gpb;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  hipLaunchKernelGGL(mul_bcast_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)a, (const half_t*)r,
+                     (half_t*)da, (half_t*)dr, npix, cs, r_cs, acc_a, acc_r, LPP);
+  SEG_CHECK_LAUNCH("seg_mul_bcast_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_convlstm_gate_fwd(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) {
+  SEG_CHECK_ARG(z && h && npix > 0 && F > 0 && (F & 7) == 0 && 4 * F <= z_cs && F <= h_cs && (z_cs & 7) == 0 && (h_cs & 7) == 0,
+                "seg_convlstm_gate_fwd: bad arguments (F=%d z_cs=%d h_cs=%d)", F, z_cs, h_cs);
+  hipLaunchKernelGGL(convlstm_gate_fwd_kernel, dim3(grid_for(npix * (F / 8))), dim3(TPB), 0, ST(stream), (const half_t*)z, z_cs, (half_t*)h,
+                     h_cs, npix, F);
+  SEG_CHECK_LAUNCH("seg_convlstm_gate_fwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_convlstm_gate_bwd(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F,
+                                     seg_stream_t stream) {
+  SEG_CHECK_ARG(dh && z && dz && npix > 0 && F > 0 && (F & 7) == 0 && 4 * F <= z_cs && F <= h_cs, "seg_convlstm_gate_bwd: bad arguments");
+  hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(grid_for(npix * (F / 8))), dim3(TPB), 0, ST(stream), (const half_t*)dh, h_cs,
+                     (const half_t*)z, z_cs, (half_t*)dz, npix, F);
+  SEG_CHECK_LAUNCH("seg_convlstm_gate_bwd");
+  return SEG_OK;
+}
+
+static int head_lpp(int Cin) {
+  int LPP = pow2ceil((Cin + 7) / 8);
+  return LPP > 64 ? 64 : LPP;
+}
+
+extern "C" int seg_head_fwd(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w,
+                            int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && w && y && Cin > 0 && Cin <= cs && (cs & 7) == 0 && Cout >= 1 && Cout <= HEAD_MAXC && w_ld >= Cin && sy >= 1 && sx >= 1 &&
+                    N > 0 && H > 0 && W > 0,
+                "seg_head_fwd: bad arguments (Cin=%d cs=%d Cout=%d)", Cin, cs, Cout);
+  const int LPP = head_lpp(Cin), gpb = TPB / LPP;
+  const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
+  int64_t blocks = (npix + gpb - 1) / gpb;
+  if (blocks > 4 * MAX_BLOCKS) blocks = 4 * MAX_BLOCKS;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), (const half_t*)x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout,
+                     act, y, LPP);
+  SEG_CHECK_LAUNCH("seg_head_fwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W,
+                            int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate,
+                            const float* gs_ptr, float* dw, float* db, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && y && x && w && Cin > 0 && Cin <= cs && (cs & 7) == 0 && Cout >= 1 && Cout <= HEAD_MAXC && w_ld >= Cin,
+                "seg_head_bwd: bad arguments");
+  const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
+  if (dx != nullptr) {
+    const int LPP = head_lpp(cs), gpb = TPB / LPP;
+    int64_t blocks = (npix + gpb - 1) / gpb;
+    if (blocks > 4 * MAX_BLOCKS) blocks = 4 * MAX_BLOCKS;
+    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), dy, y, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act,
+                       (half_t*)dx, accumulate, gs_ptr, LPP);
+  }
+  if (dw != nullptr) {
+    int blocks = (int)((npix + 511) / 512);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), dy, y, (const half_t*)x, cs, Cin, N, H, W, sy, sx, w_ld,
+                       Cout, act, dw, db, col_layout(((Cin + 7) / 8) * 8));
+  }
+  SEG_CHECK_LAUNCH("seg_head_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float* loss_out, float* dpred,
+                                seg_stream_t stream) {
+  SEG_CHECK_ARG(pred && target && loss_out && dpred && npix > 0 && C >= 1 && kind >= SEG_LOSS_MSE && kind <= SEG_LOSS_CCE,
+                "seg_loss_fwd_bwd: bad arguments");
+  const double n = (kind == SEG_LOSS_CCE) ? (double)npix : (double)npix * C;
+  const int64_t items = (kind == SEG_LOSS_CCE) ? npix : npix * C;
+  hipLaunchKernelGGL(loss_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), kind, pred, target, npix, C, (float)(1.0 / n), loss_out,
+                     dpred);
+  SEG_CHECK_LAUNCH("seg_loss_fwd_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_absmax(const float* x, int64_t n, float* amax, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && amax && n > 0, "seg_absmax: bad arguments");
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), x, n, amax);
+  SEG_CHECK_LAUNCH("seg_absmax");
+  return SEG_OK;
+}
+
+extern "C" int seg_grad_scale(const float* amax, float target, float* gs, seg_stream_t stream) {
+  SEG_CHECK_ARG(amax && gs && target > 0.f, "seg_grad_scale: bad arguments");
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, ST(stream), amax, target, gs);
+  SEG_CHECK_LAUNCH("seg_grad_scale");
+  return SEG_OK;
+}
+
+extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1, float b2, float eps,
+                             float gmul, seg_stream_t stream) {
+  SEG_CHECK_ARG(p && g && m && v && n > 0, "seg_adam_step: bad arguments");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), p, g, m, v, (half_t*)p16, n, alpha_t, b1, b2, eps, gmul);
+  SEG_CHECK_LAUNCH("seg_adam_step");
+  return SEG_OK;
+}
+
+extern "C" int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad, seg_stream_t stream) {
+  SEG_CHECK_ARG(w && wt && rows > 0 && T > 0 && K > 0 && rows_pad >= rows, "seg_transpose_w: bad arguments");
+  hipLaunchKernelGGL(transpose_w_kernel, dim3(grid_for((int64_t)K * T * rows_pad)), dim3(TPB), 0, ST(stream), w, (half_t*)wt, rows, T, K,
+                     rows_pad);
+  SEG_CHECK_LAUNCH("seg_transpose_w");
+  return SEG_OK;
+}
+
+extern "C" int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && n > 0, "seg_cast_f32_f16: bad arguments");
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), x, (half_t*)y, n);
+  SEG_CHECK_LAUNCH("seg_cast_f32_f16");
+  return SEG_OK;
+}
+
+extern "C" int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && npix > 0 && C > 0 && C <= cs, "seg_pack_input: bad arguments");
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(npix * cs)), dim3(TPB), 0, ST(stream), x, (half_t*)y, npix, C, cs);
+  SEG_CHECK_LAUNCH("seg_pack_input");
+  return SEG_OK;
+}
+
+extern "C" int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && npix > 0 && C > 0 && coff + C <= cs, "seg_unpack_f32: bad arguments");
+  hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(npix * C)), dim3(TPB), 0, ST(stream), (const half_t*)x, y, npix, C, cs, coff);
+  SEG_CHECK_LAUNCH("seg_unpack_f32");
+  return SEG_OK;
+}

@@ -1,0 +1,80 @@
+"""Data-parallel training: one process per GPU, minibatch sharded across ranks (weak scaling, bs/GPU fixed),
+per-replica BatchNorm statistics (the reference has no SyncBN), and ONE exchange step per optimiser step: a sum
+all-reduce of the flat fp32 gradient buffer over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
+
+The reference is single-device (no tf.distribute anywhere); this is the data-parallel
+train_step the north star adds around `2DCNN/Train.py:394-415`.
+
+All parameters live in one flat buffer (model.ParamStore), so the collective is issued on large contiguous
+slices ("buckets") instead of per-layer tensors: xGMI is point-to-point (7 links x ~153 GB/s per GPU), and a
+few large messages keep every link busy.  Gradients are averaged by the Adam kernel (gmul = 1/world_size).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend: Optional[str] = None) -> int:
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns the local rank."""
+    if dist.is_initialized():
+        return int(os.environ.get("LOCAL_RANK", 0))
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", 0)),
+                            world_size=int(os.environ.get("WORLD_SIZE", 1)))
+    return local_rank
+
+
+def bucket_bounds(numel: int, bucket_elems: int):
+    """Contiguous [lo, hi) slices covering [0, numel)."""
+    out, lo = [], 0
+    while lo < numel:
+        hi = min(numel, lo + bucket_elems)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def allreduce_flat(buf: torch.Tensor, bucket_elems: int = 64 << 20, group=None):
+    """In-place sum all-reduce of a flat tensor in large contiguous buckets (async launches, one wait)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    works = [dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
+             for lo, hi in bucket_bounds(buf.numel(), bucket_elems)]
+    for w in works:
+        w.wait()
+
+
+def broadcast_flat(buf: torch.Tensor, src: int = 0, group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(buf, src=src, group=group)
+
+
+class DataParallel:
+    """Wraps a built SegModel: identical initial weights on every rank, gradient all-reduce before Adam."""
+
+    def __init__(self, model, bucket_elems: int = 64 << 20, group=None):
+        self.model, self.group, self.bucket_elems = model, group, bucket_elems
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        model.world_size = self.world_size
+        model.allreduce = self._allreduce
+        if self.world_size > 1:
+            st = model.store
+            broadcast_flat(st.P, 0, group)
+            broadcast_flat(st.S, 0, group)
+            model._refresh_copies()
+
+    def _allreduce(self, flat_grads: torch.Tensor):
+        allreduce_flat(flat_grads, self.bucket_elems, self.group)
+
+    def train_step(self, x_local, targets_local, loss=None):
+        return self.model.train_step(x_local, targets_local, loss)

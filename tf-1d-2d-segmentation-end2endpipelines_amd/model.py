@@ -1,0 +1,1089 @@
+"""SegModel - executes a layer graph (graph.py) on one MI355X through the C ABI in include/seg_hip.h.
+
+This object stands where the reference has a ``tf.keras.Model`` (returned by the encoder-named methods,
+`TensorFlow/2DCNN/models/unet_variants.py:1109-1114`) and offers the calls the reference's scripts make on it
+(SURVEY.md section 8b): ``predict`` (2DCNN/Test.py:153,161), ``get_weights``/``set_weights``/``count_params``
+(Train.py:354-367), a ``train_step`` = Keras' default fit step (Train.py:322-325, 394-415: forward with
+training-mode BN, sum of per-output losses with unit weights, gradients, Adam), and ``summary``.
+
+torch is used for device memory, streams and (in dp.py) torch.distributed - every FLOP of the path runs in the
+hand-written HIP kernels.  There is no CPU fallback: constructing a SegModel without a GPU / without
+libseg_hip.so raises.
+
+Lowering (Keras-level nodes -> fused launches)
+  conv [-> bn] [-> act] [-> maxpool]   one implicit-GEMM launch (virtual concat, bias, BN partial statistics in
+                                       the epilogue) + bn_finalize + bn_act_apply (activation and 2x2 pool fused)
+  convT [-> bn] [-> act]               the same kernel with 4 (2 in 1D) sub-pixel classes; LeakyReLU in the epilogue
+  concat                               never materialised when it feeds a conv / ConvLSTM
+  convlstm                             implicit GEMM (4F gate pre-activations) + gate kernel
+  1x1 conv that is a model output      head kernel (fp32 logits/probabilities, sigmoid / softmax fused)
+  add [-> act], mul, upsample, maxpool, standalone bn/act      one HBM-bound kernel each
+Backward mirrors it: bn/act backward in two passes, data gradients through the same implicit-GEMM kernel with
+transposed weights (one launch per concat segment, accumulating where a tensor has several consumers), weight
+gradients through the transposed-read MFMA kernel into ONE flat fp32 gradient buffer (single all-reduce, single
+Adam launch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import zlib
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import ACT, LOSS, Geom, IgemmFwdArgs, IgemmWgradArgs
+from .graph import Graph, Node
+
+BN_PARTS_BWD = 512
+GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
+WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
+
+
+def _r8(v):
+    return (v + 7) // 8 * 8
+
+
+def _r32(v):
+    return (v + 31) // 32 * 32
+
+
+def _cdiv(a, b):
+    return -(-a // b)
+
+
+class _DryRun:
+    """Host-logic test mode (tests/test_lowering.py): buffers live on the CPU and kernel calls are only recorded.
+    It computes nothing - it is NOT a fallback; SegModel.build() refuses to run without a GPU unless a test
+    switches this on explicitly."""
+    on = False
+    log: List[str] = []
+
+
+def _dev():
+    return "cpu" if _DryRun.on else "cuda"
+
+
+class KernelProfile:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)."""
+    on = False
+    records: List[tuple] = []     # (name, tag, flops, bytes, start_event, end_event)
+
+    @classmethod
+    def summary(cls):
+        torch.cuda.synchronize()
+        agg: Dict[str, List[float]] = {}
+        for name, tag, flops, nbytes, e0, e1 in cls.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += flops
+            a[3] += nbytes
+        return {k: dict(launches=v[0], seconds=v[1], flops=v[2], bytes=v[3]) for k, v in agg.items()}
+
+
+def call(name, *args, flops=0.0, nbytes=0.0, tag=""):
+    if _DryRun.on:
+        _DryRun.log.append(name)
+        return
+    if KernelProfile.on:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ffi.call(name, *args)
+        e1.record()
+        KernelProfile.records.append((name, tag, flops, nbytes, e0, e1))
+        return
+    _ffi.call(name, *args)
+
+
+def _stream():
+    if _DryRun.on:
+        return C.c_void_p(0)
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ------------------------------------------------------------------------------------------------ init
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+def init_param(spec, seed) -> np.ndarray:
+    """Keras initialisers by name (he_uniform: unet_variants.py:7; glorot_uniform default; he_normal: :149)."""
+    r = _rng(seed, spec.name)
+    fi, fo = spec.fan
+    shape, init = spec.shape, spec.init
+    if init == "zeros":
+        return np.zeros(shape, np.float32)
+    if init == "ones":
+        return np.ones(shape, np.float32)
+    if init == "he_uniform":
+        lim = math.sqrt(6.0 / fi)
+        return r.uniform(-lim, lim, shape).astype(np.float32)
+    if init == "glorot_uniform":
+        lim = math.sqrt(6.0 / (fi + fo))
+        return r.uniform(-lim, lim, shape).astype(np.float32)
+    if init == "he_normal":
+        std = math.sqrt(2.0 / fi) / 0.87962566103423978
+        v = np.clip(r.standard_normal(shape), -2.0, 2.0)
+        return (v * std).astype(np.float32)
+    if init == "orthogonal":
+        rows, cols = int(np.prod(shape[:-1])), int(shape[-1])
+        a = r.standard_normal((max(rows, cols), min(rows, cols)))
+        q, rr = np.linalg.qr(a)
+        q = q * np.sign(np.diag(rr))
+        if rows < cols:
+            q = q.T
+        return q.reshape(shape).astype(np.float32)
+    if init == "unit_forget_bias":
+        b = np.zeros(shape, np.float32)
+        F4 = shape[0] // 4
+        b[F4:2 * F4] = 1.0
+        return b
+    raise ValueError(init)
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def _same_pad(n_in, k, s):
+    out = _cdiv(n_in, s)
+    total = max((out - 1) * s + k - n_in, 0)
+    return total // 2
+
+
+def _fill_geom(g: Geom, N, Hin, Win, Hl, Wl, isy, isx, Hout, Wout, osy, osx, classes, T_total):
+    """classes: list of (oy, ox, [(dy, dx, widx), ...]) with the same tap count each."""
+    g.N, g.Hin, g.Win, g.Hl, g.Wl, g.isy, g.isx = N, Hin, Win, Hl, Wl, isy, isx
+    g.Hout, g.Wout, g.osy, g.osx = Hout, Wout, osy, osx
+    g.ncls, g.ntaps, g.T_total = len(classes), len(classes[0][2]), T_total
+    assert all(len(c[2]) == g.ntaps for c in classes) and g.ncls * g.ntaps <= _ffi.MAX_TAPS and g.ncls <= _ffi.MAX_CLS
+    for ci, (oy, ox, taps) in enumerate(classes):
+        g.oy[ci], g.ox[ci] = oy, ox
+        for t, (dy, dx, wi) in enumerate(taps):
+            e = ci * g.ntaps + t
+            g.tap_dy[e], g.tap_dx[e], g.tap_w[e] = dy, dx, wi
+    return g
+
+
+def geom_conv(N, H, W, kh, kw, sh, sw) -> Geom:
+    """Conv2D(padding='same'): out(i,j) = sum_k in(i*s + k - pad_before)."""
+    pt, pl = _same_pad(H, kh, sh), _same_pad(W, kw, sw)
+    Ho, Wo = _cdiv(H, sh), _cdiv(W, sw)
+    taps = [(ky - pt, kx - pl, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+    return _fill_geom(Geom(), N, H, W, Ho, Wo, sh, sw, Ho, Wo, 1, 1, [(0, 0, taps)], kh * kw)
+
+
+def geom_conv_dgrad(N, H, W, kh, kw, sh, sw) -> Geom:
+    """Data gradient of the conv above, as a gather over dz.  stride 1: dx(y) = sum_k dz(y + pad - k) w[k];
+    1x1/stride s: dx(i*s) = dz(i) w (other pixels untouched -> caller pre-zeroes)."""
+    Ho, Wo = _cdiv(H, sh), _cdiv(W, sw)
+    if sh == 1 and sw == 1:
+        pt, pl = _same_pad(H, kh, 1), _same_pad(W, kw, 1)
+        taps = [(pt - ky, pl - kx, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+        return _fill_geom(Geom(), N, Ho, Wo, H, W, 1, 1, H, W, 1, 1, [(0, 0, taps)], kh * kw)
+    if kh == 1 and kw == 1:
+        return _fill_geom(Geom(), N, Ho, Wo, Ho, Wo, 1, 1, H, W, sh, sw, [(0, 0, [(0, 0, 0)])], 1)
+    raise NotImplementedError("data gradient of a strided conv with a kernel larger than 1x1 is not on the hot path")
+
+
+def geom_convT(N, H, W, kh, kw, sh, sw) -> Geom:
+    """Conv2DTranspose(padding='same'): Y = s*i + k - pb  ->  sub-pixel class py = Y mod s gathers the taps
+    k with (py + pb - k) % s == 0 at input offset (py + pb - k) / s."""
+    pbh, pbw = max(kh - sh, 0) // 2, max(kw - sw, 0) // 2
+    classes = []
+    for py in range(sh):
+        for px in range(sw):
+            taps = []
+            for ky in range(kh):
+                if (py + pbh - ky) % sh:
+                    continue
+                for kx in range(kw):
+                    if (px + pbw - kx) % sw:
+                        continue
+                    taps.append(((py + pbh - ky) // sh, (px + pbw - kx) // sw, ky * kw + kx))
+            classes.append((py, px, taps))
+    return _fill_geom(Geom(), N, H, W, H, W, 1, 1, H * sh, W * sw, sh, sw, classes, kh * kw)
+
+
+def geom_convT_dgrad(N, H, W, kh, kw, sh, sw) -> Geom:
+    """dx(i) = sum_k dY(s*i + k - pb) w[k]  (a strided gather over the up-sampled gradient)."""
+    pbh, pbw = max(kh - sh, 0) // 2, max(kw - sw, 0) // 2
+    taps = [(ky - pbh, kx - pbw, ky * kw + kx) for ky in range(kh) for kx in range(kw)]
+    return _fill_geom(Geom(), N, H * sh, W * sw, H, W, sh, sw, H, W, 1, 1, [(0, 0, taps)], kh * kw)
+
+
+def pack_gemm_weight(kern: np.ndarray, cin_l: Sequence[int], woff: Sequence[int], n_rows: int, Kpad: int,
+                     transposed: bool) -> np.ndarray:
+    """Keras kernel (kh,kw,Cin,Cout) [conv, ConvLSTM] or (kh,kw,Cout,Cin) [transposed conv] -> GEMM operand
+    [n_rows][T][Kpad]: segment s of the (virtual) concat occupies K columns woff[s] .. woff[s]+cin_l[s]."""
+    T = kern.shape[0] * kern.shape[1]
+    k2 = np.asarray(kern, np.float32).reshape(T, kern.shape[2], kern.shape[3])
+    cout = kern.shape[2] if transposed else kern.shape[3]
+    E = np.zeros((n_rows, T, Kpad), np.float32)
+    lo = 0
+    for s, c in enumerate(cin_l):
+        blk = k2[:, :, lo:lo + c].transpose(1, 0, 2) if transposed else k2[:, lo:lo + c, :].transpose(2, 0, 1)
+        E[:cout, :, woff[s]:woff[s] + c] = blk
+        lo += c
+    return E
+
+
+def unpack_gemm_weight(flat: np.ndarray, shape, cin_l, woff, n_rows, Kpad, transposed) -> np.ndarray:
+    T = shape[0] * shape[1]
+    cout = shape[2] if transposed else shape[3]
+    E = np.asarray(flat, np.float32).reshape(n_rows, T, Kpad)
+    out_k = np.zeros((T, shape[2], shape[3]), np.float32)
+    lo = 0
+    for s, c in enumerate(cin_l):
+        blk = E[:cout, :, woff[s]:woff[s] + c]
+        if transposed:
+            out_k[:, :, lo:lo + c] = blk.transpose(1, 0, 2)
+        else:
+            out_k[:, lo:lo + c, :] = blk.transpose(1, 2, 0)
+        lo += c
+    return out_k.reshape(shape)
+
+
+def pick_tile_fwd(M, n_rows, ncls):
+    tn = 128 if n_rows > 64 else 64
+    tm = 128
+    blocks = lambda: ncls * _cdiv(M, tm) * _cdiv(n_rows, tn)
+    if blocks() < 512:
+        tm = 64
+    if blocks() < 512 and tn == 128:
+        tn = 64
+    return tm, tn
+
+
+def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], nentries):
+    tm = 128 if n_rows > 64 else 64
+    tn = 128 if max(seg_cs) > 64 else 64
+    tiles = _cdiv(n_rows, tm) * sum(_cdiv(c, tn) for c in seg_cs) * nentries
+    splitk = max(1, min(_cdiv(1536, tiles), _cdiv(M, 256)))
+    return tm, tn, splitk
+
+
+# ------------------------------------------------------------------------------------------------ tensors / params
+class DevTensor:
+    """NHWC fp16 activation with channel stride cs (multiple of 8); pad channels are zero."""
+    registry: Optional[Dict[str, "DevTensor"]] = None
+
+    def __init__(self, name, N, H, W, Cl):
+        self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cl
+        self.cs = _r8(Cl)
+        self.buf = torch.zeros((N, H, W, self.cs), dtype=torch.float16, device=_dev())
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = True
+        self.gw = False          # "gradient written" flag used while the static backward schedule is built
+        if DevTensor.registry is not None:
+            DevTensor.registry[name] = self
+
+    @property
+    def npix(self):
+        return self.N * self.H * self.W
+
+    def ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.buf)
+        return self.grad
+
+    def claim(self) -> int:
+        """Returns the accumulate flag for the next producer of this tensor's gradient."""
+        acc = 1 if self.gw else 0
+        self.gw = True
+        self.ensure_grad()
+        return acc
+
+
+class Slot:
+    """A parameter as the engine stores it (GEMM layout, padded) inside the flat buffers."""
+
+    def __init__(self, spec, numel, to_engine, from_engine, trainable):
+        self.spec, self.numel, self.to_engine, self.from_engine, self.trainable = spec, numel, to_engine, from_engine, trainable
+        self.off = -1
+
+
+class ParamStore:
+    ALIGN = 64
+
+    def __init__(self):
+        self.slots: Dict[str, Slot] = {}
+        self.n_train = 0
+        self.n_state = 0
+        self.P = self.G = self.M = self.V = self.P16 = self.S = None
+
+    def add(self, spec, numel, to_engine, from_engine):
+        s = Slot(spec, numel, to_engine, from_engine, spec.trainable)
+        if spec.trainable:
+            s.off = self.n_train
+            self.n_train += _cdiv(numel, self.ALIGN) * self.ALIGN
+        else:
+            s.off = self.n_state
+            self.n_state += _cdiv(numel, self.ALIGN) * self.ALIGN
+        self.slots[spec.name] = s
+        return s
+
+    def allocate(self):
+        n = max(self.n_train, self.ALIGN)
+        self.P = torch.zeros(n, dtype=torch.float32, device=_dev())
+        self.G = torch.zeros(n, dtype=torch.float32, device=_dev())
+        self.M = torch.zeros(n, dtype=torch.float32, device=_dev())
+        self.V = torch.zeros(n, dtype=torch.float32, device=_dev())
+        self.P16 = torch.zeros(n, dtype=torch.float16, device=_dev())
+        self.S = torch.zeros(max(self.n_state, self.ALIGN), dtype=torch.float32, device=_dev())
+
+    def view(self, name, which="P") -> torch.Tensor:
+        s = self.slots[name]
+        buf = getattr(self, which) if s.trainable else self.S
+        return buf[s.off:s.off + s.numel]
+
+    def ptr(self, name, which="P") -> C.c_void_p:
+        s = self.slots[name]
+        buf = getattr(self, which) if s.trainable else self.S
+        return C.c_void_p(buf.data_ptr() + s.off * buf.element_size())
+
+
+# ------------------------------------------------------------------------------------------------ ops
+class Op:
+    def forward(self, training: bool):
+        raise NotImplementedError
+
+    def plan_backward(self):
+        """Called once, in reverse order, to fix accumulate flags."""
+
+    def backward(self):
+        pass
+
+    def post_step(self):
+        """Refresh derived weight copies after an optimiser step / weight import."""
+
+
+class InputOp(Op):
+    def __init__(self, m, t: DevTensor, Cin):
+        self.m, self.t, self.Cin = m, t, Cin
+        t.needs_grad = False
+
+    def forward(self, training):
+        x = self.m._x
+        call("seg_pack_input", _p(x), _p(self.t.buf), self.t.npix, self.Cin, self.t.cs, _stream())
+
+
+class ConvOp(Op):
+    """conv / convT / convlstm input-conv (+ BN + activation + pool | + ConvLSTM gates)."""
+
+    def __init__(self, m, node: Node, kind, segs: List[Tuple[DevTensor, int]], bn: Optional[Node], act, alpha,
+                 out: DevTensor, pooled: Optional[DevTensor], pool_size, lstm_F=0):
+        self.m, self.node, self.kind, self.segs, self.bn = m, node, kind, segs, bn
+        self.act, self.alpha, self.out, self.pooled, self.pool_size, self.F = act, alpha, out, pooled, pool_size, lstm_F
+        st = m.store
+        kh, kw = node.attrs["kernel"]
+        sh, sw = node.attrs.get("strides", (1, 1))
+        t0 = segs[0][0]
+        N, H, W = t0.N, t0.H, t0.W
+        self.N, self.H, self.W = N, H, W
+        self.T = kh * kw
+        self.cout = node.shape[2] if kind != "convlstm" else 4 * lstm_F
+        self.n_rows = _r8(self.cout)
+        # ---- K layout over the (virtual) concat
+        self.woff, k = [], 0
+        for t, _c in segs:
+            self.woff.append(k)
+            k += _r32(t.cs)
+        self.Kpad = k
+        self.rows_pad = _r32(self.n_rows)
+        if kind == "convT":
+            self.g_fwd = geom_convT(N, H, W, kh, kw, sh, sw)
+            self.g_dgrad = geom_convT_dgrad(N, H, W, kh, kw, sh, sw)
+            Ho, Wo = H * sh, W * sw
+        else:
+            self.g_fwd = geom_conv(N, H, W, kh, kw, sh, sw)
+            self.g_dgrad = geom_conv_dgrad(N, H, W, kh, kw, sh, sw)
+            Ho, Wo = _cdiv(H, sh), _cdiv(W, sw)
+        self.strided = (sh, sw) != (1, 1) and kind != "convT"
+        self.Ho, self.Wo = Ho, Wo
+        self.M = N * self.g_fwd.Hl * self.g_fwd.Wl
+        # ---- z: the conv output before BN / gates (aliases `out` when nothing follows that needs it)
+        self.has_bn = bn is not None
+        if self.has_bn or kind == "convlstm":
+            self.z = DevTensor(node.name + ":z", N, Ho, Wo, self.cout)
+        else:
+            self.z = out
+        assert self.z.cs == self.n_rows, (node.name, self.z.cs, self.n_rows)
+        # ---- parameters
+        cin_l = [c for _t, c in segs]
+        n_rows, T, Kpad, woff, cout = self.n_rows, self.T, self.Kpad, list(self.woff), self.cout
+        transposed = kind == "convT"
+
+        def to_engine(kern):
+            return pack_gemm_weight(kern, cin_l, woff, n_rows, Kpad, transposed).reshape(-1)
+
+        def from_engine(flat, shape=node.params[0].shape):
+            return unpack_gemm_weight(flat, shape, cin_l, woff, n_rows, Kpad, transposed)
+
+        kspec = node.params[0]
+        self.wname = kspec.name
+        st.add(kspec, n_rows * T * Kpad, to_engine, from_engine)
+        self.bname = None
+        for ps in node.params[1:]:
+            if ps.name.endswith("/bias"):
+                self.bname = ps.name
+                st.add(ps, n_rows, lambda b: np.pad(b, (0, n_rows - b.shape[0])), lambda f, c=cout: f[:c].copy())
+            else:   # ConvLSTM recurrent kernel: a weight of the Keras layer that the T = 1 forward never reads
+                st.add(ps, int(np.prod(ps.shape)), lambda a: a.reshape(-1), lambda f, sh_=ps.shape: f.reshape(sh_).copy())
+        if self.has_bn:
+            for ps in bn.params:
+                st.add(ps, n_rows, _pad_to(n_rows), lambda f, c=cout: f[:c].copy())
+            self.bn_name = bn.name
+            self.eps, self.momentum = float(bn.attrs["eps"]), float(bn.attrs["momentum"])
+        # ---- tiles and scratch
+        self.tm, self.tn = pick_tile_fwd(self.M, n_rows, self.g_fwd.ncls)
+        self.nparts = self.g_fwd.ncls * _cdiv(self.M, self.tm)
+        dev = _dev()
+        if self.has_bn:
+            self.stats = torch.zeros(self.nparts * 2 * n_rows, dtype=torch.float32, device=dev)
+            self.mean, self.invstd, self.scale, self.shift, self.c1, self.c2 = (
+                torch.zeros(n_rows, dtype=torch.float32, device=dev) for _ in range(6))
+            self.bpart = torch.zeros(BN_PARTS_BWD * 2 * n_rows, dtype=torch.float32, device=dev)
+        self.need_dgrad = [t.needs_grad for t, _c in segs]
+        # algorithmic FLOPs (2*MAC over logical channels): forward == weight gradient; data gradient per segment
+        pix_taps = self.N * self.g_fwd.Hl * self.g_fwd.Wl * self.g_fwd.ncls * self.g_fwd.ntaps
+        self.flops_fwd = 2.0 * pix_taps * sum(cin_l) * self.cout
+        self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
+        self.wt = torch.zeros(Kpad * T * self.rows_pad, dtype=torch.float16, device=dev) if any(self.need_dgrad) else None
+        self.fwd_args = None
+
+    # -- argument blocks (built after the parameter store has been allocated)
+    def finalize(self):
+        st = self.m.store
+        a = IgemmFwdArgs()
+        a.g = self.g_fwd
+        a.nseg = len(self.segs)
+        for s, (t, _c) in enumerate(self.segs):
+            a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s] = t.cs, t.cs, self.woff[s], t.buf.data_ptr()
+        a.w = st.ptr(self.wname, "P16").value
+        a.Kpad, a.n_rows, a.n_valid = self.Kpad, self.n_rows, self.cout
+        a.out, a.out_cs, a.out_coff = self.z.buf.data_ptr(), self.z.cs, 0
+        a.bias = st.ptr(self.bname, "P").value if self.bname else None
+        fused_act = (not self.has_bn) and self.kind != "convlstm"
+        a.act, a.alpha = (ACT[self.act] if fused_act else 0), float(self.alpha)
+        a.accumulate = 0
+        a.stats = self.stats.data_ptr() if self.has_bn else None
+        a.tile_m, a.tile_n = self.tm, self.tn
+        self.fwd_args = a
+        self.fwd_args_eval = IgemmFwdArgs.from_buffer_copy(a)
+        self.fwd_args_eval.stats = None
+        # wgrad
+        wg = IgemmWgradArgs()
+        wg.g = self.g_fwd
+        wg.nseg = a.nseg
+        for s in range(a.nseg):
+            wg.seg_c[s], wg.seg_cs[s], wg.seg_woff[s], wg.seg_ptr[s] = a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s]
+        wg.dz_cs, wg.dz_coff = self.z.cs, 0
+        wg.dw = st.ptr(self.wname, "G").value
+        wg.Kpad, wg.n_rows = self.Kpad, self.n_rows
+        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs], self.g_fwd.ncls * self.g_fwd.ntaps)
+        wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
+        wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
+        wg.variant = WGRAD_VARIANT
+        self.wg_args = wg
+
+    def post_step(self):
+        if self.wt is not None:
+            call("seg_transpose_w", self.m.store.ptr(self.wname, "P"), _p(self.wt), self.n_rows, self.T, self.Kpad,
+                 self.rows_pad, _stream())
+
+    def forward(self, training):
+        st, s = self.m.store, _stream()
+        a = self.fwd_args if (training and self.has_bn) else self.fwd_args_eval
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, tag="fwd")
+        if self.has_bn:
+            bn = self.bn_name
+            call("seg_bn_finalize", _p(self.stats), self.nparts, self.n_rows, self.z.npix, st.ptr(bn + "/gamma"),
+                 st.ptr(bn + "/beta"), self.eps, self.momentum, st.ptr(bn + "/moving_mean"), st.ptr(bn + "/moving_variance"),
+                 1 if self.m.graph.ndim == 2 else 0, 1 if training else 0, _p(self.mean), _p(self.invstd), _p(self.scale),
+                 _p(self.shift), s)
+            ph, pw = self.pool_size if self.pooled is not None else (1, 1)
+            call("seg_bn_act_apply", _p(self.z.buf), self.z.cs, 0, _p(self.out.buf), self.out.cs, 0, self.z.N, self.z.H,
+                 self.z.W, self.n_rows, self.cout, _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha),
+                 _p(self.pooled.buf) if self.pooled is not None else None, ph, pw, s)
+        elif self.kind == "convlstm":
+            call("seg_convlstm_gate_fwd", _p(self.z.buf), self.z.cs, _p(self.out.buf), self.out.cs, self.z.npix, self.F, s)
+        elif self.pooled is not None:
+            call("seg_maxpool_fwd", _p(self.out.buf), _p(self.pooled.buf), self.out.N, self.out.H, self.out.W, self.out.cs,
+                 self.pool_size[0], self.pool_size[1], s)
+
+    def plan_backward(self):
+        self.pool_acc = None
+        if self.pooled is not None and self.pooled.gw:
+            self.pool_acc = self.out.claim()
+        self.live = self.out.gw
+        if not self.live:
+            return
+        if self.kind == "convlstm":
+            self.z.ensure_grad()
+        self.dg_args = []
+        for s_i, (t, _c) in enumerate(self.segs):
+            if not t.needs_grad:
+                continue
+            acc = t.claim()
+            a = IgemmFwdArgs()
+            a.g = self.g_dgrad
+            a.nseg = 1
+            a.seg_c[0], a.seg_cs[0], a.seg_woff[0] = self.n_rows, self.z.cs, 0
+            a.seg_ptr[0] = None     # dz pointer filled below
+            a.w = self.wt.data_ptr() + self.woff[s_i] * self.T * self.rows_pad * 2
+            a.Kpad, a.n_rows, a.n_valid = self.rows_pad, t.cs, t.cs
+            a.out, a.out_cs, a.out_coff = t.grad.data_ptr(), t.cs, 0
+            a.bias, a.act, a.alpha, a.stats = None, 0, 0.0, None
+            a.accumulate = acc
+            Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
+            a.tile_m, a.tile_n = pick_tile_fwd(Md, t.cs, 1)
+            self.dg_args.append((a, t, acc, self.flops_seg[s_i]))
+
+    def backward(self):
+        st, s = self.m.store, _stream()
+        if self.pool_acc is not None:
+            call("seg_maxpool_bwd", _p(self.pooled.grad), _p(self.out.buf), _p(self.pooled.buf), _p(self.out.grad),
+                 self.out.N, self.out.H, self.out.W, self.out.cs, self.pool_size[0], self.pool_size[1], self.pool_acc, s)
+        if not self.live:
+            return
+        gs_inv = C.c_void_p(self.m.gs.data_ptr() + 4)
+        if self.has_bn:
+            bn = self.bn_name
+            dA = self.out.grad
+            call("seg_bn_act_bwd_reduce", _p(dA), self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
+                 _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
+                 _p(self.bpart), BN_PARTS_BWD, s)
+            call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
+                 st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
+            call("seg_bn_act_bwd_apply", _p(dA), self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
+                 self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
+                 _p(self.c2), ACT[self.act], float(self.alpha), 0, s)
+            dz = dA
+        elif self.kind == "convlstm":
+            dz = self.z.ensure_grad()
+            call("seg_convlstm_gate_bwd", _p(self.out.grad), self.out.cs, _p(self.z.buf), self.z.cs, _p(dz), self.z.npix, self.F, s)
+            call("seg_act_bwd", _p(dz), _p(dz), _p(dz), self.z.npix, self.z.cs, self.cout, 0, 0.0,
+                 st.ptr(self.bname, "G") if self.bname else None, 1.0, gs_inv, s)
+        else:
+            dz = self.out.grad
+            call("seg_act_bwd", _p(dz), _p(self.out.buf), _p(dz), self.out.npix, self.out.cs, self.cout, ACT[self.act],
+                 float(self.alpha), st.ptr(self.bname, "G") if self.bname else None, 1.0, gs_inv, s)
+        for a, t, acc, fl in self.dg_args:
+            if self.strided and not acc:
+                t.grad.zero_()
+            a.seg_ptr[0] = dz.data_ptr()
+            call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad")
+        self.wg_args.dz = dz.data_ptr()
+        call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad")
+
+
+def _pad_to(n):
+    return lambda a: np.pad(np.asarray(a, np.float32), (0, n - a.shape[0]))
+
+
+class HeadOp(Op):
+    """1x1 conv that is a model output: fp32 result, sigmoid / softmax fused (unet_variants.py:1106, :136)."""
+
+    def __init__(self, m, node: Node, x: DevTensor):
+        self.m, self.node, self.x = m, node, x
+        sh, sw = node.attrs["strides"]
+        self.sy, self.sx = sh, sw
+        self.cin, self.cout = x.C, node.shape[2]
+        if self.cout > 8:
+            raise NotImplementedError("output heads with more than 8 channels are not implemented yet")
+        self.w_ld = x.cs
+        self.act = ACT[node.attrs["activation"]]
+        Ho, Wo = node.shape[0], node.shape[1]
+        self.y = torch.zeros((x.N, Ho, Wo, self.cout), dtype=torch.float32, device=_dev())
+        self.dy = torch.zeros_like(self.y)
+        cin, cout, w_ld = self.cin, self.cout, self.w_ld
+        kspec, bspec = node.params[0], node.params[1]
+
+        def to_engine(k):
+            E = np.zeros((cout, w_ld), np.float32)
+            E[:, :cin] = k.reshape(cin, cout).T
+            return E.reshape(-1)
+        m.store.add(kspec, cout * w_ld, to_engine, lambda f: f.reshape(cout, w_ld)[:, :cin].T.reshape(kspec.shape).copy())
+        m.store.add(bspec, cout, lambda b: np.asarray(b, np.float32), lambda f: f[:cout].copy())
+        self.wname, self.bname = kspec.name, bspec.name
+
+    def forward(self, training):
+        st = self.m.store
+        call("seg_head_fwd", _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W, self.sy, self.sx,
+             st.ptr(self.wname), self.w_ld, st.ptr(self.bname), self.cout, self.act, _p(self.y), _stream())
+
+    def plan_backward(self):
+        self.acc = self.x.claim() if self.x.needs_grad else None
+
+    def backward(self):
+        st = self.m.store
+        if self.acc == 0 and (self.sy, self.sx) != (1, 1):
+            self.x.grad.zero_()
+        call("seg_head_bwd", _p(self.dy), _p(self.y), _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W,
+             self.sy, self.sx, st.ptr(self.wname), self.w_ld, self.cout, self.act,
+             _p(self.x.grad) if self.acc is not None else None, self.acc or 0, _p(self.m.gs), st.ptr(self.wname, "G"),
+             st.ptr(self.bname, "G"), _stream())
+
+
+class BNOp(Op):
+    """Stand-alone BatchNormalization (+ activation) on an existing tensor (MultiResBlock / ResPath tails)."""
+
+    def __init__(self, m, bn: Node, x: DevTensor, act, alpha, out: DevTensor):
+        self.m, self.bn_name, self.x, self.act, self.alpha, self.out = m, bn.name, x, act, alpha, out
+        self.C, self.cl = x.cs, x.C
+        self.eps, self.momentum = float(bn.attrs["eps"]), float(bn.attrs["momentum"])
+        for ps in bn.params:
+            m.store.add(ps, self.C, _pad_to(self.C), lambda f, c=self.cl: f[:c].copy())
+        self.nparts = max(1, min(512, x.npix // 64))
+        dev = _dev()
+        self.stats = torch.zeros(self.nparts * 2 * self.C, dtype=torch.float32, device=dev)
+        self.bpart = torch.zeros(BN_PARTS_BWD * 2 * self.C, dtype=torch.float32, device=dev)
+        self.mean, self.invstd, self.scale, self.shift, self.c1, self.c2 = (
+            torch.zeros(self.C, dtype=torch.float32, device=dev) for _ in range(6))
+
+    def forward(self, training):
+        st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
+        if training:
+            call("seg_bn_stats", _p(x.buf), x.npix, x.cs, 0, self.C, _p(self.stats), self.nparts, self.C, 0, s)
+        call("seg_bn_finalize", _p(self.stats), self.nparts, self.C, x.npix, st.ptr(bn + "/gamma"), st.ptr(bn + "/beta"),
+             self.eps, self.momentum, st.ptr(bn + "/moving_mean"), st.ptr(bn + "/moving_variance"),
+             1 if self.m.graph.ndim == 2 else 0, 1 if training else 0, _p(self.mean), _p(self.invstd), _p(self.scale),
+             _p(self.shift), s)
+        call("seg_bn_act_apply", _p(x.buf), x.cs, 0, _p(self.out.buf), self.out.cs, 0, x.N, x.H, x.W, self.C, self.cl,
+             _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha), None, 1, 1, s)
+
+    def plan_backward(self):
+        self.live = self.out.gw
+        self.acc = self.x.claim() if (self.live and self.x.needs_grad) else None
+
+    def backward(self):
+        if not self.live or self.acc is None:
+            return
+        st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
+        dA = self.out.grad
+        call("seg_bn_act_bwd_reduce", _p(dA), self.out.cs, 0, _p(x.buf), x.cs, 0, x.npix, self.C, _p(self.scale), _p(self.shift),
+             _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha), _p(self.bpart), BN_PARTS_BWD, s)
+        call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.C, x.npix, st.ptr(bn + "/gamma", "G"),
+             st.ptr(bn + "/beta", "G"), 1.0, C.c_void_p(self.m.gs.data_ptr() + 4), _p(self.c1), _p(self.c2), s)
+        call("seg_bn_act_bwd_apply", _p(dA), self.out.cs, 0, _p(x.buf), x.cs, 0, _p(x.grad), x.cs, 0, x.npix, self.C,
+             _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1), _p(self.c2), ACT[self.act],
+             float(self.alpha), self.acc, s)
+
+
+class AddOp(Op):
+    """add([...]) / Add() (+ activation); also used with one input as a plain Activation layer."""
+
+    def __init__(self, m, xs: List[DevTensor], act, alpha, out: DevTensor):
+        self.m, self.xs, self.act, self.alpha, self.out = m, xs, act, alpha, out
+        if len(xs) > 4:
+            raise NotImplementedError("add of more than 4 tensors")
+        self.ptrs = (C.c_void_p * 4)(*[x.buf.data_ptr() for x in xs])
+
+    def forward(self, training):
+        call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
+             float(self.alpha), _stream())
+
+    def plan_backward(self):
+        self.live = self.out.gw
+        if not self.live:
+            return
+        self.mask, gp = 0, []
+        for k, x in enumerate(self.xs):
+            if x.needs_grad:
+                if x.claim():
+                    self.mask |= 1 << k
+                gp.append(x.grad.data_ptr())
+            else:
+                gp.append(None)
+        self.gptrs = (C.c_void_p * 4)(*gp)
+
+    def backward(self):
+        if self.live:
+            call("seg_add_act_bwd", _p(self.out.grad), _p(self.out.buf), self.gptrs, len(self.xs), self.out.buf.numel(),
+                 ACT[self.act], float(self.alpha), self.mask, _stream())
+
+
+class MulOp(Op):
+    def __init__(self, m, a: DevTensor, r: DevTensor, out: DevTensor):
+        self.m, self.a, self.r, self.out = m, a, r, out
+        if r.C != 1:
+            raise NotImplementedError("mul: the second operand must be a 1-channel map (Attention_Block)")
+
+    def forward(self, training):
+        call("seg_mul_bcast_fwd", _p(self.a.buf), _p(self.r.buf), _p(self.out.buf), self.a.npix, self.a.cs, self.r.cs, _stream())
+
+    def plan_backward(self):
+        self.live = self.out.gw
+        if self.live:
+            self.acc_a = self.a.claim() if self.a.needs_grad else None
+            self.acc_r = self.r.claim() if self.r.needs_grad else None
+
+    def backward(self):
+        if self.live:
+            call("seg_mul_bcast_bwd", _p(self.out.grad), _p(self.a.buf), _p(self.r.buf),
+                 _p(self.a.grad) if self.acc_a is not None else None, _p(self.r.grad) if self.acc_r is not None else None,
+                 self.a.npix, self.a.cs, self.r.cs, self.acc_a or 0, self.acc_r or 0, _stream())
+
+
+class UpsampleOp(Op):
+    def __init__(self, m, x: DevTensor, size, bilinear, out: DevTensor):
+        self.m, self.x, self.size, self.bilinear, self.out = m, x, size, 1 if bilinear else 0, out
+
+    def forward(self, training):
+        x = self.x
+        call("seg_upsample_fwd", _p(x.buf), _p(self.out.buf), x.N, x.H, x.W, x.cs, self.size[0], self.size[1], self.bilinear, _stream())
+
+    def plan_backward(self):
+        self.live = self.out.gw and self.x.needs_grad
+        if self.live:
+            self.acc = self.x.claim()
+
+    def backward(self):
+        if self.live:
+            x = self.x
+            call("seg_upsample_bwd", _p(self.out.grad), _p(x.grad), x.N, x.H, x.W, x.cs, self.size[0], self.size[1],
+                 self.bilinear, self.acc, _stream())
+
+
+class PoolOp(Op):
+    def __init__(self, m, x: DevTensor, size, out: DevTensor):
+        self.m, self.x, self.size, self.out = m, x, size, out
+
+    def forward(self, training):
+        x = self.x
+        call("seg_maxpool_fwd", _p(x.buf), _p(self.out.buf), x.N, x.H, x.W, x.cs, self.size[0], self.size[1], _stream())
+
+    def plan_backward(self):
+        self.live = self.out.gw and self.x.needs_grad
+        if self.live:
+            self.acc = self.x.claim()
+
+    def backward(self):
+        if self.live:
+            x = self.x
+            call("seg_maxpool_bwd", _p(self.out.grad), _p(x.buf), _p(self.out.buf), _p(x.grad), x.N, x.H, x.W, x.cs,
+                 self.size[0], self.size[1], self.acc, _stream())
+
+
+# ------------------------------------------------------------------------------------------------ model
+class SegModel:
+    def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0):
+        self.graph = graph
+        self.seed = seed
+        self.name = graph.name
+        self.built = False
+        self.training = True
+        self._x = None
+        self.adam_t = 0
+        self.lr, self.beta_1, self.beta_2, self.epsilon = 2e-4, 0.9, 0.999, 1e-7
+        self.loss_name = "mse"
+        self.world_size = 1
+        self.allreduce = None          # set by dp.DataParallel
+        if batch_size is not None:
+            self.build(batch_size)
+
+    # ---------------------------------------------------------------- Keras-like surface
+    @property
+    def output_names(self):
+        return list(self.graph.output_names)
+
+    def count_params(self) -> int:
+        return self.graph.count_params()
+
+    def summary(self, print_fn=print):
+        print_fn(self.graph.summary())
+
+    def compile(self, loss="mse", optimizer="Adam", lr=2e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, metrics=None):
+        """model.compile(...) (2DCNN/Train.py:322-325).  Losses: 'mse' | 'bce' | 'cce' (mean reduction, applied to every
+        output and summed with unit weights); optimiser: Keras Adam."""
+        if loss not in LOSS:
+            raise ValueError(f"loss must be one of {sorted(LOSS)}")
+        if str(optimizer).lower() != "adam":
+            raise NotImplementedError("only the Adam optimiser is on the hot path (SURVEY.md f3)")
+        self.loss_name, self.lr, self.beta_1, self.beta_2, self.epsilon = loss, lr, beta_1, beta_2, epsilon
+
+    # ---------------------------------------------------------------- build / lowering
+    def build(self, batch_size: int):
+        if not _DryRun.on:
+            if not torch.cuda.is_available():
+                raise RuntimeError("SegModel needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+            _ffi.lib()
+        g = self.graph
+        self.N = int(batch_size)
+        self.tensors: Dict[str, DevTensor] = {}
+        DevTensor.registry = self.tensors
+        self.store = ParamStore()
+        self.ops: List[Op] = []
+        self.heads: List[HeadOp] = []
+        self.gs = torch.ones(2, dtype=torch.float32, device=_dev())        # [grad scale S, 1/S]
+        self.amax = torch.zeros(1, dtype=torch.float32, device=_dev())
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=_dev())
+        cons = g.consumers()
+        live = g.live_nodes()
+        outset = set(g.outputs)
+        val: Dict[int, object] = {}        # node idx -> DevTensor | list[(DevTensor, C)] (virtual concat)
+        done = set()
+        N = self.N
+
+        def only_consumer(i, kind):
+            c = cons[i]
+            if len(c) == 1 and g.nodes[c[0]].kind == kind and i not in outset:
+                return g.nodes[c[0]]
+            return None
+
+        def segs_of(i) -> List[Tuple[DevTensor, int]]:
+            v = val[i]
+            return v if isinstance(v, list) else [(v, v.C)]
+
+        def tensor_of(i) -> DevTensor:
+            v = val[i]
+            if isinstance(v, list):
+                raise NotImplementedError(f"node {g.nodes[i].name}: a concat feeding this layer type must be materialised "
+                                          "(not implemented yet)")
+            return v
+
+        for i in live:
+            if i in done:
+                continue
+            n = g.nodes[i]
+            k = n.kind
+            if k == "input":
+                t = DevTensor(n.name, N, n.shape[0], n.shape[1], n.shape[2])
+                self.ops.append(InputOp(self, t, n.shape[2]))
+                val[i] = t
+            elif k == "concat":
+                segs = []
+                for j in n.inputs:
+                    segs.extend(segs_of(j))
+                if len(segs) > _ffi.MAX_SEG:
+                    raise NotImplementedError(f"{n.name}: more than {_ffi.MAX_SEG} concat segments")
+                val[i] = segs
+            elif k in ("conv", "convT", "convlstm"):
+                if k == "conv" and i in outset and n.attrs["kernel"] == (1, 1):
+                    op = HeadOp(self, n, tensor_of(n.inputs[0]))
+                    self.ops.append(op)
+                    self.heads.append(op)
+                    val[i] = op
+                    continue
+                if k == "conv" and n.attrs["activation"] not in (None, "linear"):
+                    raise NotImplementedError(f"{n.name}: activation inside a non-output conv")
+                last = n
+                chain = [n]
+                bn = only_consumer(i, "bn")
+                if bn is not None:
+                    last = bn
+                    chain.append(bn)
+                act, alpha = None, 0.0
+                an = only_consumer(last.idx, "act") if k != "convlstm" else None
+                if an is not None and an.attrs["fn"] != "softmax":
+                    act, alpha, last = an.attrs["fn"], an.attrs["alpha"], an
+                    chain.append(an)
+                F = n.attrs["filters"] if k == "convlstm" else 0
+                if k == "convlstm" and (F % 8):
+                    raise NotImplementedError(f"{n.name}: ConvLSTM filters must be a multiple of 8 (got {F})")
+                out = DevTensor(last.name, N, last.shape[0], last.shape[1], last.shape[2])
+                pooled, psize, pool_node = None, (1, 1), None
+                for c in cons[last.idx]:
+                    cn = g.nodes[c]
+                    if cn.kind == "maxpool" and bn is not None and last.idx not in outset and pooled is None:
+                        pool_node, psize = cn, cn.attrs["size"]
+                        pooled = DevTensor(cn.name, N, cn.shape[0], cn.shape[1], cn.shape[2])
+                        break
+                op = ConvOp(self, n, k, segs_of(n.inputs[0]), bn, act, alpha, out, pooled, psize, F)
+                self.ops.append(op)
+                for nd in chain:
+                    val[nd.idx] = out
+                    done.add(nd.idx)
+                if pool_node is not None:
+                    val[pool_node.idx] = pooled
+                    done.add(pool_node.idx)
+            elif k == "bn":
+                act, alpha, last = None, 0.0, n
+                an = only_consumer(i, "act")
+                if an is not None and an.attrs["fn"] != "softmax":
+                    act, alpha, last = an.attrs["fn"], an.attrs["alpha"], an
+                x = self._materialise(val, n.inputs[0])
+                out = DevTensor(last.name, N, *last.shape)
+                self.ops.append(BNOp(self, n, x, act, alpha, out))
+                val[i] = val[last.idx] = out
+                done.add(last.idx)
+            elif k == "add":
+                act, alpha, last = None, 0.0, n
+                an = only_consumer(i, "act")
+                if an is not None and an.attrs["fn"] != "softmax":
+                    act, alpha, last = an.attrs["fn"], an.attrs["alpha"], an
+                xs = [tensor_of(j) for j in n.inputs]
+                out = DevTensor(last.name, N, *last.shape)
+                self.ops.append(AddOp(self, xs, act, alpha, out))
+                val[i] = val[last.idx] = out
+                done.add(last.idx)
+            elif k == "act":
+                x = tensor_of(n.inputs[0])
+                out = DevTensor(n.name, N, *n.shape)
+                self.ops.append(AddOp(self, [x], n.attrs["fn"], n.attrs["alpha"], out))
+                val[i] = out
+            elif k == "mul":
+                a, r = tensor_of(n.inputs[0]), tensor_of(n.inputs[1])
+                out = DevTensor(n.name, N, *n.shape)
+                self.ops.append(MulOp(self, a, r, out))
+                val[i] = out
+            elif k == "upsample":
+                x = tensor_of(n.inputs[0])
+                out = DevTensor(n.name, N, *n.shape)
+                self.ops.append(UpsampleOp(self, x, n.attrs["size"], n.attrs["interpolation"] == "bilinear", out))
+                val[i] = out
+            elif k == "maxpool":
+                x = tensor_of(n.inputs[0])
+                out = DevTensor(n.name, N, *n.shape)
+                self.ops.append(PoolOp(self, x, n.attrs["size"], out))
+                val[i] = out
+            else:
+                raise NotImplementedError(f"layer kind {k!r} ({n.name}) is not lowered to HIP yet")
+        for oi in g.outputs:
+            if not isinstance(val[oi], HeadOp):
+                raise NotImplementedError("model outputs must be 1x1 conv heads")
+        self.out_heads = [val[oi] for oi in g.outputs]
+        # ---- parameters
+        self.store.allocate()
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                op.finalize()
+        self.set_weights({p.name: init_param(p, self.seed) for p in g.param_specs()})
+        # ---- static backward schedule (accumulate flags)
+        for op in reversed(self.ops):
+            op.plan_backward()
+        DevTensor.registry = None
+        self.built = True
+        return self
+
+    def _materialise(self, val, i) -> DevTensor:
+        v = val[i]
+        if isinstance(v, list):
+            raise NotImplementedError("BatchNormalization over a concatenation (MultiResBlock) is not lowered yet")
+        return v
+
+    # ---------------------------------------------------------------- weights
+    def set_weights(self, weights: Dict[str, np.ndarray]):
+        """weights: structural name -> numpy array in Keras layout (see graph.py)."""
+        st = self.store
+        host_p = st.P.cpu().numpy()
+        host_s = st.S.cpu().numpy()
+        for name, arr in weights.items():
+            s = st.slots.get(name)
+            if s is None:
+                raise KeyError(f"unknown parameter {name!r}")
+            arr = np.asarray(arr, np.float32)
+            if tuple(arr.shape) != tuple(s.spec.shape):
+                raise ValueError(f"{name}: shape {arr.shape} != {s.spec.shape}")
+            flat = np.asarray(s.to_engine(arr), np.float32).reshape(-1)
+            assert flat.size == s.numel, (name, flat.size, s.numel)
+            (host_p if s.trainable else host_s)[s.off:s.off + s.numel] = flat
+        st.P.copy_(torch.from_numpy(host_p))
+        st.S.copy_(torch.from_numpy(host_s))
+        self._refresh_copies()
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        st = self.store
+        host_p, host_s = st.P.cpu().numpy(), st.S.cpu().numpy()
+        out = {}
+        for name, s in st.slots.items():
+            src = host_p if s.trainable else host_s
+            out[name] = np.asarray(s.from_engine(src[s.off:s.off + s.numel]), np.float32).reshape(s.spec.shape)
+        return out
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        """Gradients of the last backward pass, Keras layout (already divided by the internal gradient scale)."""
+        st = self.store
+        host = st.G.cpu().numpy()
+        return {name: np.asarray(s.from_engine(host[s.off:s.off + s.numel]), np.float32).reshape(s.spec.shape)
+                for name, s in st.slots.items() if s.trainable}
+
+    def _refresh_copies(self):
+        st = self.store
+        call("seg_cast_f32_f16", _p(st.P), _p(st.P16), st.P.numel(), _stream())
+        for op in self.ops:
+            op.post_step()
+
+    # ---------------------------------------------------------------- execution
+    def _check_x(self, x):
+        g = self.graph
+        H, W, Cin = g.nodes[g.inputs[0]].shape
+        if g.ndim == 1 and x.dim() == 3:
+            x = x.unsqueeze(1)
+        if not self.built:
+            self.build(x.shape[0])
+        if tuple(x.shape) != (self.N, H, W, Cin):
+            raise ValueError(f"input shape {tuple(x.shape)} != {(self.N, H, W, Cin)} (NHWC; the batch size is fixed at build)")
+        return x.to(device=_dev(), dtype=torch.float32).contiguous()
+
+    def forward(self, x: torch.Tensor, training: Optional[bool] = None) -> List[torch.Tensor]:
+        """x: (N,H,W,C) [2D] or (N,L,C) [1D] float32.  Returns [out, level1, ...] fp32 NHWC (views of internal buffers)."""
+        training = self.training if training is None else training
+        self._x = self._check_x(x)
+        for op in self.ops:
+            op.forward(training)
+        outs = [h.y for h in self.out_heads]
+        return [o.squeeze(1) for o in outs] if self.graph.ndim == 1 else outs
+
+    __call__ = forward
+
+    def predict(self, x, batch_size=None, verbose=0):
+        """model.predict (2DCNN/Test.py:153,161): inference-mode BN.  Returns numpy, a list when the model has several outputs."""
+        x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x
+        outs = [o.cpu().numpy() for o in self.forward(x, training=False)]
+        return outs if len(outs) > 1 else outs[0]
+
+    def backward(self, grads: Optional[Sequence[torch.Tensor]] = None):
+        """Backward pass.  grads[i] = dLoss/d output_i (fp32, same shape as the output); None: use the gradients the
+        loss kernels left in the heads' dy buffers."""
+        s = _stream()
+        if grads is not None:
+            for h, gt in zip(self.out_heads, grads):
+                h.dy.copy_(gt.reshape(h.dy.shape))
+        self.amax.zero_()
+        for h in self.out_heads:
+            call("seg_absmax", _p(h.dy), h.dy.numel(), _p(self.amax), s)
+        call("seg_grad_scale", _p(self.amax), GRAD_TARGET, _p(self.gs), s)
+        self.store.G.zero_()
+        for op in reversed(self.ops):
+            op.backward()
+
+    def compute_loss(self, targets: Sequence[torch.Tensor], loss: Optional[str] = None) -> torch.Tensor:
+        """Sum over outputs of the mean-reduced loss (unit weights, 2DCNN/Train.py:322); fills the heads' dy buffers."""
+        kind = LOSS[loss or self.loss_name]
+        self.loss_buf.zero_()
+        s = _stream()
+        for h, t in zip(self.out_heads, targets):
+            t = t.to(device=_dev(), dtype=torch.float32).contiguous()
+            if t.numel() != h.y.numel():
+                raise ValueError(f"target for {h.node.name}: {tuple(t.shape)} vs output {tuple(h.y.shape)}")
+            npix = h.y.numel() // h.cout
+            call("seg_loss_fwd_bwd", kind, _p(h.y), _p(t), npix, h.cout, _p(self.loss_buf), _p(h.dy), s)
+        return self.loss_buf
+
+    def optimizer_step(self):
+        st = self.store
+        if self.allreduce is not None:
+            self.allreduce(st.G)
+        self.adam_t += 1
+        a_t = self.lr * math.sqrt(1.0 - self.beta_2 ** self.adam_t) / (1.0 - self.beta_1 ** self.adam_t)
+        call("seg_adam_step", _p(st.P), _p(st.G), _p(st.M), _p(st.V), _p(st.P16), st.P.numel(), a_t, self.beta_1, self.beta_2,
+             self.epsilon, 1.0 / self.world_size, _stream())
+        for op in self.ops:
+            op.post_step()
+
+    def train_step(self, x, targets, loss: Optional[str] = None) -> torch.Tensor:
+        """One optimiser step = Keras' default train_step (Train.py:394-415): forward (training BN) -> loss -> backward
+        -> [gradient all-reduce] -> Adam.  Returns the (device) scalar loss; nothing synchronises with the host."""
+        self.forward(x, training=True)
+        if not isinstance(targets, (list, tuple)):
+            targets = [targets]
+        lv = self.compute_loss(targets, loss)
+        self.backward(None)
+        self.optimizer_step()
+        return lv
