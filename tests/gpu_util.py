@@ -143,15 +143,19 @@ def ref_conv(xs, kern, bias, kind, strides):
 
 
 # ------------------------------------------------------------------------------------------------ whole-model compare
-def compare_model(model, x, targets, loss, verbose=False):
+def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False):
     """Runs forward(training) + loss + backward on the GPU model and on the oracle primitives wired by the same
     graph (the wiring itself is checked against the independent oracle wiring in test_graph_builders.py).
-    Returns dict with per-node forward errors (max abs), loss pair and per-parameter relative gradient errors."""
+    Returns per-node forward errors, loss pair, per-node activation-gradient errors and per-parameter gradient
+    errors (all 'max abs err', with the reference magnitude beside it)."""
     g = model.graph
     w_np = model.get_weights()
     W = {k: torch.from_numpy(v.copy()).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
          for k, v in w_np.items()}
-    outs_ref, vals = run_graph(g, x, W, training=True, return_all=True)
+    outs_ref, vals = run_graph(g, x, W, training=True, return_all=True, emulate_fp16=emulate_fp16)
+    for v in vals.values():
+        if v.requires_grad:
+            v.retain_grad()
     lossf = LOSSES[loss]
     ref_loss = sum(lossf(o, t) for o, t in zip(outs_ref, targets))
     ref_loss.backward()
@@ -159,7 +163,8 @@ def compare_model(model, x, targets, loss, verbose=False):
     lv = model.compute_loss(targets, loss)
     model.backward(None)
     torch.cuda.synchronize()
-    res = {"nodes": [], "loss": (float(lv.cpu()), float(ref_loss.detach())), "grads": {}, "outs": []}
+    S = float(model.gs[0].cpu())
+    res = {"nodes": [], "loss": (float(lv.cpu()), float(ref_loss.detach())), "grads": {}, "outs": [], "agrads": [], "S": S}
     for name, t in model.tensors.items():
         key = name[:-2] if name.endswith(":z") else name
         if key not in vals:
@@ -172,18 +177,47 @@ def compare_model(model, x, targets, loss, verbose=False):
         res["nodes"].append((name, float((got - ref).abs().max()), float(ref.abs().max())))
     for o, r in zip(outs, outs_ref):
         res["outs"].append(float((o.cpu() - r.detach()).abs().max()))
+    # activation gradients: a ConvOp leaves dL/d(conv output) in its out.grad (in place); other tensors keep dL/d(tensor)
+    seen = set()
+    for op in model.ops:
+        if isinstance(op, M.ConvOp) and getattr(op, "live", False) and op.kind != "convlstm":
+            ref = vals[op.node.name].grad
+            t = op.out
+            if ref is not None and t.grad is not None:
+                got = t.grad[..., :t.C].float().cpu() / S
+                res["agrads"].append(("d/" + op.node.name, float((got - ref).abs().max()), float(ref.abs().max())))
+            seen.add(t.name)
+    for name, t in model.tensors.items():
+        if name in seen or name.endswith(":z") or t.grad is None or name not in vals or vals[name].grad is None:
+            continue
+        ref = vals[name].grad
+        got = t.grad[..., :t.C].float().cpu() / S
+        if got.shape == ref.shape:
+            res["agrads"].append(("d/" + name, float((got - ref).abs().max()), float(ref.abs().max())))
+    res["gcos"] = {}
     grads = model.get_grads()
+    gmax = max((float(t.grad.abs().max()) for t in W.values() if t.grad is not None), default=1.0)
+    res["gmax"] = gmax
     for k, t in W.items():
         if t.grad is None or k not in grads:
             continue
         gr = t.grad.numpy()
-        den = float(np.abs(gr).max())
-        res["grads"][k] = (float(np.abs(grads[k] - gr).max()), den)
+        res["grads"][k] = (float(np.abs(grads[k] - gr).max()), float(np.abs(gr).max()))
+        a, b = grads[k].reshape(-1).astype(np.float64), gr.reshape(-1).astype(np.float64)
+        na, nb = np.linalg.norm(a), np.linalg.norm(b)
+        res["gcos"][k] = (float(a @ b / (na * nb + 1e-300)), float(na / (nb + 1e-300)), float(np.abs(gr).max()))
     if verbose:
         for n, e, mag in res["nodes"]:
             print(f"   node {n:34s} max|err| {e:.3e}  (ref max {mag:.3e})")
-        print("   outs", ["%.3e" % e for e in res["outs"]], "loss", res["loss"])
-        worst = sorted(res["grads"].items(), key=lambda kv: -(kv[1][0] / (kv[1][1] + 1e-20)))
-        for k, (e, d) in worst[:12]:
-            print(f"   grad {k:40s} abs err {e:.3e} / max {d:.3e} = {e / (d + 1e-20):.3e}")
+        print("   outs", ["%.3e" % e for e in res["outs"]], "loss", res["loss"], "S", S)
+        for n, e, mag in res["agrads"]:
+            print(f"   agrad {n:36s} max|err| {e:.3e}  (ref max {mag:.3e})  rel {e / (mag + 1e-30):.3e}")
+        for k, (e, d) in res["grads"].items():
+            print(f"   pgrad {k:40s} abs err {e:.3e} / max {d:.3e} = {e / (d + 1e-30):.3e}")
     return res
+
+
+def grad_rel_err(res, floor=1e-4):
+    """worst |err| / (max|ref| + floor * global max |grad|): parameters whose true gradient is numerically zero
+    (conv bias in front of BatchNormalization) are judged against the global gradient scale."""
+    return max((e / (d + floor * res["gmax"]) for e, d in res["grads"].values()), default=0.0)

@@ -1,0 +1,515 @@
+"""GPU parity tests, op level: every C-ABI entry point of include/seg_hip.h against the oracle primitive
+(oracle/keras_ref.py, torch-CPU fp32) on IDENTICAL fp16-representable inputs, so that activation masks agree and
+the comparison isolates kernel logic.  Tolerances: fp16 output storage = 2^-11 relative (about 5e-4); fp32
+outputs (statistics, weight gradients, heads, losses, Adam) 1e-4 or tighter."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import gpu_util as U
+from gpu_util import P, ffi, h16, stream, to_dev_nhwc
+from oracle import keras_ref as K
+from oracle import train_ref as TR
+
+rng = np.random.default_rng(1234)
+ACT = ffi.ACT
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def dev_f32(a):
+    return torch.as_tensor(np.asarray(a, np.float32)).cuda().contiguous()
+
+
+def from_dev(t, Cc):
+    return t[..., :Cc].float().cpu()
+
+
+# ------------------------------------------------------------------------------------------------ implicit GEMM
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64)])
+def test_conv3x3_fwd_tiles_bias_relu_stats(tile):
+    xs = [torch.randn(2, 16, 16, 32)]
+    kern = rng.standard_normal((3, 3, 32, 64)).astype(np.float32) * 0.1
+    b = rng.standard_normal(64).astype(np.float32)
+    out, st, pad = U.igemm_conv(xs, kern, b, "conv", (1, 1), "relu", 0.0, True, tile)
+    pre = U.ref_conv(xs, kern, b, "conv", (1, 1))
+    assert rel(out, torch.relu(pre)) < 2e-3
+    assert rel(st[:, :64], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-4
+
+
+@pytest.mark.parametrize("case", [
+    dict(shape=(2, 16, 24), cins=[64, 32, 64], cout=128, k=(3, 3), kind="conv", s=(1, 1)),       # virtual concat
+    dict(shape=(2, 16, 16), cins=[3], cout=64, k=(3, 3), kind="conv", s=(1, 1)),                 # first layer (Cin 3 -> pad 8)
+    dict(shape=(3, 13, 11), cins=[40], cout=24, k=(3, 3), kind="conv", s=(1, 1)),                # ragged sizes
+    dict(shape=(2, 16, 16), cins=[64], cout=32, k=(1, 1), kind="conv", s=(2, 2)),                # attention theta
+    dict(shape=(2, 16, 16), cins=[64], cout=1, k=(1, 1), kind="conv", s=(1, 1)),                 # attention psi (Cout 1 -> pad 8)
+    dict(shape=(4, 1, 128), cins=[16], cout=16, k=(1, 3), kind="conv", s=(1, 1)),                # Conv1D
+    dict(shape=(2, 8, 8), cins=[64], cout=32, k=(4, 4), kind="convT", s=(2, 2)),                 # Conv2DTranspose 4x4/s2
+    dict(shape=(4, 1, 64), cins=[32], cout=16, k=(1, 2), kind="convT", s=(1, 2)),                # Conv1DTranspose k2/s2
+    dict(shape=(4, 8, 8), cins=[256], cout=256, k=(3, 3), kind="conv", s=(1, 1)),                # bottleneck-like
+], ids=lambda c: f"{c['kind']}{c['k']}s{c['s']}-{c['cins']}->{c['cout']}")
+def test_igemm_fwd_cases(case):
+    N, H, W = case["shape"]
+    xs = [torch.randn(N, H, W, c) for c in case["cins"]]
+    cin = sum(case["cins"])
+    kshape = (*case["k"], case["cout"], cin) if case["kind"] == "convT" else (*case["k"], cin, case["cout"])
+    kern = rng.standard_normal(kshape).astype(np.float32) * 0.1
+    b = rng.standard_normal(case["cout"]).astype(np.float32)
+    out, st, pad = U.igemm_conv(xs, kern, b, case["kind"], case["s"], "leaky_relu", 0.3, True)
+    pre = U.ref_conv(xs, kern, b, case["kind"], case["s"])
+    assert out.shape == pre.shape
+    assert rel(out, K.activation(pre, "leaky_relu", 0.3)) < 2e-3
+    assert pad == 0.0                                            # channel padding stays exactly zero
+    assert rel(st[:, :case["cout"]], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-4
+
+
+def test_igemm_fwd_accumulate():
+    xs = [torch.randn(2, 16, 16, 32)]
+    kern = rng.standard_normal((3, 3, 32, 64)).astype(np.float32) * 0.1
+    prev = h16(torch.randn(2, 16, 16, 64))
+    out, _, _ = U.igemm_conv(xs, kern, None, "conv", (1, 1), None, 0.0, False, None, accumulate_into=prev)
+    assert rel(out, prev + U.ref_conv(xs, kern, None, "conv", (1, 1))) < 2e-3
+
+
+@pytest.mark.parametrize("kind,k,s,shape,cin,cout", [("conv", (3, 3), (1, 1), (2, 16, 16), 32, 64),
+                                                     ("conv", (1, 3), (1, 1), (4, 1, 64), 16, 32),
+                                                     ("convT", (4, 4), (2, 2), (2, 8, 8), 64, 32),
+                                                     ("convT", (1, 2), (1, 2), (4, 1, 32), 32, 16),
+                                                     ("conv", (1, 1), (2, 2), (2, 16, 16), 64, 32)])
+def test_dgrad_matches_autograd(kind, k, s, shape, cin, cout):
+    """data gradient = the same kernel on dz with transposed weights and the gather geometry of model.geom_*_dgrad."""
+    N, H, W = shape
+    x = h16(torch.randn(N, H, W, cin)).requires_grad_(True)
+    kshape = (*k, cout, cin) if kind == "convT" else (*k, cin, cout)
+    kern = h16(torch.from_numpy(rng.standard_normal(kshape).astype(np.float32) * 0.1))
+    y = (K.conv2d_transpose_same if kind == "convT" else K.conv2d_same)(x, kern, None, s)
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    M = U.M
+    n_rows, T, Kpad = U.r8(cout), k[0] * k[1], U.r32(U.r8(cin))
+    E = M.pack_gemm_weight(kern.numpy(), [cin], [0], n_rows, Kpad, kind == "convT")
+    rows_pad = U.r32(n_rows)
+    wt = torch.zeros(Kpad * T * rows_pad, dtype=torch.float16, device="cuda")
+    Ed = dev_f32(E.reshape(-1))
+    ffi.call("seg_transpose_w", P(Ed), P(wt), n_rows, T, Kpad, rows_pad, stream())
+    g = (M.geom_convT_dgrad if kind == "convT" else M.geom_conv_dgrad)(N, H, W, *k, *s)
+    dzd = to_dev_nhwc(dz)
+    cs_in = U.r8(cin)
+    dx = torch.zeros((N, H, W, cs_in), dtype=torch.float16, device="cuda")
+    a = ffi.IgemmFwdArgs()
+    a.g, a.nseg = g, 1
+    a.seg_c[0], a.seg_cs[0], a.seg_woff[0], a.seg_ptr[0] = n_rows, dzd.shape[3], 0, dzd.data_ptr()
+    a.w, a.Kpad, a.n_rows, a.n_valid = wt.data_ptr(), rows_pad, cs_in, cs_in
+    a.out, a.out_cs, a.out_coff = dx.data_ptr(), cs_in, 0
+    a.tile_m, a.tile_n = M.pick_tile_fwd(N * g.Hl * g.Wl, cs_in, 1)
+    ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(dx, cin), x.grad) < 2e-3
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("case", [
+    dict(shape=(2, 16, 16), cins=[32], cout=64, k=(3, 3), kind="conv", s=(1, 1), sk=4, tile=(64, 64)),
+    dict(shape=(2, 16, 24), cins=[64, 32, 64], cout=128, k=(3, 3), kind="conv", s=(1, 1), sk=3, tile=(128, 128)),
+    dict(shape=(2, 16, 16), cins=[64, 32], cout=128, k=(3, 3), kind="conv", s=(1, 1), sk=2, tile=(128, 64)),
+    dict(shape=(2, 16, 16), cins=[3], cout=64, k=(3, 3), kind="conv", s=(1, 1), sk=None, tile=None),
+    dict(shape=(3, 13, 11), cins=[40], cout=24, k=(3, 3), kind="conv", s=(1, 1), sk=None, tile=None),
+    dict(shape=(2, 8, 8), cins=[64], cout=32, k=(4, 4), kind="convT", s=(2, 2), sk=None, tile=None),
+    dict(shape=(2, 16, 16), cins=[64], cout=32, k=(1, 1), kind="conv", s=(2, 2), sk=None, tile=None),
+    dict(shape=(4, 1, 64), cins=[32], cout=16, k=(1, 2), kind="convT", s=(1, 2), sk=None, tile=None),
+], ids=lambda c: f"{c['kind']}{c['k']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
+def test_wgrad_matches_autograd(case, variant):
+    N, H, W = case["shape"]
+    xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]
+    cin = sum(case["cins"])
+    kshape = (*case["k"], case["cout"], cin) if case["kind"] == "convT" else (*case["k"], cin, case["cout"])
+    kern = torch.zeros(kshape, requires_grad=True)
+    y = (K.conv2d_transpose_same if case["kind"] == "convT" else K.conv2d_same)(torch.cat(xs, -1), kern, None, case["s"])
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    got = U.igemm_wgrad(xs, dz, kshape, case["kind"], case["s"], variant, case["sk"], case["tile"])
+    assert rel(torch.from_numpy(got), kern.grad) < 1e-4          # fp32 accumulate of exact fp16 products
+
+
+# ------------------------------------------------------------------------------------------------ BatchNormalization
+def _bn_setup(N, H, W, Cc, act):
+    cs = U.r8(Cc)
+    z = h16(torch.randn(N, H, W, Cc) * 1.7 + 0.3)
+    gamma = torch.rand(Cc) + 0.5
+    beta = torch.randn(Cc) * 0.2
+    return cs, z, gamma, beta
+
+
+@pytest.mark.parametrize("Cc,act,pool", [(64, "relu", (2, 2)), (24, "relu", None), (8, "sigmoid", None), (128, None, None),
+                                         (16, "relu", (1, 2))])
+def test_bn_forward_training(Cc, act, pool):
+    N, H, W = 2, 12, 16
+    cs, z, gamma, beta = _bn_setup(N, H, W, Cc, act)
+    zd = to_dev_nhwc(z)
+    npix = N * H * W
+    nparts = 7
+    stats = torch.zeros(nparts * 2 * cs, dtype=torch.float32, device="cuda")
+    ffi.call("seg_bn_stats", P(zd), npix, cs, 0, cs, P(stats), nparts, cs, 0, stream())
+    pad = lambda v, fill=0.0: dev_f32(np.concatenate([v.numpy(), np.full(cs - Cc, fill, np.float32)]))
+    g_d, b_d, mm, mv = pad(gamma), pad(beta), pad(torch.zeros(Cc)), pad(torch.ones(Cc), 1.0)
+    mean, invstd, scale, shift = (torch.zeros(cs, device="cuda") for _ in range(4))
+    ffi.call("seg_bn_finalize", P(stats), nparts, cs, npix, P(g_d), P(b_d), 1e-3, 0.99, P(mm), P(mv), 1, 1, P(mean), P(invstd),
+             P(scale), P(shift), stream())
+    y = torch.zeros_like(zd)
+    pooled = None
+    if pool:
+        pooled = torch.zeros((N, H // pool[0], W // pool[1], cs), dtype=torch.float16, device="cuda")
+    ffi.call("seg_bn_act_apply", P(zd), cs, 0, P(y), cs, 0, N, H, W, cs, Cc, P(scale), P(shift), ACT[act], 0.0,
+             P(pooled) if pool else None, *(pool or (1, 1)), stream())
+    torch.cuda.synchronize()
+    ref, nm, nv = K.batchnorm(z, gamma, beta, torch.zeros(Cc), torch.ones(Cc), True, fused_4d=True)
+    ref = K.activation(ref, act)
+    assert float((from_dev(y, Cc) - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+    assert rel(mean[:Cc].cpu(), z.mean((0, 1, 2))) < 1e-4
+    assert rel(mm[:Cc].cpu(), nm) < 1e-4 and rel(mv[:Cc].cpu(), nv) < 1e-4      # moving stats: momentum .99, unbiased var
+    if pool:
+        pr = K.maxpool(from_dev(y, Cc), pool)
+        assert torch.equal(from_dev(pooled, Cc), pr)                               # pooled == max of the stored tensor
+    if cs > Cc:
+        assert float(y[..., Cc:].abs().max()) == 0.0
+
+
+def test_bn_finalize_many_parts_prereduce():
+    cs, npix, nparts = 64, 100000, 1000
+    part = torch.rand(nparts, 2, cs)
+    part[:, 1] += 1.0
+    stats = part.clone().cuda().reshape(-1)
+    ones, zeros = torch.ones(cs, device="cuda"), torch.zeros(cs, device="cuda")
+    mm, mv = zeros.clone(), ones.clone()
+    mean, invstd, scale, shift = (torch.zeros(cs, device="cuda") for _ in range(4))
+    ffi.call("seg_bn_finalize", P(stats), nparts, cs, npix, P(ones), P(zeros), 1e-3, 0.99, P(mm), P(mv), 1, 1, P(mean), P(invstd),
+             P(scale), P(shift), stream())
+    torch.cuda.synchronize()
+    s = part.sum(0)
+    m = s[0] / npix
+    v = s[1] / npix - m * m
+    assert rel(mean.cpu(), m) < 1e-5 and rel(invstd.cpu(), torch.rsqrt(v + 1e-3)) < 1e-5
+
+
+def test_bn_inference_uses_moving_stats():
+    cs = 16
+    g_d, b_d = dev_f32(np.full(cs, 1.5)), dev_f32(np.full(cs, 0.25))
+    mm, mv = dev_f32(np.linspace(-1, 1, cs)), dev_f32(np.linspace(0.5, 2, cs))
+    scale, shift = torch.zeros(cs, device="cuda"), torch.zeros(cs, device="cuda")
+    ffi.call("seg_bn_finalize", None, 0, cs, 0, P(g_d), P(b_d), 1e-3, 0.99, P(mm), P(mv), 1, 0, None, None, P(scale), P(shift), stream())
+    torch.cuda.synchronize()
+    sc = 1.5 / np.sqrt(np.linspace(0.5, 2, cs) + 1e-3)
+    assert np.allclose(scale.cpu().numpy(), sc, rtol=1e-5)
+    assert np.allclose(shift.cpu().numpy(), 0.25 - np.linspace(-1, 1, cs) * sc, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("Cc,act", [(64, "relu"), (24, None), (8, "sigmoid"), (256, "relu")])
+def test_bn_backward_matches_autograd(Cc, act):
+    N, H, W = 2, 10, 12
+    cs, z, gamma, beta = _bn_setup(N, H, W, Cc, act)
+    npix = N * H * W
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y, _, _ = K.batchnorm(zr, gr, br, torch.zeros(Cc), torch.ones(Cc), True)
+    y = K.activation(y, act)
+    dA = h16(torch.randn_like(y))
+    (y * dA).sum().backward()
+    # GPU: forward statistics first (the backward consumes mean / invstd / scale / shift of the forward)
+    zd, dAd = to_dev_nhwc(z), to_dev_nhwc(dA)
+    pad = lambda v, fill=0.0: dev_f32(np.concatenate([v.detach().numpy(), np.full(cs - Cc, fill, np.float32)]))
+    g_d, b_d, mm, mv = pad(gamma), pad(beta), pad(torch.zeros(Cc)), pad(torch.ones(Cc), 1.0)
+    stats = torch.zeros(4 * 2 * cs, dtype=torch.float32, device="cuda")
+    mean, invstd, scale, shift, c1, c2, dg, db = (torch.zeros(cs, device="cuda") for _ in range(8))
+    ffi.call("seg_bn_stats", P(zd), npix, cs, 0, cs, P(stats), 4, cs, 0, stream())
+    ffi.call("seg_bn_finalize", P(stats), 4, cs, npix, P(g_d), P(b_d), 1e-3, 0.99, P(mm), P(mv), 1, 1, P(mean), P(invstd), P(scale),
+             P(shift), stream())
+    nparts = 37
+    part = torch.zeros(nparts * 2 * cs, dtype=torch.float32, device="cuda")
+    ffi.call("seg_bn_act_bwd_reduce", P(dAd), cs, 0, P(zd), cs, 0, npix, cs, P(scale), P(shift), P(mean), P(invstd), ACT[act], 0.0,
+             P(part), nparts, stream())
+    gsv = torch.tensor([4.0, 0.25], device="cuda")
+    ffi.call("seg_bn_bwd_finalize", P(part), nparts, cs, npix, P(dg), P(db), 2.0, C.c_void_p(gsv.data_ptr() + 4), P(c1), P(c2), stream())
+    dz = torch.zeros_like(zd)
+    ffi.call("seg_bn_act_bwd_apply", P(dAd), cs, 0, P(zd), cs, 0, P(dz), cs, 0, npix, cs, P(scale), P(shift), P(mean), P(invstd), P(c1),
+             P(c2), ACT[act], 0.0, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(dg[:Cc].cpu(), 0.5 * gr.grad) < 2e-4 and rel(db[:Cc].cpu(), 0.5 * br.grad) < 2e-4     # gscale 2 * 0.25
+    assert rel(from_dev(dz, Cc), zr.grad) < 2e-3
+    # in-place + accumulate form used by the engine
+    acc0 = h16(torch.randn(N, H, W, Cc))
+    buf = to_dev_nhwc(acc0)
+    ffi.call("seg_bn_act_bwd_apply", P(dAd), cs, 0, P(zd), cs, 0, P(buf), cs, 0, npix, cs, P(scale), P(shift), P(mean), P(invstd), P(c1),
+             P(c2), ACT[act], 0.0, 1, stream())
+    ffi.call("seg_bn_act_bwd_apply", P(dAd), cs, 0, P(zd), cs, 0, P(dAd), cs, 0, npix, cs, P(scale), P(shift), P(mean), P(invstd), P(c1),
+             P(c2), ACT[act], 0.0, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(buf, Cc), acc0 + zr.grad) < 3e-3
+    assert rel(from_dev(dAd, Cc), zr.grad) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("act,alpha", [("leaky_relu", 0.3), ("relu", 0.0), ("sigmoid", 0.0), (None, 0.0)])
+def test_act_bwd_and_bias_grad(act, alpha):
+    N, H, W, Cc = 2, 9, 7, 24
+    z = torch.randn(N, H, W, Cc)
+    y = h16(K.activation(z, act, alpha))
+    dy = h16(torch.randn(N, H, W, Cc))
+    yd, dyd = to_dev_nhwc(y), to_dev_nhwc(dy)
+    db = torch.zeros(Cc, device="cuda")
+    gsv = torch.tensor([8.0, 0.125], device="cuda")
+    ffi.call("seg_act_bwd", P(dyd), P(yd), P(dyd), N * H * W, U.r8(Cc), Cc, ACT[act], alpha, P(db), 1.0, C.c_void_p(gsv.data_ptr() + 4), stream())
+    torch.cuda.synchronize()
+    if act == "leaky_relu":
+        d = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, alpha))
+    elif act == "relu":
+        d = (y > 0).float()
+    elif act == "sigmoid":
+        d = y * (1 - y)
+    else:
+        d = torch.ones_like(y)
+    ref = dy * d
+    assert rel(from_dev(dyd, Cc), ref) < 1e-3
+    assert rel(db.cpu(), 0.125 * h16(ref).sum((0, 1, 2))) < 2e-3
+
+
+@pytest.mark.parametrize("shape,pool", [((2, 8, 12, 16), (2, 2)), ((2, 9, 7, 8), (2, 2)), ((3, 1, 32, 16), (1, 2)), ((1, 16, 16, 8), (4, 4))])
+def test_maxpool_fwd_bwd(shape, pool):
+    N, H, W, Cc = shape
+    x = h16(torch.randn(shape)).requires_grad_(True)
+    y = K.maxpool(x, pool)
+    dy = h16(torch.randn_like(y))
+    (y * dy).sum().backward()
+    xd = to_dev_nhwc(x.detach())
+    yd = torch.zeros((N, H // pool[0], W // pool[1], Cc), dtype=torch.float16, device="cuda")
+    ffi.call("seg_maxpool_fwd", P(xd), P(yd), N, H, W, Cc, *pool, stream())
+    dxd = torch.full_like(xd, 3.0)
+    dyd = to_dev_nhwc(dy)
+    ffi.call("seg_maxpool_bwd", P(dyd), P(xd), P(yd), P(dxd), N, H, W, Cc, *pool, 0, stream())
+    acc = h16(torch.randn(shape))
+    accd = to_dev_nhwc(acc)
+    ffi.call("seg_maxpool_bwd", P(dyd), P(xd), P(yd), P(accd), N, H, W, Cc, *pool, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(from_dev(yd, Cc), y.detach())
+    assert torch.equal(from_dev(dxd, Cc), x.grad)                # no ties in random data; border rows get exact zeros
+    assert rel(from_dev(accd, Cc), acc + x.grad) < 1e-3
+
+
+def test_maxpool_bwd_tie_goes_to_first_maximum():
+    x = torch.zeros(1, 2, 2, 8)
+    x[0, 0, 1, :] = 1.0
+    x[0, 1, 0, :] = 1.0                                           # two equal maxima: (0,1) comes first in scan order
+    xd = to_dev_nhwc(x)
+    yd = torch.zeros((1, 1, 1, 8), dtype=torch.float16, device="cuda")
+    ffi.call("seg_maxpool_fwd", P(xd), P(yd), 1, 2, 2, 8, 2, 2, stream())
+    dxd = torch.zeros_like(xd)
+    dyd = to_dev_nhwc(torch.full((1, 1, 1, 8), 5.0))
+    ffi.call("seg_maxpool_bwd", P(dyd), P(xd), P(yd), P(dxd), 1, 2, 2, 8, 2, 2, 0, stream())
+    torch.cuda.synchronize()
+    got = dxd.float().cpu()
+    assert float(got[0, 0, 1, 0]) == 5.0 and float(got[0, 1, 0, 0]) == 0.0 and float(got.sum()) == 40.0
+
+
+@pytest.mark.parametrize("shape,f,bil", [((2, 6, 5, 8), (2, 2), 1), ((1, 4, 4, 16), (4, 4), 1), ((2, 1, 16, 8), (1, 2), 0),
+                                         ((2, 3, 3, 8), (2, 2), 0)])
+def test_upsample_fwd_bwd(shape, f, bil):
+    N, H, W, Cc = shape
+    x = h16(torch.randn(shape)).requires_grad_(True)
+    y = K.upsample(x, f, "bilinear" if bil else "nearest")
+    dy = h16(torch.randn_like(y))
+    (y * dy).sum().backward()
+    xd = to_dev_nhwc(x.detach())
+    yd = torch.zeros((N, H * f[0], W * f[1], Cc), dtype=torch.float16, device="cuda")
+    ffi.call("seg_upsample_fwd", P(xd), P(yd), N, H, W, Cc, *f, bil, stream())
+    dxd = torch.zeros_like(xd)
+    dyd = to_dev_nhwc(dy)
+    ffi.call("seg_upsample_bwd", P(dyd), P(dxd), N, H, W, Cc, *f, bil, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(yd, Cc), y.detach()) < 1e-3
+    assert rel(from_dev(dxd, Cc), x.grad) < 2e-3
+
+
+def test_upsample_bilinear_known_answer():
+    """2x bilinear of [0, 4] (half-pixel centres, edge clamp) = [0, 1, 3, 4]."""
+    x = torch.zeros(1, 1, 2, 8)
+    x[0, 0, 1, :] = 4.0
+    yd = torch.zeros((1, 1, 4, 8), dtype=torch.float16, device="cuda")
+    xd = to_dev_nhwc(x)
+    ffi.call("seg_upsample_fwd", P(xd), P(yd), 1, 1, 2, 8, 1, 2, 1, stream())
+    torch.cuda.synchronize()
+    assert yd[0, 0, :, 0].float().cpu().tolist() == [0.0, 1.0, 3.0, 4.0]
+
+
+@pytest.mark.parametrize("n,act", [(2, "relu"), (3, None), (1, "sigmoid"), (4, "relu")])
+def test_add_act_fwd_bwd(n, act):
+    shape = (2, 5, 6, 16)
+    xs = [h16(torch.randn(shape)).requires_grad_(True) for _ in range(n)]
+    y = K.activation(sum(xs[1:], xs[0]), act)
+    dy = h16(torch.randn(shape))
+    (y * dy).sum().backward()
+    xds = [to_dev_nhwc(x.detach()) for x in xs]
+    yd = torch.zeros_like(xds[0])
+    ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in xds])
+    ffi.call("seg_add_act_fwd", ptrs, n, P(yd), yd.numel(), ACT[act], 0.0, stream())
+    accs = [h16(torch.randn(shape)) for _ in range(n)]
+    dxs = [to_dev_nhwc(a) for a in accs]
+    mask = 0b0101 & ((1 << n) - 1)
+    gp = (C.c_void_p * 4)(*[t.data_ptr() for t in dxs])
+    dyd = to_dev_nhwc(dy)
+    ffi.call("seg_add_act_bwd", P(dyd), P(yd), gp, n, yd.numel(), ACT[act], 0.0, mask, stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(yd, 16), y.detach()) < 1e-3
+    for k in range(n):
+        ref = xs[k].grad + (accs[k] if mask & (1 << k) else 0)
+        assert rel(from_dev(dxs[k], 16), ref) < 2e-3
+
+
+def test_mul_bcast_fwd_bwd():
+    N, H, W, Cc = 2, 6, 5, 40
+    a = h16(torch.randn(N, H, W, Cc)).requires_grad_(True)
+    r = h16(torch.rand(N, H, W, 1)).requires_grad_(True)
+    y = a * r
+    dy = h16(torch.randn_like(y))
+    (y * dy).sum().backward()
+    ad, rd = to_dev_nhwc(a.detach()), to_dev_nhwc(r.detach())
+    yd = torch.zeros_like(ad)
+    ffi.call("seg_mul_bcast_fwd", P(ad), P(rd), P(yd), N * H * W, Cc, 8, stream())
+    da, dr = torch.zeros_like(ad), torch.zeros_like(rd)
+    dyd = to_dev_nhwc(dy)
+    ffi.call("seg_mul_bcast_bwd", P(dyd), P(ad), P(rd), P(da), P(dr), N * H * W, Cc, 8, 0, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(yd, Cc), y.detach()) < 1e-3
+    assert rel(from_dev(da, Cc), a.grad) < 1e-3
+    assert rel(from_dev(dr, 1), r.grad) < 2e-3
+
+
+def test_convlstm_gates_fwd_bwd():
+    N, H, W, Fh = 2, 5, 6, 16
+    z = h16(torch.randn(N, H, W, 4 * Fh) * 2.0).requires_grad_(True)
+    zi, zf, zc, zo = torch.chunk(z, 4, -1)
+    h = K.hard_sigmoid(zo) * torch.tanh(K.hard_sigmoid(zi) * torch.tanh(zc))
+    dh = h16(torch.randn_like(h))
+    (h * dh).sum().backward()
+    zd = to_dev_nhwc(z.detach())
+    hd = torch.zeros((N, H, W, Fh), dtype=torch.float16, device="cuda")
+    ffi.call("seg_convlstm_gate_fwd", P(zd), 4 * Fh, P(hd), Fh, N * H * W, Fh, stream())
+    dz = torch.full_like(zd, 9.0)
+    dhd = to_dev_nhwc(dh)
+    ffi.call("seg_convlstm_gate_bwd", P(dhd), Fh, P(zd), 4 * Fh, P(dz), N * H * W, Fh, stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(hd, Fh), h.detach()) < 1e-3
+    assert rel(from_dev(dz, 4 * Fh), z.grad) < 2e-3
+    assert float(dz[..., Fh:2 * Fh].abs().max()) == 0.0          # the forget gate is dead (zero gradient)
+
+
+# ------------------------------------------------------------------------------------------------ heads / loss / optimiser
+@pytest.mark.parametrize("Cin,Cout,act,stride", [(64, 1, "sigmoid", 1), (64, 4, "softmax", 1), (16, 2, "softmax", 1), (256, 1, None, 1),
+                                                 (40, 3, None, 1), (32, 1, None, 2)])
+def test_head_fwd_bwd(Cin, Cout, act, stride):
+    N, H, W = 2, 8, 10
+    x = h16(torch.randn(N, H, W, Cin)).requires_grad_(True)
+    kern = (torch.randn(1, 1, Cin, Cout) * 0.2).requires_grad_(True)
+    b = torch.randn(Cout).requires_grad_(True)
+    y = K.activation(K.conv2d_same(x, kern, b, (stride, stride)), act)
+    dy = torch.randn_like(y)
+    (y * dy).sum().backward()
+    cs = U.r8(Cin)
+    xd = to_dev_nhwc(x.detach())
+    wE = torch.zeros(Cout, cs)
+    wE[:, :Cin] = kern.detach().reshape(Cin, Cout).T
+    wd, bd = wE.cuda().contiguous(), b.detach().cuda()
+    yd = torch.zeros(y.shape, device="cuda")
+    ffi.call("seg_head_fwd", P(xd), cs, Cin, N, H, W, stride, stride, P(wd), cs, P(bd), Cout, ACT[act], P(yd), stream())
+    gsv = torch.tensor([16.0, 1 / 16.0], device="cuda")
+    dx = torch.zeros_like(xd)
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    dyd = dy.cuda().contiguous()
+    ffi.call("seg_head_bwd", P(dyd), P(yd), P(xd), cs, Cin, N, H, W, stride, stride, P(wd), cs, Cout, ACT[act], P(dx), 0,
+             P(gsv), P(dw), P(db), stream())
+    torch.cuda.synchronize()
+    assert float((yd.cpu() - y.detach()).abs().max()) < 2e-5
+    assert rel(from_dev(dx, Cin) / 16.0, x.grad) < 1e-3
+    assert rel(dw[:, :Cin].cpu(), kern.grad.reshape(Cin, Cout).T) < 1e-4
+    assert rel(db.cpu(), b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("kind,Cc", [("mse", 1), ("mse", 3), ("bce", 1), ("cce", 4), ("cce", 2)])
+def test_losses_match_keras_definitions(kind, Cc):
+    npix = 5000
+    if kind == "cce":
+        p = torch.softmax(torch.randn(npix, Cc) * 3, -1)
+        t = F.one_hot(torch.randint(0, Cc, (npix,)), Cc).float()
+    else:
+        p = torch.sigmoid(torch.randn(npix, Cc) * 3)
+        t = (torch.rand(npix, Cc) > 0.5).float() if kind == "bce" else torch.rand(npix, Cc)
+    pr = p.clone().requires_grad_(True)
+    L = TR.LOSSES[kind](pr, t)
+    L.backward()
+    lo = torch.zeros(1, device="cuda")
+    dp = torch.zeros(npix, Cc, device="cuda")
+    pd, td = p.cuda(), t.cuda()                      # keep the device tensors alive across the launch
+    ffi.call("seg_loss_fwd_bwd", ffi.LOSS[kind], P(pd), P(td), npix, Cc, P(lo), P(dp), stream())
+    torch.cuda.synchronize()
+    assert abs(float(lo.cpu()) - float(L.detach())) < 2e-5 * max(1.0, abs(float(L.detach())))
+    assert rel(dp.cpu(), pr.grad) < 1e-4
+
+
+def test_grad_scale_is_power_of_two_in_range():
+    for amax in [3.7e-7, 0.0123, 1.0, 777.0, 5e4]:
+        x = torch.zeros(1000, device="cuda")
+        x[17] = -amax
+        am, gs = torch.zeros(1, device="cuda"), torch.zeros(2, device="cuda")
+        ffi.call("seg_absmax", P(x), 1000, P(am), stream())
+        ffi.call("seg_grad_scale", P(am), 1024.0, P(gs), stream())
+        torch.cuda.synchronize()
+        s = float(gs[0].cpu())
+        assert abs(float(am.cpu()) - amax) <= 1e-6 * amax
+        assert 512.0 <= amax * s < 1024.0 and np.log2(s) == round(np.log2(s)) and abs(float(gs[1].cpu()) * s - 1.0) < 1e-6
+
+
+def test_adam_matches_keras_adam_three_steps():
+    n = 10000
+    p0 = torch.randn(n)
+    params = {"w": p0.clone()}
+    opt = TR.KerasAdam(params, lr=2e-4)
+    p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.zeros(n, dtype=torch.float16, device="cuda")
+    import math
+    for t in range(1, 4):
+        g = torch.randn(n) * (10.0 ** torch.randint(-6, 1, (n,)).float())
+        opt.step({"w": g})
+        a_t = 2e-4 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        gd = (g * 4).cuda()
+        ffi.call("seg_adam_step", P(p), P(gd), P(m), P(v), P(p16), n, a_t, 0.9, 0.999, 1e-7, 0.25, stream())
+        torch.cuda.synchronize()
+    assert float((p.cpu() - params["w"]).abs().max()) < 1e-6
+    assert torch.equal(p16.cpu(), p.cpu().half())
+
+
+def test_pack_unpack_input():
+    x = torch.rand(3, 5, 7, 3)
+    y = torch.zeros((3, 5, 7, 8), dtype=torch.float16, device="cuda")
+    xd = x.cuda()
+    ffi.call("seg_pack_input", P(xd), P(y), 3 * 5 * 7, 3, 8, stream())
+    back = torch.zeros(3, 5, 7, 3, device="cuda")
+    ffi.call("seg_unpack_f32", P(y), P(back), 3 * 5 * 7, 3, 8, 0, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y[..., :3].cpu(), x.half()) and float(y[..., 3:].abs().max()) == 0.0
+    assert torch.equal(back.cpu(), x.half().float())
+
+
+def test_bad_arguments_fail_loudly():
+    a = ffi.IgemmFwdArgs()
+    with pytest.raises(ffi.SegHipError):
+        ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    with pytest.raises(ffi.SegHipError, match="seg_head_fwd"):
+        ffi.call("seg_head_fwd", None, 8, 8, 1, 1, 1, 1, 1, None, 8, None, 9, 0, None, stream())

@@ -1,0 +1,119 @@
+"""CPU: host logic of the engine in dry-run mode (buffers on the CPU, kernel calls only recorded - nothing is
+computed): lowering / fusion decisions, the static backward schedule, parameter layout round trips, geometry."""
+import importlib
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+
+import segamd
+
+M = importlib.import_module("tf-1d-2d-segmentation-end2endpipelines_amd.model")
+
+
+@pytest.fixture(autouse=True)
+def dry():
+    M._DryRun.on = True
+    M._DryRun.log.clear()
+    yield
+    M._DryRun.on = False
+
+
+def B(*a, **k):
+    return segamd.unet_model_builder(*a, train_mode="from_scratch", **k).ResNet50()
+
+
+def step(m, x):
+    M._DryRun.log.clear()
+    m.train_step(x, [torch.rand(*h.y.shape) for h in m.out_heads])
+    return Counter(M._DryRun.log)
+
+
+def test_unetpp_fusion_counts():
+    d = 3
+    m = B("UNetPP", 32, 32, 16, d, ds=1).build(2)
+    c = step(m, torch.rand(2, 32, 32, 3))
+    nodes = d * (d + 1) // 2
+    convs = (d + 1) + 2 + nodes                      # encoder + latent(2) + nested nodes, every one conv+BN+ReLU fused
+    assert c["seg_bn_act_apply"] == convs and c["seg_bn_finalize"] == convs
+    assert c["seg_head_fwd"] == d + 1 and c["seg_head_bwd"] == d + 1
+    assert c["seg_igemm_wgrad"] == convs + nodes     # + one transposed conv per node
+    assert c["seg_maxpool_bwd"] == d                 # pooling fused into bn_act_apply forward; only the backward is a launch
+    assert c["seg_maxpool_fwd"] == 0
+    assert c["seg_adam_step"] == 1                   # ONE flat optimiser launch
+    # no concat is ever materialised: every tensor in the registry is a real layer output
+    assert not any(n.endswith("/cat") for n in m.tensors)
+    # data-gradient launches: one per concat segment that needs a gradient
+    segs = sum(len(op.segs) for op in m.ops if isinstance(op, M.ConvOp)) - 1      # the image needs none
+    assert c["seg_igemm_fwd"] == (convs + nodes) + segs
+
+
+def test_accumulate_flags_follow_consumer_count():
+    m = B("UNetPP", 32, 32, 16, 2, ds=0).build(2)
+    step(m, torch.rand(2, 32, 32, 3))
+    acc = {}
+    for op in m.ops:
+        if isinstance(op, M.ConvOp) and getattr(op, "live", False):
+            for a, t, flag, _fl in op.dg_args:
+                acc.setdefault(t.name, []).append(flag)
+    # X01's output feeds X02 (dense skip) and nothing else in depth 2 with ds=0 -> written once
+    assert acc["X01/relu"] == [0]
+    # enc1 output: consumers X01 (skip), X02 (skip) + its pooled copy -> first writer plain, later ones accumulate
+    assert sorted(acc["enc1/relu"]) == [0, 1] or sorted(acc["enc1/relu"]) == [1, 1]
+    assert all(sorted(v)[1:] == [1] * (len(v) - 1) for v in acc.values())
+
+
+@pytest.mark.parametrize("mk", [lambda: B("UNet", 32, 32, 16, 2, num_channels=1, lstm=1, dense_loop=2),
+                                lambda: B("UNetPP", 32, 32, 16, 3, ds=1, ag=1),
+                                lambda: B("UNet3P", 32, 32, 8, 2, ds=1),
+                                lambda: segamd.UNet1D(64, 2, 1, 16, 3, ds=1, ag=1).UNet(),
+                                lambda: segamd.BCDUNet(64, 2, 1, 16, 3, lstm=1, dense_loop=2).BCDUNet()])
+def test_weight_layout_roundtrip(mk):
+    m = mk().build(2)
+    w = m.get_weights()
+    specs = {p.name: p.shape for p in m.graph.param_specs()}
+    assert {k: v.shape for k, v in w.items()} == specs
+    rng = np.random.default_rng(0)
+    w2 = {k: rng.standard_normal(v.shape).astype(np.float32) for k, v in w.items()}
+    m.set_weights(w2)
+    w3 = m.get_weights()
+    assert all(np.array_equal(w2[k], w3[k]) for k in w2)
+    assert m.count_params() == sum(int(np.prod(s)) for s in specs.values())
+
+
+def test_geometry_tables():
+    g = M.geom_conv(2, 16, 16, 3, 3, 1, 1)
+    assert (g.ncls, g.ntaps, g.T_total) == (1, 9, 9)
+    assert [(g.tap_dy[i], g.tap_dx[i]) for i in range(9)] == [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    t = M.geom_convT(2, 8, 8, 4, 4, 2, 2)              # Y = 2i + ky - 1  
+    assert (t.ncls, t.ntaps, t.Hout, t.osy) == (4, 4, 16, 2)
+    for c in range(4):
+        py = t.oy[c]
+        for k in range(4):
+            e = c * 4 + k
+            ky = t.tap_w[e] // 4
+            assert 2 * t.tap_dy[e] + ky - 1 == py          # i_in = i + dy  <=>  2 i + py = 2 (i + dy) + ky - 1
+    d = M.geom_convT_dgrad(2, 8, 8, 4, 4, 2, 2)
+    assert (d.Hin, d.isy, d.ntaps) == (16, 2, 16) and sorted(set(d.tap_dy[i] for i in range(16))) == [-1, 0, 1, 2]
+    t1 = M.geom_convT(2, 1, 32, 1, 2, 1, 2)            # Conv1DTranspose k2 s2: y = 2i + k
+    assert (t1.ncls, t1.ntaps) == (2, 1) and [t1.tap_dx[i] for i in range(2)] == [0, 0]
+    s2 = M.geom_conv(2, 16, 16, 1, 1, 2, 2)            # 1x1 stride 2 'same': no padding, samples 0,2,4,...
+    assert (s2.Hl, s2.isy, s2.tap_dy[0]) == (8, 2, 0)
+
+
+def test_pack_gemm_weight_places_segments():
+    kern = np.arange(3 * 3 * 5 * 4, dtype=np.float32).reshape(3, 3, 5, 4)
+    E = M.pack_gemm_weight(kern, [2, 3], [0, 32], 8, 64, False)
+    assert E.shape == (8, 9, 64)
+    assert E[1, 4, 0] == kern[1, 1, 0, 1] and E[1, 4, 33] == kern[1, 1, 3, 1]
+    assert E[4:].sum() == 0 and E[:, :, 2:32].sum() == 0 and E[:, :, 35:].sum() == 0
+    back = M.unpack_gemm_weight(E.reshape(-1), kern.shape, [2, 3], [0, 32], 8, 64, False)
+    assert np.array_equal(back, kern)
+
+
+def test_unsupported_layers_say_so():
+    with pytest.raises(NotImplementedError):
+        B("UNet", 32, 32, 8, 2, ae=1, feature_number=16).build(2)
+    with pytest.raises(NotImplementedError, match="ConvLSTM filters"):
+        B("UNet", 32, 32, 8, 2, lstm=1).build(2)

@@ -122,16 +122,35 @@ __global__ __launch_bounds__(TPB) void bn_prereduce_kernel(float* stats, int npa
   }
 }
 
+// Sum `nparts` partial rows for 16 channels per block with 16 part-lanes per channel (deterministic order),
+// result for channel (blockIdx.x*16 + c) lands in lane pl == 0.
+__device__ __forceinline__ void reduce_parts16(const float* stats, int nparts, int C, int c, int pl, float& s, float& q,
+                                               float (*sm)[16][16]) {
+  s = 0.f;
+  q = 0.f;
+  if (c < C)
+    for (int p = pl; p < nparts; p += 16) {
+      s += stats[((size_t)p * 2 + 0) * C + c];
+      q += stats[((size_t)p * 2 + 1) * C + c];
+    }
+  sm[0][pl][threadIdx.x & 15] = s;
+  sm[1][pl][threadIdx.x & 15] = q;
+  __syncthreads();
+  if (pl == 0)
+    for (int k = 1; k < 16; ++k) { s += sm[0][k][threadIdx.x & 15]; q += sm[1][k][threadIdx.x & 15]; }
+}
+
 __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* stats, int nparts, int C, float inv_count, float unbias,
                                                           const float* gamma, const float* beta, float eps, float momentum,
                                                           float* mmean, float* mvar, int training, float* mean_o, float* invstd_o,
                                                           float* scale_o, float* shift_o) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sm[2][16][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  float s = 0.f, q = 0.f;
+  if (training) reduce_parts16(stats, nparts, C, c, pl, s, q, sm);
+  if (pl != 0 || c >= C) return;
   float mean, var;
   if (training) {
-    float s = 0.f, q = 0.f;
-    for (int p = 0; p < nparts; ++p) { s += stats[((size_t)p * 2 + 0) * C + c]; q += stats[((size_t)p * 2 + 1) * C + c]; }
     mean = s * inv_count;
     var = fmaxf(q * inv_count - mean * mean, 0.f);
     mmean[c] = mmean[c] * momentum + mean * (1.f - momentum);
@@ -262,10 +281,11 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const half_t* dy
 __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* partial, int nparts, int C, float inv_count, float* dgamma,
                                                               float* dbeta, float gscale, const float* gscale_ptr, float* c1,
                                                               float* c2) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f, q = 0.f;
-  for (int p = 0; p < nparts; ++p) { s += partial[((size_t)p * 2 + 0) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
+  __shared__ float sm[2][16][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  float s, q;
+  reduce_parts16(partial, nparts, C, c, pl, s, q, sm);
+  if (pl != 0 || c >= C) return;
   float gs = gscale;
   if (gscale_ptr) gs *= *gscale_ptr;
   if (dbeta) dbeta[c] += s * gs;
@@ -618,7 +638,8 @@ __global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const half_t* dy, co
 
 // ------------------------------------------------------------------------------------------------ ConvLSTM (T = 1) gates
 __device__ __forceinline__ float hsig(float v) { return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); }
-__device__ __forceinline__ float hsig_grad(float v) { return (v > -2.5f && v < 2.5f) ? 0.2f : 0.f; }
+// TF clip_by_value (minimum/maximum) passes the gradient AT the knees, so the interval is closed
+__device__ __forceinline__ float hsig_grad(float v) { return (v >= -2.5f && v <= 2.5f) ? 0.2f : 0.f; }
 
 __global__ __launch_bounds__(TPB) void convlstm_gate_fwd_kernel(const half_t* z, int z_cs, half_t* h, int h_cs, int64_t npix, int F) {
   const int CH = F / 8;
@@ -1016,7 +1037,7 @@ extern "C" int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, in
     np = S;
   }
   const float unbias = (unbiased_moving && count > 1) ? (float)((double)count / (double)(count - 1)) : 1.f;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, ST(stream), stats, np, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(TPB), 0, ST(stream), stats, np, C,
                      training ? (float)(1.0 / (double)count) : 0.f, unbias, gamma, beta, eps, momentum, moving_mean, moving_var, training,
                      mean, invstd, scale, shift);
   SEG_CHECK_LAUNCH("seg_bn_finalize");
@@ -1058,7 +1079,7 @@ extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_c
 extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma, float* dbeta,
                                    float gscale, const float* gscale_ptr, float* c1, float* c2, seg_stream_t stream) {
   SEG_CHECK_ARG(partial && c1 && c2 && nparts > 0 && C > 0 && count > 0, "seg_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, ST(stream), partial, nparts, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(TPB), 0, ST(stream), partial, nparts, C,
                      (float)(1.0 / (double)count), dgamma, dbeta, gscale, gscale_ptr, c1, c2);
   SEG_CHECK_LAUNCH("seg_bn_bwd_finalize");
   return SEG_OK;

@@ -18,6 +18,7 @@ import gpu_util as U
 torch.manual_seed(0)
 rng = np.random.default_rng(0)
 FAILS = []
+VERBOSE = bool(int(os.environ.get('DIAG_VERBOSE', '0')))
 
 
 def report(name, err, tol):
@@ -109,13 +110,24 @@ def sec_wgrad():
 def model_case(tag, model, x, targets, loss, fwd_tol=2e-3, grad_tol=3e-2):
     t0 = time.time()
     model.build(x.shape[0])
-    res = U.compare_model(model, x, targets, loss, verbose=True)
+    res32 = U.compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False)
+    report(f"model {tag} vs FP32 oracle: forward outs", max(res32["outs"]), 5e-3)
+    print("   fp32-oracle outs err", ["%.3e" % e for e in res32["outs"]], " worst pgrad rel", "%.3e" % U.grad_rel_err(res32))
+    res = U.compare_model(model, x, targets, loss, verbose=VERBOSE, emulate_fp16=True)
+    fwd_tol = 1e-3
     worst_node = max((e for _n, e, _m in res["nodes"]), default=0.0)
     report(f"model {tag} forward outs", max(res["outs"]), fwd_tol)
     report(f"model {tag} worst node (abs)", worst_node, 5e-2)
     report(f"model {tag} loss", abs(res["loss"][0] - res["loss"][1]) / max(1e-6, abs(res["loss"][1])), 2e-3)
-    gw = max((e / (d + 1e-12) for e, d in res["grads"].values() if d > 1e-10), default=0.0)
-    report(f"model {tag} worst param-grad rel err", gw, grad_tol)
+    report(f"model {tag} worst param-grad rel err", U.grad_rel_err(res), grad_tol)
+    wa = max((e / (m + 1e-30) for _n, e, m in res["agrads"]), default=0.0)
+    report(f"model {tag} worst activation-grad rel err", wa, 5e-2)
+    if not VERBOSE:
+        worst = sorted(res["grads"].items(), key=lambda kv: -(kv[1][0] / (kv[1][1] + 1e-4 * res["gmax"])))[:4]
+        for k, (e, d) in worst:
+            print(f"   pgrad {k:40s} abs err {e:.3e} / max {d:.3e}")
+        for n_, e, m_ in sorted(res["agrads"], key=lambda t: -t[1] / (t[2] + 1e-30))[:4]:
+            print(f"   agrad {n_:36s} max|err| {e:.3e}  (ref max {m_:.3e})")
     print(f"   ({time.time() - t0:.1f}s)")
 
 
