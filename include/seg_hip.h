@@ -211,6 +211,62 @@ int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs,
 /* fp16 [npix][cs] columns [coff, coff+C) -> fp32 [npix][C]                                                     */
 int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
 
+/* ---- exact-fp32 parity mode -----------------------------------------------------------------------------------
+ * Every entry point above that reads or writes activation tensors also exists with the suffix _f32: identical
+ * arguments, but activations, the GEMM weight operand `w` (and seg_transpose_w's output) are fp32, and the
+ * contraction runs on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain, 1/16 of the fp16 MFMA rate).  It is
+ * the mode the 1e-3 / bit-exact-mask parity of the north star is asserted in (tests/test_gpu_fp32.py); the fp16
+ * functions are the throughput mode.  seg_igemm_wgrad_f32 always uses the transposing-store form (variant 1). */
+int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t stream);
+int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream);
+int seg_bn_stats_f32(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts,
+                     int32_t stats_ld, int32_t stats_coff, seg_stream_t stream);
+int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff,
+                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
+                         const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
+                         seg_stream_t stream);
+int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                              int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, int32_t act, float alpha, float* partial,
+                              int32_t nparts, seg_stream_t stream);
+int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                             int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate,
+                             seg_stream_t stream);
+int seg_act_bwd_f32(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act,
+                    float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream);
+int seg_maxpool_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw,
+                        seg_stream_t stream);
+int seg_maxpool_bwd_f32(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W,
+                        int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream);
+int seg_upsample_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
+                         int32_t bilinear, seg_stream_t stream);
+int seg_upsample_bwd_f32(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh,
+                         int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream);
+int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha,
+                        seg_stream_t stream);
+int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
+                        float alpha, int32_t accumulate_mask, seg_stream_t stream);
+int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs,
+                          seg_stream_t stream);
+int seg_mul_bcast_bwd_f32(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs,
+                          int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream);
+int seg_convlstm_gate_fwd_f32(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F,
+                              seg_stream_t stream);
+int seg_convlstm_gate_bwd_f32(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix,
+                              int32_t F, seg_stream_t stream);
+int seg_head_fwd_f32(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx,
+                     const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y,
+                     seg_stream_t stream);
+int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H,
+                     int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act,
+                     void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream);
+int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
+                        seg_stream_t stream);
+int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
+int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

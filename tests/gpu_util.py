@@ -32,11 +32,11 @@ def r32(v):
     return (v + 31) // 32 * 32
 
 
-def to_dev_nhwc(x: torch.Tensor) -> torch.Tensor:
-    """fp32 NHWC CPU -> fp16 NHWC cuda with the channel stride padded to 8."""
+def to_dev_nhwc(x: torch.Tensor, dt=torch.float16) -> torch.Tensor:
+    """fp32 NHWC CPU -> fp16 (or fp32) NHWC cuda with the channel stride padded to 8."""
     N, H, W, Cc = x.shape
-    t = torch.zeros((N, H, W, r8(Cc)), dtype=torch.float16, device="cuda")
-    t[..., :Cc] = x.to("cuda", torch.float16)
+    t = torch.zeros((N, H, W, r8(Cc)), dtype=dt, device="cuda")
+    t[..., :Cc] = x.to("cuda", dt)
     return t
 
 
@@ -46,14 +46,15 @@ def h16(x: torch.Tensor) -> torch.Tensor:
 
 
 def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0, want_stats=False, tile=None,
-               accumulate_into=None):
+               accumulate_into=None, f32=False):
     """xs: list of fp32 NHWC CPU tensors (virtual concat); kern: Keras layout numpy.  Returns (out fp32 NHWC CPU, stats)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kern.shape[:2]
     transposed = kind == "convT"
     cout = kern.shape[2] if transposed else kern.shape[3]
     n_rows = r8(cout)
-    devs = [to_dev_nhwc(x) for x in xs]
+    dt = torch.float32 if f32 else torch.float16
+    devs = [to_dev_nhwc(x, dt) for x in xs]
     cin_l = [x.shape[3] for x in xs]
     woff, k = [], 0
     for d in devs:
@@ -61,7 +62,7 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         k += r32(d.shape[3])
     Kpad = k
     E = M.pack_gemm_weight(kern, cin_l, woff, n_rows, Kpad, transposed)
-    w16 = torch.from_numpy(E).to("cuda", torch.float16).contiguous()
+    w16 = torch.from_numpy(E).to("cuda", dt).contiguous()
     g = M.geom_convT(N, H, W, kh, kw, *strides) if transposed else M.geom_conv(N, H, W, kh, kw, *strides)
     Ho, Wo = g.Hout, g.Wout
     a = ffi.IgemmFwdArgs()
@@ -71,10 +72,10 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s] = d.shape[3], d.shape[3], woff[s], d.data_ptr()
     a.w, a.Kpad, a.n_rows, a.n_valid = w16.data_ptr(), Kpad, n_rows, cout
     if accumulate_into is not None:
-        out = to_dev_nhwc(accumulate_into)
+        out = to_dev_nhwc(accumulate_into, dt)
         a.accumulate = 1
     else:
-        out = torch.full((N, Ho, Wo, n_rows), 7.0, dtype=torch.float16, device="cuda")
+        out = torch.full((N, Ho, Wo, n_rows), 7.0, dtype=dt, device="cuda")
     a.out, a.out_cs, a.out_coff = out.data_ptr(), n_rows, 0
     bdev = None
     if bias is not None:
@@ -90,21 +91,22 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         nparts = g.ncls * (-(-Mtot // tm))
         stats = torch.zeros((nparts, 2, n_rows), dtype=torch.float32, device="cuda")
         a.stats = stats.data_ptr()
-    ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    ffi.call("seg_igemm_fwd_f32" if f32 else "seg_igemm_fwd", C.byref(a), stream())
     torch.cuda.synchronize()
     res = out[..., :cout].float().cpu()
     pad = out[..., cout:].float().abs().max().item() if n_rows > cout else 0.0
     return res, (stats.sum(0).cpu() if stats is not None else None), pad
 
 
-def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None):
+def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None, f32=False):
     """Returns dW in Keras layout (numpy)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kshape[:2]
     transposed = kind == "convT"
     cout = kshape[2] if transposed else kshape[3]
     n_rows = r8(cout)
-    devs = [to_dev_nhwc(x) for x in xs]
+    dt = torch.float32 if f32 else torch.float16
+    devs = [to_dev_nhwc(x, dt) for x in xs]
     cin_l = [x.shape[3] for x in xs]
     woff, k = [], 0
     for d in devs:
@@ -113,7 +115,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
     Kpad = k
     T = kh * kw
     g = M.geom_convT(N, H, W, kh, kw, *strides) if transposed else M.geom_conv(N, H, W, kh, kw, *strides)
-    dzd = to_dev_nhwc(dz)
+    dzd = to_dev_nhwc(dz, dt)
     dw = torch.zeros(n_rows * T * Kpad, dtype=torch.float32, device="cuda")
     a = ffi.IgemmWgradArgs()
     a.g = g
@@ -128,7 +130,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
         tm, tn = tile
     a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)
     a.scale, a.scale_ptr, a.variant = 1.0, None, variant
-    ffi.call("seg_igemm_wgrad", C.byref(a), stream())
+    ffi.call("seg_igemm_wgrad_f32" if f32 else "seg_igemm_wgrad", C.byref(a), stream())
     torch.cuda.synchronize()
     return M.unpack_gemm_weight(dw.cpu().numpy(), kshape, cin_l, woff, n_rows, Kpad, transposed)
 
@@ -177,6 +179,7 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False):
         res["nodes"].append((name, float((got - ref).abs().max()), float(ref.abs().max())))
     for o, r in zip(outs, outs_ref):
         res["outs"].append(float((o.cpu() - r.detach()).abs().max()))
+        res.setdefault("out_mag", []).append(float(r.detach().abs().max()))
     # activation gradients: a ConvOp leaves dL/d(conv output) in its out.grad (in place); other tensors keep dL/d(tensor)
     seen = set()
     for op in model.ops:
@@ -206,6 +209,7 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False):
         a, b = grads[k].reshape(-1).astype(np.float64), gr.reshape(-1).astype(np.float64)
         na, nb = np.linalg.norm(a), np.linalg.norm(b)
         res["gcos"][k] = (float(a @ b / (na * nb + 1e-300)), float(na / (nb + 1e-300)), float(np.abs(gr).max()))
+        res.setdefault("gl2", {})[k] = (float(np.linalg.norm(a - b)), float(nb))
     if verbose:
         for n, e, mag in res["nodes"]:
             print(f"   node {n:34s} max|err| {e:.3e}  (ref max {mag:.3e})")

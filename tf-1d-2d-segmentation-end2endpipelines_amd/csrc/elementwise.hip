@@ -71,7 +71,8 @@ __device__ __forceinline__ void block_col_reduce(float (&v)[NV][8], float* sm, i
 }
 
 // ------------------------------------------------------------------------------------------------ BN statistics
-__global__ __launch_bounds__(TPB) void bn_stats_kernel(const half_t* x, int64_t npix, int cs, int coff, int C, float* stats,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const T* x, int64_t npix, int cs, int coff, int C, float* stats,
                                                        int nparts, int stats_ld, int stats_coff, ColLayout L) {
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const half_t* x, int64_t 
     if (ch < L.CH) {
       for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
         float f[8];
-        unpack8(ld16(x + pix * cs + coff + ch * 8), f);
+        load8(x + pix * cs + coff + ch * 8, f);
 #pragma unroll
         for (int t = 0; t < 8; ++t) { acc[0][t] += f[t]; acc[1][t] += f[t] * f[t]; }
       }
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* stats, in
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply (+pool)
-__global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const half_t* x, int x_cs, int x_coff, half_t* y, int y_cs, int y_coff,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs, int x_coff, T* y, int y_cs, int y_coff,
                                                            int64_t npix, int C, int c_valid, const float* scale, const float* shift,
                                                            int act, float alpha) {
   const int CH = C / 8;
@@ -177,21 +179,22 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const half_t* x, int 
     const int64_t pix = it / CH;
     const int ch = (int)(it - pix * CH);
     float f[8];
-    unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), f);
+    load8(x + pix * x_cs + x_coff + ch * 8, f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int c = ch * 8 + t;
       float v = seg_act(f[t] * scale[c] + shift[c], act, alpha);
       f[t] = c < c_valid ? v : 0.f;
     }
-    st16(y + pix * y_cs + y_coff + ch * 8, pack8(f));
+    store8(y + pix * y_cs + y_coff + ch * 8, f);
   }
 }
 
-__global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const half_t* x, int x_cs, int x_coff, half_t* y, int y_cs,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const T* x, int x_cs, int x_coff, T* y, int y_cs,
                                                                 int y_coff, int N, int H, int W, int C, int c_valid,
                                                                 const float* scale, const float* shift, int act, float alpha,
-                                                                half_t* pooled, int ph, int pw) {
+                                                                T* pooled, int ph, int pw) {
   const int CH = C / 8;
   const int HP = H / ph, WP = W / pw;                  // pooled extent ('valid')
   const int HB = (H + ph - 1) / ph, WB = (W + pw - 1) / pw;   // windows incl. ragged border (no pooled output there)
@@ -211,29 +214,27 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const half_t* x,
         if (yy >= H || xx >= W) continue;
         const int64_t pix = ((int64_t)n * H + yy) * W + xx;
         float f[8];
-        unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), f);
+        load8(x + pix * x_cs + x_coff + ch * 8, f);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           float v = seg_act(f[t] * sc[t] + sh[t], act, alpha);
           v = (ch * 8 + t) < c_valid ? v : 0.f;
           f[t] = v;
         }
-        const u4 pk = pack8(f);
-        st16(y + pix * y_cs + y_coff + ch * 8, pk);
-        float fr[8];
-        unpack8(pk, fr);   // pool the ROUNDED values so that pooled == max of the stored fp16 tensor
+        store8(y + pix * y_cs + y_coff + ch * 8, f);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) mx[t] = fmaxf(mx[t], fr[t]);
+        for (int t = 0; t < 8; ++t) mx[t] = fmaxf(mx[t], stored<T>(f[t]));   // pool the values as stored (pooled == max of y)
       }
     if (hb < HP && wb < WP) {
       const int64_t pp = ((int64_t)n * HP + hb) * WP + wb;
-      st16(pooled + pp * y_cs + ch * 8, pack8(mx));
+      store8(pooled + pp * y_cs + ch * 8, mx);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
-__global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const half_t* dy, int dy_cs, int dy_coff, const half_t* x, int x_cs,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int dy_cs, int dy_coff, const T* x, int x_cs,
                                                                 int x_coff, int64_t npix, int C, const float* scale,
                                                                 const float* shift, const float* mean, const float* invstd, int act,
                                                                 float alpha, float* partial, int nparts, ColLayout L) {
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const half_t* dy
       }
       for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
         float g[8], xv[8];
-        unpack8(ld16(dy + pix * dy_cs + dy_coff + ch * 8), g);
-        unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), xv);
+        load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
+        load8(x + pix * x_cs + x_coff + ch * 8, xv);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const float yv = seg_act(xv[t] * sc[t] + sh[t], act, alpha);
@@ -294,8 +295,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* parti
   c2[c] = q * inv_count;
 }
 
-__global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const half_t* dy, int dy_cs, int dy_coff, const half_t* x, int x_cs,
-                                                               int x_coff, half_t* dx, int dx_cs, int dx_coff, int64_t npix, int C,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int dy_cs, int dy_coff, const T* x, int x_cs,
+                                                               int x_coff, T* dx, int dx_cs, int dx_coff, int64_t npix, int C,
                                                                const float* scale, const float* shift, const float* mean,
                                                                const float* invstd, const float* c1, const float* c2, int act,
                                                                float alpha, int accumulate) {
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const half_t* dy,
     const int64_t pix = it / CH;
     const int ch = (int)(it - pix * CH);
     float g[8], xv[8], o[8];
-    unpack8(ld16(dy + pix * dy_cs + dy_coff + ch * 8), g);
-    unpack8(ld16(x + pix * x_cs + x_coff + ch * 8), xv);
+    load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
+    load8(x + pix * x_cs + x_coff + ch * 8, xv);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int c = ch * 8 + t;
@@ -316,19 +318,20 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const half_t* dy,
       if (c1 != nullptr) gg = gg - c1[c] - (xv[t] - mean[c]) * invstd[c] * c2[c];
       o[t] = gg * sc;
     }
-    half_t* dst = dx + pix * dx_cs + dx_coff + ch * 8;
+    T* dst = dx + pix * dx_cs + dx_coff + ch * 8;
     if (accumulate) {
       float old[8];
-      unpack8(ld16(dst), old);
+      load8(dst, old);
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] += old[t];
     }
-    st16(dst, pack8(o));
+    store8(dst, o);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ activation backward
-__global__ __launch_bounds__(TPB) void act_bwd_kernel(const half_t* dy, const half_t* y, half_t* dx, int64_t npix, int cs, int C,
+template <typename T>
+__global__ __launch_bounds__(TPB) void act_bwd_kernel(const T* dy, const T* y, T* dx, int64_t npix, int cs, int C,
                                                       int act, float alpha, float* dbias, float gscale, const float* gscale_ptr,
                                                       ColLayout L) {
   __shared__ float sm[TPB * 8];
@@ -345,14 +348,14 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(const half_t* dy, const ha
     if (ch < L.CH) {
       for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
         float g[8], yv[8];
-        unpack8(ld16(dy + pix * cs + ch * 8), g);
-        unpack8(ld16(y + pix * cs + ch * 8), yv);
+        load8(dy + pix * cs + ch * 8, g);
+        load8(y + pix * cs + ch * 8, yv);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           g[t] *= seg_act_grad_from_out(yv[t], act, alpha);
           acc[0][t] += g[t];
         }
-        st16(dx + pix * cs + ch * 8, pack8(g));
+        store8(dx + pix * cs + ch * 8, g);
       }
     }
     if (dbias != nullptr) {
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(const half_t* dy, const ha
 }
 
 // ------------------------------------------------------------------------------------------------ max pooling
-__global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int cs, int ph, int pw) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const T* x, T* y, int N, int H, int W, int cs, int ph, int pw) {
   const int CH = cs / 8, HP = H / ph, WP = W / pw;
   const int64_t items = (int64_t)N * HP * WP * CH;
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
@@ -382,15 +386,16 @@ __global__ __launch_bounds__(TPB) void maxpool_fwd_kernel(const half_t* x, half_
     for (int dy = 0; dy < ph; ++dy)
       for (int dx = 0; dx < pw; ++dx) {
         float f[8];
-        unpack8(ld16(x + (((int64_t)n * H + hp * ph + dy) * W + wp * pw + dx) * cs + ch * 8), f);
+        load8(x + (((int64_t)n * H + hp * ph + dy) * W + wp * pw + dx) * cs + ch * 8, f);
 #pragma unroll
         for (int t = 0; t < 8; ++t) mx[t] = fmaxf(mx[t], f[t]);
       }
-    st16(y + it * 8, pack8(mx));
+    store8(y + it * 8, mx);
   }
 }
 
-__global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const half_t* dy, const half_t* x, const half_t* y, half_t* dx, int N, int H,
+template <typename T>
+__global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const T* dy, const T* x, const T* y, T* dx, int N, int H,
                                                           int W, int cs, int ph, int pw, int accumulate) {
   const int CH = cs / 8, HP = H / ph, WP = W / pw;
   const int HB = (H + ph - 1) / ph, WB = (W + pw - 1) / pw;
@@ -408,31 +413,31 @@ __global__ __launch_bounds__(TPB) void maxpool_bwd_kernel(const half_t* dy, cons
     for (int t = 0; t < 8; ++t) { g[t] = 0.f; mx[t] = 0.f; done[t] = false; }
     if (full) {
       const int64_t pp = ((int64_t)n * HP + hb) * WP + wb;
-      unpack8(ld16(dy + pp * cs + ch * 8), g);
-      unpack8(ld16(y + pp * cs + ch * 8), mx);
+      load8(dy + pp * cs + ch * 8, g);
+      load8(y + pp * cs + ch * 8, mx);
     }
     for (int dyy = 0; dyy < ph; ++dyy)
       for (int dxx = 0; dxx < pw; ++dxx) {
         const int yy = hb * ph + dyy, xx = wb * pw + dxx;
         if (yy >= H || xx >= W) continue;
-        half_t* dst = dx + (((int64_t)n * H + yy) * W + xx) * cs + ch * 8;
+        T* dst = dx + (((int64_t)n * H + yy) * W + xx) * cs + ch * 8;
         float o[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) o[t] = 0.f;
         if (full) {
           float f[8];
-          unpack8(ld16(x + (((int64_t)n * H + yy) * W + xx) * cs + ch * 8), f);
+          load8(x + (((int64_t)n * H + yy) * W + xx) * cs + ch * 8, f);
 #pragma unroll
           for (int t = 0; t < 8; ++t)
             if (!done[t] && f[t] == mx[t]) { o[t] = g[t]; done[t] = true; }
         }
         if (accumulate) {
           float old[8];
-          unpack8(ld16(dst), old);
+          load8(dst, old);
 #pragma unroll
           for (int t = 0; t < 8; ++t) o[t] += old[t];
         }
-        st16(dst, pack8(o));
+        store8(dst, o);
       }
   }
 }
@@ -447,7 +452,8 @@ __device__ __forceinline__ void bilin_src(int o, int f, int n_in, int& i0, int& 
   i1 = min(max(a + 1, 0), n_in - 1);
 }
 
-__global__ __launch_bounds__(TPB) void upsample_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int cs, int fh, int fw,
+template <typename T>
+__global__ __launch_bounds__(TPB) void upsample_fwd_kernel(const T* x, T* y, int N, int H, int W, int cs, int fh, int fw,
                                                            int bilinear) {
   const int CH = cs / 8, HO = H * fh, WO = W * fw;
   const int64_t items = (int64_t)N * HO * WO * CH;
@@ -464,25 +470,26 @@ __global__ __launch_bounds__(TPB) void upsample_fwd_kernel(const half_t* x, half
       bilin_src(yo, fh, H, y0, y1, wy);
       bilin_src(xo, fw, W, x0, x1, wx);
       float a[8], b[8], c[8], d[8];
-      const half_t* base = x + (int64_t)n * H * W * cs + ch * 8;
-      unpack8(ld16(base + ((int64_t)y0 * W + x0) * cs), a);
-      unpack8(ld16(base + ((int64_t)y0 * W + x1) * cs), b);
-      unpack8(ld16(base + ((int64_t)y1 * W + x0) * cs), c);
-      unpack8(ld16(base + ((int64_t)y1 * W + x1) * cs), d);
+      const T* base = x + (int64_t)n * H * W * cs + ch * 8;
+      load8(base + ((int64_t)y0 * W + x0) * cs, a);
+      load8(base + ((int64_t)y0 * W + x1) * cs, b);
+      load8(base + ((int64_t)y1 * W + x0) * cs, c);
+      load8(base + ((int64_t)y1 * W + x1) * cs, d);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float top = a[t] + (b[t] - a[t]) * wx, bot = c[t] + (d[t] - c[t]) * wx;
         o[t] = top + (bot - top) * wy;
       }
     } else {
-      unpack8(ld16(x + (((int64_t)n * H + yo / fh) * W + xo / fw) * cs + ch * 8), o);
+      load8(x + (((int64_t)n * H + yo / fh) * W + xo / fw) * cs + ch * 8, o);
     }
-    st16(y + it * 8, pack8(o));
+    store8(y + it * 8, o);
   }
 }
 
 // gather form of the transpose: every input pixel sums the output pixels whose footprint contains it
-__global__ __launch_bounds__(TPB) void upsample_bwd_kernel(const half_t* dy, half_t* dx, int N, int H, int W, int cs, int fh, int fw,
+template <typename T>
+__global__ __launch_bounds__(TPB) void upsample_bwd_kernel(const T* dy, T* dx, int N, int H, int W, int cs, int fh, int fw,
                                                            int bilinear, int accumulate) {
   const int CH = cs / 8, HO = H * fh, WO = W * fw;
   const int64_t items = (int64_t)N * H * W * CH;
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(TPB) void upsample_bwd_kernel(const half_t* dy, hal
     float o[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[t] = 0.f;
-    const half_t* base = dy + (int64_t)n * HO * WO * cs + ch * 8;
+    const T* base = dy + (int64_t)n * HO * WO * cs + ch * 8;
     if (bilinear) {
       const int ylo = max(0, (yi - 1) * fh), yhi = min(HO, (yi + 2) * fh);
       const int xlo = max(0, (xi - 1) * fw), xhi = min(WO, (xi + 2) * fw);
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(TPB) void upsample_bwd_kernel(const half_t* dy, hal
           const float cx = (x0 == xi ? 1.f - wx : 0.f) + (x1 == xi ? wx : 0.f);
           if (cx == 0.f) continue;
           float g[8];
-          unpack8(ld16(base + ((int64_t)yo * WO + xo) * cs), g);
+          load8(base + ((int64_t)yo * WO + xo) * cs, g);
 #pragma unroll
           for (int t = 0; t < 8; ++t) o[t] += g[t] * (cy * cx);
         }
@@ -519,50 +526,52 @@ __global__ __launch_bounds__(TPB) void upsample_bwd_kernel(const half_t* dy, hal
       for (int a = 0; a < fh; ++a)
         for (int b = 0; b < fw; ++b) {
           float g[8];
-          unpack8(ld16(base + ((int64_t)(yi * fh + a) * WO + xi * fw + b) * cs), g);
+          load8(base + ((int64_t)(yi * fh + a) * WO + xi * fw + b) * cs, g);
 #pragma unroll
           for (int t = 0; t < 8; ++t) o[t] += g[t];
         }
     }
-    half_t* dst = dx + it * 8;
+    T* dst = dx + it * 8;
     if (accumulate) {
       float old[8];
-      unpack8(ld16(dst), old);
+      load8(dst, old);
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] += old[t];
     }
-    st16(dst, pack8(o));
+    store8(dst, o);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ add / mul
-struct Ptr4 { const half_t* p[4]; };
-struct MPtr4 { half_t* p[4]; };
+template <typename T> struct Ptr4 { const T* p[4]; };
+template <typename T> struct MPtr4 { T* p[4]; };
 
-__global__ __launch_bounds__(TPB) void add_act_fwd_kernel(Ptr4 xs, int n, half_t* y, int64_t nchunks, int act, float alpha) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void add_act_fwd_kernel(Ptr4<T> xs, int n, T* y, int64_t nchunks, int act, float alpha) {
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < nchunks; it += (int64_t)gridDim.x * TPB) {
     float o[8];
-    unpack8(ld16(xs.p[0] + it * 8), o);
+    load8(xs.p[0] + it * 8, o);
     for (int k = 1; k < n; ++k) {
       float f[8];
-      unpack8(ld16(xs.p[k] + it * 8), f);
+      load8(xs.p[k] + it * 8, f);
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] += f[t];
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[t] = seg_act(o[t], act, alpha);
-    st16(y + it * 8, pack8(o));
+    store8(y + it * 8, o);
   }
 }
 
-__global__ __launch_bounds__(TPB) void add_act_bwd_kernel(const half_t* dy, const half_t* y, MPtr4 dxs, int n, int64_t nchunks, int act,
+template <typename T>
+__global__ __launch_bounds__(TPB) void add_act_bwd_kernel(const T* dy, const T* y, MPtr4<T> dxs, int n, int64_t nchunks, int act,
                                                           float alpha, int accmask) {
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < nchunks; it += (int64_t)gridDim.x * TPB) {
     float g[8];
-    unpack8(ld16(dy + it * 8), g);
+    load8(dy + it * 8, g);
     if (act != SEG_ACT_NONE) {
       float yv[8];
-      unpack8(ld16(y + it * 8), yv);
+      load8(y + it * 8, yv);
 #pragma unroll
       for (int t = 0; t < 8; ++t) g[t] *= seg_act_grad_from_out(yv[t], act, alpha);
     }
@@ -573,31 +582,33 @@ __global__ __launch_bounds__(TPB) void add_act_bwd_kernel(const half_t* dy, cons
       for (int t = 0; t < 8; ++t) o[t] = g[t];
       if (accmask & (1 << k)) {
         float old[8];
-        unpack8(ld16(dxs.p[k] + it * 8), old);
+        load8(dxs.p[k] + it * 8, old);
 #pragma unroll
         for (int t = 0; t < 8; ++t) o[t] += old[t];
       }
-      st16(dxs.p[k] + it * 8, pack8(o));
+      store8(dxs.p[k] + it * 8, o);
     }
   }
 }
 
-__global__ __launch_bounds__(TPB) void mul_bcast_fwd_kernel(const half_t* a, const half_t* r, half_t* y, int64_t npix, int cs, int r_cs) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void mul_bcast_fwd_kernel(const T* a, const T* r, T* y, int64_t npix, int cs, int r_cs) {
   const int CH = cs / 8;
   const int64_t items = npix * CH;
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
     const int64_t pix = it / CH;
     const float rv = (float)r[pix * r_cs];
     float f[8];
-    unpack8(ld16(a + it * 8), f);
+    load8(a + it * 8, f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) f[t] *= rv;
-    st16(y + it * 8, pack8(f));
+    store8(y + it * 8, f);
   }
 }
 
 // one group of LPP lanes per pixel (LPP = power of two <= 64); dr needs the sum over all channels of the pixel
-__global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const half_t* dy, const half_t* a, const half_t* r, half_t* da, half_t* dr,
+template <typename T>
+__global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const T* dy, const T* a, const T* r, T* da, T* dr,
                                                             int64_t npix, int cs, int r_cs, int acc_a, int acc_r, int LPP) {
   const int CH = cs / 8;
   const int gpb = TPB / LPP;
@@ -610,28 +621,28 @@ __global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const half_t* dy, co
     for (int ch = sub; ch < CH; ch += LPP) {
       if (!ok) break;
       float g[8], av[8], o[8];
-      unpack8(ld16(dy + pix * cs + ch * 8), g);
-      unpack8(ld16(a + pix * cs + ch * 8), av);
+      load8(dy + pix * cs + ch * 8, g);
+      load8(a + pix * cs + ch * 8, av);
 #pragma unroll
       for (int t = 0; t < 8; ++t) { dot += g[t] * av[t]; o[t] = g[t] * rv; }
       if (da != nullptr) {
-        half_t* dst = da + pix * cs + ch * 8;
+        T* dst = da + pix * cs + ch * 8;
         if (acc_a) {
           float old[8];
-          unpack8(ld16(dst), old);
+          load8(dst, old);
 #pragma unroll
           for (int t = 0; t < 8; ++t) o[t] += old[t];
         }
-        st16(dst, pack8(o));
+        store8(dst, o);
       }
     }
     for (int o = LPP >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
     if (ok && sub == 0 && dr != nullptr) {
       float f[8] = {dot, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      half_t* dst = dr + pix * r_cs;
+      T* dst = dr + pix * r_cs;
       if (acc_r) f[0] += (float)dst[0];
-      if (r_cs >= 8) st16(dst, pack8(f));
-      else dst[0] = (half_t)f[0];
+      if (r_cs >= 8) store8(dst, f);
+      else dst[0] = (T)f[0];
     }
   }
 }
@@ -641,24 +652,26 @@ __device__ __forceinline__ float hsig(float v) { return fminf(fmaxf(0.2f * v + 0
 // TF clip_by_value (minimum/maximum) passes the gradient AT the knees, so the interval is closed
 __device__ __forceinline__ float hsig_grad(float v) { return (v >= -2.5f && v <= 2.5f) ? 0.2f : 0.f; }
 
-__global__ __launch_bounds__(TPB) void convlstm_gate_fwd_kernel(const half_t* z, int z_cs, half_t* h, int h_cs, int64_t npix, int F) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void convlstm_gate_fwd_kernel(const T* z, int z_cs, T* h, int h_cs, int64_t npix, int F) {
   const int CH = F / 8;
   const int64_t items = npix * CH;
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
     const int64_t pix = it / CH;
     const int ch = (int)(it - pix * CH);
     float zi[8], zc[8], zo[8], o[8];
-    const half_t* zp = z + pix * z_cs + ch * 8;
-    unpack8(ld16(zp), zi);
-    unpack8(ld16(zp + 2 * F), zc);
-    unpack8(ld16(zp + 3 * F), zo);
+    const T* zp = z + pix * z_cs + ch * 8;
+    load8(zp, zi);
+    load8(zp + 2 * F, zc);
+    load8(zp + 3 * F, zo);
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[t] = hsig(zo[t]) * tanhf(hsig(zi[t]) * tanhf(zc[t]));
-    st16(h + pix * h_cs + ch * 8, pack8(o));
+    store8(h + pix * h_cs + ch * 8, o);
   }
 }
 
-__global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const half_t* dh, int h_cs, const half_t* z, int z_cs, half_t* dz,
+template <typename T>
+__global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const T* dh, int h_cs, const T* z, int z_cs, T* dz,
                                                                 int64_t npix, int F) {
   const int CH = F / 8;
   const int64_t items = npix * CH;
@@ -666,11 +679,11 @@ __global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const half_t* dh
     const int64_t pix = it / CH;
     const int ch = (int)(it - pix * CH);
     float zi[8], zc[8], zo[8], g[8], di[8], dc[8], dO[8], zero[8];
-    const half_t* zp = z + pix * z_cs + ch * 8;
-    unpack8(ld16(zp), zi);
-    unpack8(ld16(zp + 2 * F), zc);
-    unpack8(ld16(zp + 3 * F), zo);
-    unpack8(ld16(dh + pix * h_cs + ch * 8), g);
+    const T* zp = z + pix * z_cs + ch * 8;
+    load8(zp, zi);
+    load8(zp + 2 * F, zc);
+    load8(zp + 3 * F, zo);
+    load8(dh + pix * h_cs + ch * 8, g);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const float a = hsig(zi[t]), b = tanhf(zc[t]), u = a * b, tu = tanhf(u), o = hsig(zo[t]);
@@ -680,18 +693,19 @@ __global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const half_t* dh
       dc[t] = du * a * (1.f - b * b);
       zero[t] = 0.f;
     }
-    half_t* dp = dz + pix * z_cs + ch * 8;
-    st16(dp, pack8(di));
-    st16(dp + F, pack8(zero));
-    st16(dp + 2 * F, pack8(dc));
-    st16(dp + 3 * F, pack8(dO));
+    T* dp = dz + pix * z_cs + ch * 8;
+    store8(dp, di);
+    store8(dp + F, zero);
+    store8(dp + 2 * F, dc);
+    store8(dp + 3 * F, dO);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ 1x1 heads (Cout <= 8)
 constexpr int HEAD_MAXC = 8;
 
-__global__ __launch_bounds__(TPB) void head_fwd_kernel(const half_t* x, int cs, int Cin, int N, int H, int W, int sy, int sx,
+template <typename T>
+__global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int Cin, int N, int H, int W, int sy, int sx,
                                                        const float* w, int w_ld, const float* b, int Cout, int act, float* y, int LPP) {
   const int CH = (Cin + 7) / 8;
   const int HO = (H + sy - 1) / sy, WO = (W + sx - 1) / sx;
@@ -708,10 +722,10 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const half_t* x, int cs, 
       const int xo = (int)(pix % WO);
       const int yo = (int)((pix / WO) % HO);
       const int n = (int)(pix / ((int64_t)WO * HO));
-      const half_t* xp = x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+      const T* xp = x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
       for (int ch = sub; ch < CH; ch += LPP) {
         float f[8];
-        unpack8(ld16(xp + ch * 8), f);
+        load8(xp + ch * 8, f);
 #pragma unroll
         for (int k = 0; k < HEAD_MAXC; ++k)
           if (k < Cout) {
@@ -765,8 +779,9 @@ __device__ __forceinline__ void head_dpre(const float* dy, const float* y, int C
 }
 
 // dx (+)= gs * dpre . w      (one LPP-lane group per pixel, like the forward)
+template <typename T>
 __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const float* y, int cs, int Cin, int N, int H, int W, int sy,
-                                                          int sx, const float* w, int w_ld, int Cout, int act, half_t* dx,
+                                                          int sx, const float* w, int w_ld, int Cout, int act, T* dx,
                                                           int accumulate, const float* gs_ptr, int LPP) {
   const int CH = cs / 8;
   const int HO = (H + sy - 1) / sy, WO = (W + sx - 1) / sx;
@@ -787,7 +802,7 @@ __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const
     const int xo = (int)(pix % WO);
     const int yo = (int)((pix / WO) % HO);
     const int n = (int)(pix / ((int64_t)WO * HO));
-    half_t* dp = dx + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+    T* dp = dx + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
     for (int ch = sub; ch < CH; ch += LPP) {
       float o[8];
 #pragma unroll
@@ -803,17 +818,18 @@ __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const
       }
       if (accumulate) {
         float old[8];
-        unpack8(ld16(dp + ch * 8), old);
+        load8(dp + ch * 8, old);
 #pragma unroll
         for (int t = 0; t < 8; ++t) o[t] += old[t];
       }
-      st16(dp + ch * 8, pack8(o));
+      store8(dp + ch * 8, o);
     }
   }
 }
 
 // dw[k][c] += sum_pix dpre[k] * x[c],  db[k] += sum_pix dpre[k]   ((rows x chunk-columns) layout + atomics)
-__global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const float* y, const half_t* x, int cs, int Cin, int N, int H,
+template <typename T>
+__global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const float* y, const T* x, int cs, int Cin, int N, int H,
                                                           int W, int sy, int sx, int w_ld, int Cout, int act, float* dw, float* db,
                                                           ColLayout L) {
   __shared__ float sm[TPB * 8];
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
         const int yo = (int)((pix / WO) % HO);
         const int n = (int)(pix / ((int64_t)WO * HO));
         float f[8];
-        unpack8(ld16(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + ch * 8), f);
+        load8(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + ch * 8, f);
 #pragma unroll
         for (int k = 0; k < HEAD_MAXC; ++k)
           if (k < Cout) {
@@ -975,15 +991,16 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* p, const float* g, flo
   }
 }
 
-__global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, half_t* wt, int rows, int T, int K, int rows_pad) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, T* wt, int rows, int Tn, int K, int rows_pad) {
   // out[k][t][r] = in[r][t][k];   grid-stride over the OUTPUT so that stores are coalesced
-  const int64_t n = (int64_t)K * T * rows_pad;
+  const int64_t n = (int64_t)K * Tn * rows_pad;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int r = (int)(i % rows_pad);
     const int64_t q = i / rows_pad;
-    const int t = (int)(q % T);
-    const int k = (int)(q / T);
-    wt[i] = (r < rows) ? (half_t)w[((int64_t)r * T + t) * K + k] : (half_t)0.f;
+    const int t = (int)(q % Tn);
+    const int k = (int)(q / Tn);
+    wt[i] = (r < rows) ? (T)w[((int64_t)r * Tn + t) * K + k] : (T)0.f;
   }
 }
 
@@ -991,16 +1008,18 @@ __global__ __launch_bounds__(TPB) void cast_kernel(const float* x, half_t* y, in
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) y[i] = (half_t)x[i];
 }
 
-__global__ __launch_bounds__(TPB) void pack_input_kernel(const float* x, half_t* y, int64_t npix, int C, int cs) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void pack_input_kernel(const float* x, T* y, int64_t npix, int C, int cs) {
   const int64_t n = npix * cs;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int c = (int)(i % cs);
     const int64_t pix = i / cs;
-    y[i] = (c < C) ? (half_t)x[pix * C + c] : (half_t)0.f;
+    y[i] = (c < C) ? (T)x[pix * C + c] : (T)0.f;
   }
 }
 
-__global__ __launch_bounds__(TPB) void unpack_kernel(const half_t* x, float* y, int64_t npix, int C, int cs, int coff) {
+template <typename T>
+__global__ __launch_bounds__(TPB) void unpack_kernel(const T* x, float* y, int64_t npix, int C, int cs, int coff) {
   const int64_t n = npix * C;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int c = (int)(i % C);
@@ -1014,16 +1033,19 @@ __global__ __launch_bounds__(TPB) void unpack_kernel(const half_t* x, float* y, 
 // ================================================================================================ C ABI
 #define ST(s) ((hipStream_t)(s))
 
-extern "C" int seg_bn_stats(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts,
+template <typename T>
+static int seg_bn_stats_impl(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts,
                             int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) {
   SEG_CHECK_ARG(x && stats && npix > 0 && C > 0 && (C & 7) == 0 && (cs & 7) == 0 && (coff & 7) == 0 && coff + C <= cs && nparts > 0 &&
                     stats_coff + C <= stats_ld,
                 "seg_bn_stats: bad arguments (npix=%ld C=%d cs=%d coff=%d nparts=%d)", (long)npix, C, cs, coff, nparts);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts), dim3(TPB), 0, ST(stream), (const half_t*)x, npix, cs, coff, C, stats, nparts,
+  hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)x, npix, cs, coff, C, stats, nparts,
                      stats_ld, stats_coff, col_layout(C));
   SEG_CHECK_LAUNCH("seg_bn_stats");
   return SEG_OK;
 }
+extern "C" int seg_bn_stats(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_bn_stats_impl<half_t>(x, npix, cs, coff, C, stats, nparts, stats_ld, stats_coff, stream); }
+extern "C" int seg_bn_stats_f32(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_bn_stats_impl<float>(x, npix, cs, coff, C, stats, nparts, stats_ld, stats_coff, stream); }
 
 extern "C" int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, int64_t count, const float* gamma, const float* beta,
                                float eps, float momentum, float* moving_mean, float* moving_var, int32_t unbiased_moving,
@@ -1044,7 +1066,8 @@ extern "C" int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, in
   return SEG_OK;
 }
 
-extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H,
+template <typename T>
+static int seg_bn_act_apply_impl(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H,
                                 int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha,
                                 void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && scale && shift && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (x_cs & 7) == 0 && (y_cs & 7) == 0 &&
@@ -1052,29 +1075,34 @@ extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, voi
                 "seg_bn_act_apply: bad arguments");
   const int64_t npix = (int64_t)N * H * W;
   if (pooled == nullptr) {
-    hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const half_t*)x, x_cs, x_coff,
-                       (half_t*)y, y_cs, y_coff, npix, C, c_valid, scale, shift, act, alpha);
+    hipLaunchKernelGGL((bn_act_apply_kernel<T>), dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
+                       (T*)y, y_cs, y_coff, npix, C, c_valid, scale, shift, act, alpha);
   } else {
     SEG_CHECK_ARG(ph >= 1 && pw >= 1 && y_coff == 0 && C == y_cs, "seg_bn_act_apply: fused pooling needs a dense output (C == y_cs)");
     const int64_t items = (int64_t)N * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (C / 8);
-    hipLaunchKernelGGL(bn_act_apply_pool_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)x, x_cs, x_coff,
-                       (half_t*)y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, (half_t*)pooled, ph, pw);
+    hipLaunchKernelGGL((bn_act_apply_pool_kernel<T>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
+                       (T*)y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, (T*)pooled, ph, pw);
   }
   SEG_CHECK_LAUNCH("seg_bn_act_apply");
   return SEG_OK;
 }
+extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<half_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
+extern "C" int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<float>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
 
-extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
+template <typename T>
+static int seg_bn_act_bwd_reduce_impl(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
                                      int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && x && scale && shift && mean && invstd && partial && npix > 0 && C > 0 && (C & 7) == 0 && nparts > 0 &&
                     dy_coff + C <= dy_cs && x_coff + C <= x_cs,
                 "seg_bn_act_bwd_reduce: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nparts), dim3(TPB), 0, ST(stream), (const half_t*)dy, dy_cs, dy_coff, (const half_t*)x,
+  hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff, (const T*)x,
                      x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C));
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_reduce");
   return SEG_OK;
 }
+extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, stream); }
+extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<float>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, stream); }
 
 extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma, float* dbeta,
                                    float gscale, const float* gscale_ptr, float* c1, float* c2, seg_stream_t stream) {
@@ -1085,100 +1113,128 @@ extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t
   return SEG_OK;
 }
 
-extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx,
+template <typename T>
+static int seg_bn_act_bwd_apply_impl(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx,
                                     int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
                                     const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha,
                                     int32_t accumulate, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
                     dx_coff + C <= dx_cs && (c1 == nullptr || (c2 && mean && invstd)),
                 "seg_bn_act_bwd_apply: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const half_t*)dy, dy_cs, dy_coff,
-                     (const half_t*)x, x_cs, x_coff, (half_t*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
+                     (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
                      accumulate);
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply");
   return SEG_OK;
 }
+extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, stream); }
+extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<float>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, stream); }
 
-extern "C" int seg_act_bwd(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,
+template <typename T>
+static int seg_act_bwd_impl(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,
                            float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && y && dx && npix > 0 && cs > 0 && (cs & 7) == 0 && C > 0 && C <= cs, "seg_act_bwd: bad arguments");
   int blocks = (int)((npix + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)y, (half_t*)dx, npix, cs, C,
+  hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)y, (T*)dx, npix, cs, C,
                      act, alpha, dbias, gscale, gscale_ptr, col_layout(cs));
   SEG_CHECK_LAUNCH("seg_act_bwd");
   return SEG_OK;
 }
+extern "C" int seg_act_bwd(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) { return seg_act_bwd_impl<half_t>(dy, y, dx, npix, cs, C, act, alpha, dbias, gscale, gscale_ptr, stream); }
+extern "C" int seg_act_bwd_f32(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) { return seg_act_bwd_impl<float>(dy, y, dx, npix, cs, C, act, alpha, dbias, gscale, gscale_ptr, stream); }
 
-extern "C" int seg_maxpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw,
+template <typename T>
+static int seg_maxpool_fwd_impl(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw,
                                seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && N > 0 && H >= ph && W >= pw && ph >= 1 && pw >= 1 && (cs & 7) == 0, "seg_maxpool_fwd: bad arguments");
   const int64_t items = (int64_t)N * (H / ph) * (W / pw) * (cs / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)x, (half_t*)y, N, H, W, cs, ph, pw);
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)x, (T*)y, N, H, W, cs, ph, pw);
   SEG_CHECK_LAUNCH("seg_maxpool_fwd");
   return SEG_OK;
 }
+extern "C" int seg_maxpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_maxpool_fwd_impl<half_t>(x, y, N, H, W, cs, ph, pw, stream); }
+extern "C" int seg_maxpool_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_maxpool_fwd_impl<float>(x, y, N, H, W, cs, ph, pw, stream); }
 
-extern "C" int seg_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs,
+template <typename T>
+static int seg_maxpool_bwd_impl(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs,
                                int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && x && y && dx && N > 0 && H >= ph && W >= pw && ph >= 1 && pw >= 1 && (cs & 7) == 0, "seg_maxpool_bwd: bad arguments");
   const int64_t items = (int64_t)N * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (cs / 8);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)x,
-                     (const half_t*)y, (half_t*)dx, N, H, W, cs, ph, pw, accumulate);
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x,
+                     (const T*)y, (T*)dx, N, H, W, cs, ph, pw, accumulate);
   SEG_CHECK_LAUNCH("seg_maxpool_bwd");
   return SEG_OK;
 }
+extern "C" int seg_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) { return seg_maxpool_bwd_impl<half_t>(dy, x, y, dx, N, H, W, cs, ph, pw, accumulate, stream); }
+extern "C" int seg_maxpool_bwd_f32(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) { return seg_maxpool_bwd_impl<float>(dy, x, y, dx, N, H, W, cs, ph, pw, accumulate, stream); }
 
-extern "C" int seg_upsample_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
+template <typename T>
+static int seg_upsample_fwd_impl(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
                                 int32_t bilinear, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && fh >= 1 && fw >= 1 && (cs & 7) == 0, "seg_upsample_fwd: bad arguments");
   const int64_t items = (int64_t)N * H * fh * W * fw * (cs / 8);
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)x, (half_t*)y, N, H, W, cs, fh, fw,
+  hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)x, (T*)y, N, H, W, cs, fh, fw,
                      bilinear);
   SEG_CHECK_LAUNCH("seg_upsample_fwd");
   return SEG_OK;
 }
+extern "C" int seg_upsample_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, seg_stream_t stream) { return seg_upsample_fwd_impl<half_t>(x, y, N, H, W, cs, fh, fw, bilinear, stream); }
+extern "C" int seg_upsample_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, seg_stream_t stream) { return seg_upsample_fwd_impl<float>(x, y, N, H, W, cs, fh, fw, bilinear, stream); }
 
-extern "C" int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
+template <typename T>
+static int seg_upsample_bwd_impl(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
                                 int32_t bilinear, int32_t accumulate, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && fh >= 1 && fw >= 1 && (cs & 7) == 0, "seg_upsample_bwd: bad arguments");
   const int64_t items = (int64_t)N * H * W * (cs / 8);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const half_t*)dy, (half_t*)dx, N, H, W, cs, fh,
+  hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)dy, (T*)dx, N, H, W, cs, fh,
                      fw, bilinear, accumulate);
   SEG_CHECK_LAUNCH("seg_upsample_bwd");
   return SEG_OK;
 }
+extern "C" int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream) { return seg_upsample_bwd_impl<half_t>(dy, dx, N, H, W, cs, fh, fw, bilinear, accumulate, stream); }
+extern "C" int seg_upsample_bwd_f32(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream) { return seg_upsample_bwd_impl<float>(dy, dx, N, H, W, cs, fh, fw, bilinear, accumulate, stream); }
 
-extern "C" int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) {
+template <typename T>
+static int seg_add_act_fwd_impl(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) {
   SEG_CHECK_ARG(xs && y && n >= 1 && n <= 4 && nelem > 0 && (nelem & 7) == 0, "seg_add_act_fwd: bad arguments (n=%d)", n);
-  Ptr4 p;
-  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (const half_t*)xs[k] : nullptr;
-  hipLaunchKernelGGL(add_act_fwd_kernel, dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), p, n, (half_t*)y, nelem / 8, act, alpha);
+  Ptr4<T> p;
+  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (const T*)xs[k] : nullptr;
+  hipLaunchKernelGGL((add_act_fwd_kernel<T>), dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), p, n, (T*)y, nelem / 8, act, alpha);
   SEG_CHECK_LAUNCH("seg_add_act_fwd");
   return SEG_OK;
 }
+extern "C" int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<half_t>(xs, n, y, nelem, act, alpha, stream); }
+extern "C" int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<float>(xs, n, y, nelem, act, alpha, stream); }
 
-extern "C" int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha,
+template <typename T>
+static int seg_add_act_bwd_impl(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha,
                                int32_t accumulate_mask, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && dxs && n >= 1 && n <= 4 && nelem > 0 && (nelem & 7) == 0 && (act == SEG_ACT_NONE || y), "seg_add_act_bwd: bad arguments");
-  MPtr4 p;
-  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (half_t*)dxs[k] : nullptr;
-  hipLaunchKernelGGL(add_act_bwd_kernel, dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)y, p, n,
+  MPtr4<T> p;
+  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (T*)dxs[k] : nullptr;
+  hipLaunchKernelGGL((add_act_bwd_kernel<T>), dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)y, p, n,
                      nelem / 8, act, alpha, accumulate_mask);
   SEG_CHECK_LAUNCH("seg_add_act_bwd");
   return SEG_OK;
 }
+extern "C" int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<half_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
+extern "C" int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<float>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
 
-extern "C" int seg_mul_bcast_fwd(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) {
+template <typename T>
+static int seg_mul_bcast_fwd_impl(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) {
   SEG_CHECK_ARG(a && r && y && npix > 0 && (cs & 7) == 0 && r_cs >= 1, "seg_mul_bcast_fwd: bad arguments");
-  hipLaunchKernelGGL(mul_bcast_fwd_kernel, dim3(grid_for(npix * (cs / 8))), dim3(TPB), 0, ST(stream), (const half_t*)a, (const half_t*)r,
-                     (half_t*)y, npix, cs, r_cs);
+  hipLaunchKernelGGL((mul_bcast_fwd_kernel<T>), dim3(grid_for(npix * (cs / 8))), dim3(TPB), 0, ST(stream), (const T*)a, (const T*)r,
+                     (T*)y, npix, cs, r_cs);
   SEG_CHECK_LAUNCH("seg_mul_bcast_fwd");
   return SEG_OK;
 }
+extern "C" int seg_mul_bcast_fwd(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) { return seg_mul_bcast_fwd_impl<half_t>(a, r, y, npix, cs, r_cs, stream); }
+extern "C" int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) { return seg_mul_bcast_fwd_impl<float>(a, r, y, npix, cs, r_cs, stream); }
 
-extern "C" int seg_mul_bcast_bwd(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs,
+template <typename T>
+static int seg_mul_bcast_bwd_impl(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs,
                                  int32_t acc_a, int32_t acc_r, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && a && r && npix > 0 && (cs & 7) == 0 && r_cs >= 1, "seg_mul_bcast_bwd: bad arguments");
   int LPP = pow2ceil(cs / 8);
@@ -1186,36 +1242,45 @@ extern "C" int seg_mul_bcast_bwd(const void* dy, const void* a, const void* r, v
   const int gpb = TPB / LPP;
   int64_t blocks = (npix + gpb - 1) / gpb;
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
-  hipLaunchKernelGGL(mul_bcast_bwd_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), (const half_t*)dy, (const half_t*)a, (const half_t*)r,
-                     (half_t*)da, (half_t*)dr, npix, cs, r_cs, acc_a, acc_r, LPP);
+  hipLaunchKernelGGL((mul_bcast_bwd_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)a, (const T*)r,
+                     (T*)da, (T*)dr, npix, cs, r_cs, acc_a, acc_r, LPP);
   SEG_CHECK_LAUNCH("seg_mul_bcast_bwd");
   return SEG_OK;
 }
+extern "C" int seg_mul_bcast_bwd(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream) { return seg_mul_bcast_bwd_impl<half_t>(dy, a, r, da, dr, npix, cs, r_cs, acc_a, acc_r, stream); }
+extern "C" int seg_mul_bcast_bwd_f32(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream) { return seg_mul_bcast_bwd_impl<float>(dy, a, r, da, dr, npix, cs, r_cs, acc_a, acc_r, stream); }
 
-extern "C" int seg_convlstm_gate_fwd(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) {
+template <typename T>
+static int seg_convlstm_gate_fwd_impl(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) {
   SEG_CHECK_ARG(z && h && npix > 0 && F > 0 && (F & 7) == 0 && 4 * F <= z_cs && F <= h_cs && (z_cs & 7) == 0 && (h_cs & 7) == 0,
                 "seg_convlstm_gate_fwd: bad arguments (F=%d z_cs=%d h_cs=%d)", F, z_cs, h_cs);
-  hipLaunchKernelGGL(convlstm_gate_fwd_kernel, dim3(grid_for(npix * (F / 8))), dim3(TPB), 0, ST(stream), (const half_t*)z, z_cs, (half_t*)h,
+  hipLaunchKernelGGL((convlstm_gate_fwd_kernel<T>), dim3(grid_for(npix * (F / 8))), dim3(TPB), 0, ST(stream), (const T*)z, z_cs, (T*)h,
                      h_cs, npix, F);
   SEG_CHECK_LAUNCH("seg_convlstm_gate_fwd");
   return SEG_OK;
 }
+extern "C" int seg_convlstm_gate_fwd(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_fwd_impl<half_t>(z, z_cs, h, h_cs, npix, F, stream); }
+extern "C" int seg_convlstm_gate_fwd_f32(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_fwd_impl<float>(z, z_cs, h, h_cs, npix, F, stream); }
 
-extern "C" int seg_convlstm_gate_bwd(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F,
+template <typename T>
+static int seg_convlstm_gate_bwd_impl(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F,
                                      seg_stream_t stream) {
   SEG_CHECK_ARG(dh && z && dz && npix > 0 && F > 0 && (F & 7) == 0 && 4 * F <= z_cs && F <= h_cs, "seg_convlstm_gate_bwd: bad arguments");
-  hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(grid_for(npix * (F / 8))), dim3(TPB), 0, ST(stream), (const half_t*)dh, h_cs,
-                     (const half_t*)z, z_cs, (half_t*)dz, npix, F);
+  hipLaunchKernelGGL((convlstm_gate_bwd_kernel<T>), dim3(grid_for(npix * (F / 8))), dim3(TPB), 0, ST(stream), (const T*)dh, h_cs,
+                     (const T*)z, z_cs, (T*)dz, npix, F);
   SEG_CHECK_LAUNCH("seg_convlstm_gate_bwd");
   return SEG_OK;
 }
+extern "C" int seg_convlstm_gate_bwd(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_bwd_impl<half_t>(dh, h_cs, z, z_cs, dz, npix, F, stream); }
+extern "C" int seg_convlstm_gate_bwd_f32(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_bwd_impl<float>(dh, h_cs, z, z_cs, dz, npix, F, stream); }
 
 static int head_lpp(int Cin) {
   int LPP = pow2ceil((Cin + 7) / 8);
   return LPP > 64 ? 64 : LPP;
 }
 
-extern "C" int seg_head_fwd(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w,
+template <typename T>
+static int seg_head_fwd_impl(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w,
                             int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) {
   SEG_CHECK_ARG(x && w && y && Cin > 0 && Cin <= cs && (cs & 7) == 0 && Cout >= 1 && Cout <= HEAD_MAXC && w_ld >= Cin && sy >= 1 && sx >= 1 &&
                     N > 0 && H > 0 && W > 0,
@@ -1224,13 +1289,16 @@ extern "C" int seg_head_fwd(const void* x, int32_t cs, int32_t Cin, int32_t N, i
   const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
   int64_t blocks = (npix + gpb - 1) / gpb;
   if (blocks > 4 * MAX_BLOCKS) blocks = 4 * MAX_BLOCKS;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), (const half_t*)x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout,
+  hipLaunchKernelGGL((head_fwd_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout,
                      act, y, LPP);
   SEG_CHECK_LAUNCH("seg_head_fwd");
   return SEG_OK;
 }
+extern "C" int seg_head_fwd(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) { return seg_head_fwd_impl<half_t>(x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout, act, y, stream); }
+extern "C" int seg_head_fwd_f32(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) { return seg_head_fwd_impl<float>(x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout, act, y, stream); }
 
-extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W,
+template <typename T>
+static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W,
                             int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate,
                             const float* gs_ptr, float* dw, float* db, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && y && x && w && Cin > 0 && Cin <= cs && (cs & 7) == 0 && Cout >= 1 && Cout <= HEAD_MAXC && w_ld >= Cin,
@@ -1240,19 +1308,21 @@ extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int3
     const int LPP = head_lpp(cs), gpb = TPB / LPP;
     int64_t blocks = (npix + gpb - 1) / gpb;
     if (blocks > 4 * MAX_BLOCKS) blocks = 4 * MAX_BLOCKS;
-    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), dy, y, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act,
-                       (half_t*)dx, accumulate, gs_ptr, LPP);
+    hipLaunchKernelGGL((head_bwd_dx_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), dy, y, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act,
+                       (T*)dx, accumulate, gs_ptr, LPP);
   }
   if (dw != nullptr) {
     int blocks = (int)((npix + 511) / 512);
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), dy, y, (const half_t*)x, cs, Cin, N, H, W, sy, sx, w_ld,
+    hipLaunchKernelGGL((head_bwd_dw_kernel<T>), dim3(blocks), dim3(TPB), 0, ST(stream), dy, y, (const T*)x, cs, Cin, N, H, W, sy, sx, w_ld,
                        Cout, act, dw, db, col_layout(((Cin + 7) / 8) * 8));
   }
   SEG_CHECK_LAUNCH("seg_head_bwd");
   return SEG_OK;
 }
+extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream) { return seg_head_bwd_impl<half_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, stream); }
+extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream) { return seg_head_bwd_impl<float>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, stream); }
 
 extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float* loss_out, float* dpred,
                                 seg_stream_t stream) {
@@ -1288,13 +1358,16 @@ extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void*
   return SEG_OK;
 }
 
-extern "C" int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad, seg_stream_t stream) {
-  SEG_CHECK_ARG(w && wt && rows > 0 && T > 0 && K > 0 && rows_pad >= rows, "seg_transpose_w: bad arguments");
-  hipLaunchKernelGGL(transpose_w_kernel, dim3(grid_for((int64_t)K * T * rows_pad)), dim3(TPB), 0, ST(stream), w, (half_t*)wt, rows, T, K,
+template <typename T>
+static int seg_transpose_w_impl(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) {
+  SEG_CHECK_ARG(w && wt && rows > 0 && Tn > 0 && K > 0 && rows_pad >= rows, "seg_transpose_w: bad arguments");
+  hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(grid_for((int64_t)K * Tn * rows_pad)), dim3(TPB), 0, ST(stream), w, (T*)wt, rows, Tn, K,
                      rows_pad);
   SEG_CHECK_LAUNCH("seg_transpose_w");
   return SEG_OK;
 }
+extern "C" int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<half_t>(w, wt, rows, Tn, K, rows_pad, stream); }
+extern "C" int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<float>(w, wt, rows, Tn, K, rows_pad, stream); }
 
 extern "C" int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && n > 0, "seg_cast_f32_f16: bad arguments");
@@ -1303,16 +1376,22 @@ extern "C" int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t
   return SEG_OK;
 }
 
-extern "C" int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) {
+template <typename T>
+static int seg_pack_input_impl(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && npix > 0 && C > 0 && C <= cs, "seg_pack_input: bad arguments");
-  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(npix * cs)), dim3(TPB), 0, ST(stream), x, (half_t*)y, npix, C, cs);
+  hipLaunchKernelGGL((pack_input_kernel<T>), dim3(grid_for(npix * cs)), dim3(TPB), 0, ST(stream), x, (T*)y, npix, C, cs);
   SEG_CHECK_LAUNCH("seg_pack_input");
   return SEG_OK;
 }
+extern "C" int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<half_t>(x, y, npix, C, cs, stream); }
+extern "C" int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<float>(x, y, npix, C, cs, stream); }
 
-extern "C" int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) {
+template <typename T>
+static int seg_unpack_f32_impl(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && npix > 0 && C > 0 && coff + C <= cs, "seg_unpack_f32: bad arguments");
-  hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(npix * C)), dim3(TPB), 0, ST(stream), (const half_t*)x, y, npix, C, cs, coff);
+  hipLaunchKernelGGL((unpack_kernel<T>), dim3(grid_for(npix * C)), dim3(TPB), 0, ST(stream), (const T*)x, y, npix, C, cs, coff);
   SEG_CHECK_LAUNCH("seg_unpack_f32");
   return SEG_OK;
 }
+extern "C" int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<half_t>(x, y, npix, C, cs, coff, stream); }
+extern "C" int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<float>(x, y, npix, C, cs, coff, stream); }

@@ -13,8 +13,59 @@
 
 namespace {
 
-constexpr int BK = 32;            // halves per K step
-constexpr int ROW_BYTES = 64;     // BK * 2
+constexpr int ROW_BYTES = 64;     // one LDS tile row = one K step = 4 chunks of 16 B (32 halves or 16 floats)
+template <typename T> struct ET;
+template <> struct ET<half_t> { static constexpr int EPC = 8; };   // elements per 16-B chunk
+template <> struct ET<float> { static constexpr int EPC = 4; };
+
+// One K step (64 B per row) of MFMAs for a (TM x TN) grid of 32x32 tiles.  A/B point at the rows of this wave's
+// tiles; lane (fr = lane & 31, fh = lane >> 5) reads row fr.  fp16: two v_mfma_f32_32x32x16_f16 (k = 8 fh + j);
+// fp32: eight v_mfma_f32_32x32x2_f32 - lane half fh owns k = 8 fh .. 8 fh + 7 of the 16-deep step and MFMA j
+// contracts the pair {j, 8 + j} (the sum over k is order-free as long as A and B use the same assignment).
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_step(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
+                                         f16v (&acc)[TM][TN]) {
+  const int fswz = (fr >> 2) & 3;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ((ks * 2 + fh) ^ fswz) << 4;
+      h8 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * ROW_BYTES + ch);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * ROW_BYTES + ch);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  } else {
+    const int c0 = ((2 * fh) ^ fswz) << 4, c1 = ((2 * fh + 1) ^ fswz) << 4;
+    f4 a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const unsigned char* r = A + (a_row0 + a * 32 + fr) * ROW_BYTES;
+      a0[a] = *reinterpret_cast<const f4*>(r + c0);
+      a1[a] = *reinterpret_cast<const f4*>(r + c1);
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const unsigned char* r = B + (b_row0 + b * 32 + fr) * ROW_BYTES;
+      b0[b] = *reinterpret_cast<const f4*>(r + c0);
+      b1[b] = *reinterpret_cast<const f4*>(r + c1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a][j], b0[b][j], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a][j], b1[b][j], acc[a][b], 0, 0, 0);
+        }
+  }
+}
 constexpr int STG_LD = 36;        // floats per staging row (32 + 4 pad, keeps 16-B alignment)
 constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;   // 4 waves
 
@@ -23,9 +74,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BY
 // ---------------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args p) {
   constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int EPC = ET<T>::EPC, BK = 4 * EPC;      // elements per 16-B chunk / per K step
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -78,15 +130,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
   for (int s = 0; s < p.nseg; ++s) niter += ((p.seg_c[s] + BK - 1) / BK) * g.ntaps;
 
   u4 ra[TM], rb[TN];
-  const half_t* wbase = (const half_t*)p.w;
+  const T* wbase = (const T*)p.w;
 
   auto gload = [&](int seg, int c0, int tap) {
-    const half_t* sp = (const half_t*)p.seg_ptr[seg];
+    const T* sp = (const T*)p.seg_ptr[seg];
     const int cs = p.seg_cs[seg];
     const int sc = p.seg_c[seg];
     const int e = cls * g.ntaps + tap;
     const int dy = g.tap_dy[e], dx = g.tap_dx[e], widx = g.tap_w[e];
-    const int cc = c0 + ld_ch * 8;
+    const int cc = c0 + ld_ch * EPC;
     const bool cok = cc < sc;
 #pragma unroll
     for (int r = 0; r < TM; ++r) {
@@ -97,7 +149,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
       if (ok) v = ld16(sp + off);
       ra[r] = v;
     }
-    const half_t* wp = wbase + (size_t)widx * p.Kpad + p.seg_woff[seg] + cc;
+    const T* wp = wbase + (size_t)widx * p.Kpad + p.seg_woff[seg] + cc;
 #pragma unroll
     for (int r = 0; r < TN; ++r) {
       u4 v = {0u, 0u, 0u, 0u};
@@ -114,29 +166,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
     for (int r = 0; r < TN; ++r) st16(B + lds_off(ld_row + 64 * r, ld_ch), rb[r]);
   };
   const int fr = lane & 31, fh = lane >> 5;
-  const int fswz = (fr >> 2) & 3;   // rows used by a wave are base(multiple of 32) + fr
   auto compute = [&](int buf) {
     const unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
-    const unsigned char* B = A + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ((ks * 2 + fh) ^ fswz) << 4;
-      h8 af[TM], bf[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        int row = wm * (BM / 2) + a * 32 + fr;
-        af[a] = *reinterpret_cast<const h8*>(A + row * ROW_BYTES + ch);
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        int row = wn * (BN / 2) + b * 32 + fr;
-        bf[b] = *reinterpret_cast<const h8*>(B + row * ROW_BYTES + ch);
-      }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
+    mma_step<T, TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
   };
 
   // ---- main loop: iteration order (segment, channel chunk, tap) with taps innermost
@@ -164,7 +196,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
   float* sst = reinterpret_cast<float*>(smem + STG_BYTES);   // [2 (wm)][BN][2]
   const float* bias = p.bias;
-  half_t* out = (half_t*)p.out;
+  T* out = (T*)p.out;
   const bool do_stats = p.stats != nullptr;
   float s_sum[TN], s_sq[TN];
 #pragma unroll
@@ -215,15 +247,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
         f4 v0 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8]);
         f4 v1 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8 + 4]);
         if (opix[ps] >= 0 && nn < p.n_rows) {
-          half_t* dst = out + (size_t)opix[ps] * p.out_cs + p.out_coff + nn;
+          T* dst = out + (size_t)opix[ps] * p.out_cs + p.out_coff + nn;
           float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           if (p.accumulate) {
             float o[8];
-            unpack8(ld16(dst), o);
+            load8(dst, o);
 #pragma unroll
             for (int t = 0; t < 8; ++t) f[t] += o[t];
           }
-          st16(dst, pack8(f));
+          store8(dst, f);
         }
       }
     }
@@ -258,15 +290,17 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
 // Both operands are "reduction-major" in memory, so their MFMA fragments are read with the hardware
 // transposing LDS read ds_read_b64_tr_b16 (VARIANT 0) or transposed while being stored to LDS (VARIANT 1).
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int VARIANT>
+template <typename T, int BM, int BN, int VARIANT>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
+  static_assert(sizeof(T) == 2 || VARIANT == 1, "the transposing LDS read exists for 16-bit elements only");
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int PK = 32;                           // pixels per step
+  constexpr int EPC = ET<T>::EPC;
+  constexpr int PK = 4 * EPC;                      // pixels per step (one 64-B LDS row in the transposed tile)
   // VARIANT 0 tiles: [32 pixels][BM halves] rows of BM*2 + 64 bytes
   constexpr int ZLD = BM * 2 + 64, ALD = BN * 2 + 64;
   constexpr int Z_BYTES = (VARIANT == 0) ? PK * ZLD : BM * ROW_BYTES;
   constexpr int A_BYTES = (VARIANT == 0) ? PK * ALD : BN * ROW_BYTES;
-  constexpr int ZCH = BM / 8, ACH = BN / 8;        // 16-B chunks per pixel row
+  constexpr int ZCH = BM / EPC, ACH = BN / EPC;    // 16-B chunks per pixel row
   constexpr int ZPT = (PK * ZCH) / 256, APT = (PK * ACH) / 256;   // chunks per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -293,8 +327,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
   const int oy = g.oy[cls], ox = g.ox[cls];
   const int r0 = rt * BM, k0 = kt * BN;
   const int sc = p.seg_c[seg], cs = p.seg_cs[seg];
-  const half_t* sp = (const half_t*)p.seg_ptr[seg];
-  const half_t* dz = (const half_t*)p.dz;
+  const T* sp = (const T*)p.seg_ptr[seg];
+  const T* dz = (const T*)p.dz;
 
   int per = (M + p.splitk - 1) / p.splitk;
   per = (per + PK - 1) / PK * PK;
@@ -338,7 +372,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
     for (int r = 0; r < ZPT; ++r) {
       u4 v = {0u, 0u, 0u, 0u};
       int m = pb + z_p[r];
-      int col = r0 + z_c[r] * 8;
+      int col = r0 + z_c[r] * EPC;
       if (m < pend && col < p.n_rows) {
         size_t off = (((size_t)zn[r] * g.Hout + (zi[r] * g.osy + oy)) * g.Wout + (zj[r] * g.osx + ox)) * p.dz_cs + p.dz_coff + col;
         v = ld16(dz + off);
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
     for (int r = 0; r < APT; ++r) {
       u4 v = {0u, 0u, 0u, 0u};
       int m = pb + a_p[r];
-      int col = k0 + a_c[r] * 8;
+      int col = k0 + a_c[r] * EPC;
       int y = ai[r] * g.isy + dy, x = aj[r] * g.isx + dx;
       if (m < pend && col < sc && (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win) {
         size_t off = (((size_t)an[r] * g.Hin + y) * g.Win + x) * cs + col;
@@ -369,25 +403,26 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
 #pragma unroll
       for (int r = 0; r < APT; ++r) st16(A + a_p[r] * ALD + a_c[r] * 16, ra[r]);
     } else {
-      // transposing store: LDS tile [channel row][32 pixels], same swizzled 64-B row format as the fwd kernel
+      // transposing store: LDS tile [channel row][PK pixels], same swizzled 64-B row format as the fwd kernel
+      typedef T tvec __attribute__((ext_vector_type(EPC)));
 #pragma unroll
       for (int r = 0; r < ZPT; ++r) {
-        h8 v = __builtin_bit_cast(h8, rz[r]);
+        tvec v = __builtin_bit_cast(tvec, rz[r]);
         int pp = z_p[r];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          int row = z_c[r] * 8 + t;
-          *reinterpret_cast<half_t*>(Z + lds_off(row, pp >> 3) + (pp & 7) * 2) = v[t];
+        for (int t = 0; t < EPC; ++t) {
+          int row = z_c[r] * EPC + t;
+          *reinterpret_cast<T*>(Z + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
         }
       }
 #pragma unroll
       for (int r = 0; r < APT; ++r) {
-        h8 v = __builtin_bit_cast(h8, ra[r]);
+        tvec v = __builtin_bit_cast(tvec, ra[r]);
         int pp = a_p[r];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          int row = a_c[r] * 8 + t;
-          *reinterpret_cast<half_t*>(A + lds_off(row, pp >> 3) + (pp & 7) * 2) = v[t];
+        for (int t = 0; t < EPC; ++t) {
+          int row = a_c[r] * EPC + t;
+          *reinterpret_cast<T*>(A + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
         }
       }
     }
@@ -398,12 +433,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
   auto compute = [&](int buf) {
     const unsigned char* Z = smem + buf * (Z_BYTES + A_BYTES);
     const unsigned char* A = Z + Z_BYTES;
+    if constexpr (VARIANT == 0) {
+      typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+      typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      h8 af[TM], bf[TN];
-      if constexpr (VARIANT == 0) {
-        typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
-        typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
+      for (int ks = 0; ks < 2; ++ks) {
+        h8 af[TM], bf[TN];
         const int krow = ks * 16 + 8 * (tg >> 1) + tq;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -423,18 +458,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
           h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
           bf[b] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
         }
-      } else {
-        const int fswz = (fr >> 2) & 3;
-        const int ch = ((ks * 2 + fh) ^ fswz) << 4;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const h8*>(Z + (wm * (BM / 2) + a * 32 + fr) * ROW_BYTES + ch);
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const h8*>(A + (wn * (BN / 2) + b * 32 + fr) * ROW_BYTES + ch);
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    } else {
+      mma_step<T, TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
     }
   };
 
@@ -515,7 +545,8 @@ bool check_segs(const Args& a, const char* who) {
 
 }  // namespace
 
-extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) {
+template <typename T>
+static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_fwd: null args");
   if (!check_geom(a->g, "seg_igemm_fwd") || !check_segs(*a, "seg_igemm_fwd")) return SEG_ERR_ARG;
   SEG_CHECK_ARG(a->w && a->out, "seg_igemm_fwd: null weight/output pointer");
@@ -534,15 +565,18 @@ extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   const int lds_epi = STG_BYTES + 2 * a->tile_n * 2 * 4;
   const size_t lds = (size_t)(lds_main > lds_epi ? lds_main : lds_epi);
   hipStream_t st = (hipStream_t)stream;
-  if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128>), grid, block, lds, st, *a);
-  else if (a->tile_m == 128 && a->tile_n == 64) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64>), grid, block, lds, st, *a);
-  else if (a->tile_m == 64 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<64, 128>), grid, block, lds, st, *a);
-  else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64>), grid, block, lds, st, *a);
+  if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 128>), grid, block, lds, st, *a);
+  else if (a->tile_m == 128 && a->tile_n == 64) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 64>), grid, block, lds, st, *a);
+  else if (a->tile_m == 64 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 128>), grid, block, lds, st, *a);
+  else hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 64>), grid, block, lds, st, *a);
   SEG_CHECK_LAUNCH("seg_igemm_fwd");
   return SEG_OK;
 }
+extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) { return igemm_fwd_launch<half_t>(a, stream); }
+extern "C" int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t stream) { return igemm_fwd_launch<float>(a, stream); }
 
-extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
+template <typename T>
+static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_wgrad: null args");
   if (!check_geom(a->g, "seg_igemm_wgrad") || !check_segs(*a, "seg_igemm_wgrad")) return SEG_ERR_ARG;
   SEG_CHECK_ARG(a->dz && a->dw, "seg_igemm_wgrad: null pointer");
@@ -554,17 +588,22 @@ extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t strea
                 "seg_igemm_wgrad: tile %dx%d", a->tile_m, a->tile_n);
   SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "seg_igemm_wgrad: splitk=%d", a->splitk);
   SEG_CHECK_ARG(a->variant == 0 || a->variant == 1, "seg_igemm_wgrad: variant=%d", a->variant);
+  const int variant = (sizeof(T) == 4) ? 1 : a->variant;      // fp32: transposing-store form only
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
   int ktiles = 0;
   for (int s = 0; s < a->nseg; ++s) ktiles += (a->seg_c[s] + a->tile_n - 1) / a->tile_n;
   dim3 grid((unsigned)(rtiles * ktiles), (unsigned)(a->g.ncls * a->g.ntaps), (unsigned)a->splitk), block(256, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const int bm = a->tile_m, bn = a->tile_n;
-  size_t lds = (a->variant == 0) ? (size_t)2 * 32 * ((bm * 2 + 64) + (bn * 2 + 64)) : (size_t)2 * (bm + bn) * ROW_BYTES;
-#define SEG_WG(BM_, BN_)                                                                                       \
-  do {                                                                                                         \
-    if (a->variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, 0>), grid, block, lds, st, *a);       \
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, 1>), grid, block, lds, st, *a);                       \
+  size_t lds = (variant == 0) ? (size_t)2 * 32 * ((bm * 2 + 64) + (bn * 2 + 64)) : (size_t)2 * (bm + bn) * ROW_BYTES;
+#define SEG_WG(BM_, BN_)                                                                                          \
+  do {                                                                                                            \
+    if constexpr (sizeof(T) == 2) {                                                                               \
+      if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 0>), grid, block, lds, st, *a);        \
+      else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                          \
+    }                                                                                                             \
   } while (0)
   if (bm == 128 && bn == 128) SEG_WG(128, 128);
   else if (bm == 128 && bn == 64) SEG_WG(128, 64);
@@ -574,3 +613,5 @@ extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t strea
   SEG_CHECK_LAUNCH("seg_igemm_wgrad");
   return SEG_OK;
 }
+extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream) { return igemm_wgrad_launch<half_t>(a, stream); }
+extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream) { return igemm_wgrad_launch<float>(a, stream); }

@@ -67,6 +67,22 @@ __device__ __forceinline__ u4 pack8(const float* f) {
   return __builtin_bit_cast(u4, h);
 }
 
+// storage-type generic 8-element vector access (8 x fp16 = 16 B, 8 x fp32 = 32 B)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float* f) { unpack8(ld16(p), f); }
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
+template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const float* f) { st16(p, pack8(f)); }
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
+  *reinterpret_cast<f4*>(p) = f4{f[0], f[1], f[2], f[3]};
+  *reinterpret_cast<f4*>(p + 4) = f4{f[4], f[5], f[6], f[7]};
+}
+// the value a stored element will have when read back (fp16 rounding / identity)
+template <typename T> __device__ __forceinline__ float stored(float v) { return (float)(T)v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

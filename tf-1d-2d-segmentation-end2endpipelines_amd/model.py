@@ -84,7 +84,14 @@ class KernelProfile:
         return {k: dict(launches=v[0], seconds=v[1], flops=v[2], bytes=v[3]) for k, v in agg.items()}
 
 
+class _Mode:
+    """Storage / MFMA operand type of the model currently executing: '' = fp16 (throughput mode), '_f32' = exact fp32."""
+    sfx = ""
+
+
 def call(name, *args, flops=0.0, nbytes=0.0, tag=""):
+    if name in _ffi.DUAL:
+        name = name + _Mode.sfx
     if _DryRun.on:
         _DryRun.log.append(name)
         return
@@ -271,11 +278,12 @@ def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], nentries):
 class DevTensor:
     """NHWC fp16 activation with channel stride cs (multiple of 8); pad channels are zero."""
     registry: Optional[Dict[str, "DevTensor"]] = None
+    dtype = torch.float16
 
     def __init__(self, name, N, H, W, Cl):
         self.name, self.N, self.H, self.W, self.C = name, N, H, W, Cl
         self.cs = _r8(Cl)
-        self.buf = torch.zeros((N, H, W, self.cs), dtype=torch.float16, device=_dev())
+        self.buf = torch.zeros((N, H, W, self.cs), dtype=DevTensor.dtype, device=_dev())
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = True
         self.gw = False          # "gradient written" flag used while the static backward schedule is built
@@ -453,7 +461,7 @@ class ConvOp(Op):
         pix_taps = self.N * self.g_fwd.Hl * self.g_fwd.Wl * self.g_fwd.ncls * self.g_fwd.ntaps
         self.flops_fwd = 2.0 * pix_taps * sum(cin_l) * self.cout
         self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
-        self.wt = torch.zeros(Kpad * T * self.rows_pad, dtype=torch.float16, device=dev) if any(self.need_dgrad) else None
+        self.wt = torch.zeros(Kpad * self.T * self.rows_pad, dtype=DevTensor.dtype, device=dev) if any(self.need_dgrad) else None
         self.fwd_args = None
 
     # -- argument blocks (built after the parameter store has been allocated)
@@ -464,7 +472,7 @@ class ConvOp(Op):
         a.nseg = len(self.segs)
         for s, (t, _c) in enumerate(self.segs):
             a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s] = t.cs, t.cs, self.woff[s], t.buf.data_ptr()
-        a.w = st.ptr(self.wname, "P16").value
+        a.w = st.ptr(self.wname, "P16" if self.m.dtype == "f16" else "P").value
         a.Kpad, a.n_rows, a.n_valid = self.Kpad, self.n_rows, self.cout
         a.out, a.out_cs, a.out_coff = self.z.buf.data_ptr(), self.z.cs, 0
         a.bias = st.ptr(self.bname, "P").value if self.bname else None
@@ -535,7 +543,7 @@ class ConvOp(Op):
             a.nseg = 1
             a.seg_c[0], a.seg_cs[0], a.seg_woff[0] = self.n_rows, self.z.cs, 0
             a.seg_ptr[0] = None     # dz pointer filled below
-            a.w = self.wt.data_ptr() + self.woff[s_i] * self.T * self.rows_pad * 2
+            a.w = self.wt.data_ptr() + self.woff[s_i] * self.T * self.rows_pad * self.wt.element_size()
             a.Kpad, a.n_rows, a.n_valid = self.rows_pad, t.cs, t.cs
             a.out, a.out_cs, a.out_coff = t.grad.data_ptr(), t.cs, 0
             a.bias, a.act, a.alpha, a.stats = None, 0, 0.0, None
@@ -772,8 +780,13 @@ class PoolOp(Op):
 
 # ------------------------------------------------------------------------------------------------ model
 class SegModel:
-    def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0):
+    def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0, dtype: str = "f16"):
+        """dtype: 'f16' = fp16 activations / MFMA operands with fp32 accumulation (throughput mode);
+        'f32' = everything fp32 on v_mfma_f32_32x32x2_f32 (exact parity mode, 1/16 of the MFMA rate)."""
+        if dtype not in ("f16", "f32"):
+            raise ValueError("dtype must be 'f16' or 'f32'")
         self.graph = graph
+        self.dtype = dtype
         self.seed = seed
         self.name = graph.name
         self.built = False
@@ -808,7 +821,16 @@ class SegModel:
         self.loss_name, self.lr, self.beta_1, self.beta_2, self.epsilon = loss, lr, beta_1, beta_2, epsilon
 
     # ---------------------------------------------------------------- build / lowering
-    def build(self, batch_size: int):
+    def _enter(self):
+        _Mode.sfx = "" if self.dtype == "f16" else "_f32"
+
+    def build(self, batch_size: int, dtype: Optional[str] = None):
+        if dtype is not None:
+            if dtype not in ("f16", "f32"):
+                raise ValueError("dtype must be 'f16' or 'f32'")
+            self.dtype = dtype
+        self._enter()
+        DevTensor.dtype = torch.float16 if self.dtype == "f16" else torch.float32
         if not _DryRun.on:
             if not torch.cuda.is_available():
                 raise RuntimeError("SegModel needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
@@ -958,6 +980,7 @@ class SegModel:
         for op in reversed(self.ops):
             op.plan_backward()
         DevTensor.registry = None
+        DevTensor.dtype = torch.float16
         self.built = True
         return self
 
@@ -1005,7 +1028,9 @@ class SegModel:
 
     def _refresh_copies(self):
         st = self.store
-        call("seg_cast_f32_f16", _p(st.P), _p(st.P16), st.P.numel(), _stream())
+        self._enter()
+        if self.dtype == "f16":
+            call("seg_cast_f32_f16", _p(st.P), _p(st.P16), st.P.numel(), _stream())
         for op in self.ops:
             op.post_step()
 
@@ -1025,6 +1050,7 @@ class SegModel:
         """x: (N,H,W,C) [2D] or (N,L,C) [1D] float32.  Returns [out, level1, ...] fp32 NHWC (views of internal buffers)."""
         training = self.training if training is None else training
         self._x = self._check_x(x)
+        self._enter()
         for op in self.ops:
             op.forward(training)
         outs = [h.y for h in self.out_heads]
@@ -1042,6 +1068,7 @@ class SegModel:
         """Backward pass.  grads[i] = dLoss/d output_i (fp32, same shape as the output); None: use the gradients the
         loss kernels left in the heads' dy buffers."""
         s = _stream()
+        self._enter()
         if grads is not None:
             for h, gt in zip(self.out_heads, grads):
                 h.dy.copy_(gt.reshape(h.dy.shape))
@@ -1068,11 +1095,12 @@ class SegModel:
 
     def optimizer_step(self):
         st = self.store
+        self._enter()
         if self.allreduce is not None:
             self.allreduce(st.G)
         self.adam_t += 1
         a_t = self.lr * math.sqrt(1.0 - self.beta_2 ** self.adam_t) / (1.0 - self.beta_1 ** self.adam_t)
-        call("seg_adam_step", _p(st.P), _p(st.G), _p(st.M), _p(st.V), _p(st.P16), st.P.numel(), a_t, self.beta_1, self.beta_2,
+        call("seg_adam_step", _p(st.P), _p(st.G), _p(st.M), _p(st.V), _p(st.P16) if self.dtype == "f16" else None, st.P.numel(), a_t, self.beta_1, self.beta_2,
              self.epsilon, 1.0 / self.world_size, _stream())
         for op in self.ops:
             op.post_step()
