@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch event timings of the profiled step to this JSON file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +168,10 @@ def main():
         model.train_step(x, targets)
         KP.on = False
         summ = KP.summary()
+        if args.dump_launches:
+            rows = [dict(kernel=n, tag=t, flops=f, ms=e0.elapsed_time(e1)) for n, t, f, _b, e0, e1 in KP.records]
+            with open(args.dump_launches, "w") as fh:
+                json.dump(rows, fh)
         gemm = {k: v for k, v in summ.items() if k in ("seg_igemm_fwd", "seg_igemm_wgrad")}
         dom = max(gemm, key=lambda k: gemm[k]["seconds"])
         d_ = gemm[dom]

@@ -73,6 +73,64 @@ def test_igemm_fwd_cases(case):
     assert rel(st[:, :case["cout"]], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-4
 
 
+@pytest.mark.parametrize("tile", [(128, 128), (256, 64)])
+@pytest.mark.parametrize("case", [
+    dict(shape=(2, 24, 20), cins=[64, 32, 64], cout=128, k=(3, 3), kind="conv", s=(1, 1)),      # 9 taps, concat, ragged M
+    dict(shape=(2, 16, 16), cins=[3], cout=64, k=(3, 3), kind="conv", s=(1, 1)),                 # channel padding via range check
+    dict(shape=(3, 13, 11), cins=[40], cout=24, k=(3, 3), kind="conv", s=(1, 1)),                # partial last chunk (40 = 32 + 8)
+    dict(shape=(2, 16, 16), cins=[64], cout=32, k=(1, 1), kind="conv", s=(2, 2)),                # 1 tap, strided
+    dict(shape=(4, 1, 160), cins=[16, 16], cout=16, k=(1, 3), kind="conv", s=(1, 1)),            # 3 taps (Conv1D)
+    dict(shape=(2, 12, 8), cins=[64], cout=32, k=(4, 4), kind="convT", s=(2, 2)),                # 4 classes x 4 taps
+    dict(shape=(4, 1, 96), cins=[32], cout=16, k=(1, 2), kind="convT", s=(1, 2)),                # 2 classes x 1 tap
+    dict(shape=(2, 8, 8), cins=[256], cout=160, k=(3, 3), kind="conv", s=(1, 1)),                # two N tiles, one ragged
+], ids=lambda c: f"{c['kind']}{c['k']}s{c['s']}-{c['cins']}->{c['cout']}")
+def test_igemm_fwd_lds_dma_pipeline(case, tile):
+    """The 3-stage LDS-DMA kernel (tiles 128x128 / 256x64) on every tap count it is instantiated for."""
+    N, H, W = case["shape"]
+    xs = [torch.randn(N, H, W, c) for c in case["cins"]]
+    cin = sum(case["cins"])
+    kshape = (*case["k"], case["cout"], cin) if case["kind"] == "convT" else (*case["k"], cin, case["cout"])
+    kern = rng.standard_normal(kshape).astype(np.float32) * 0.1
+    b = rng.standard_normal(case["cout"]).astype(np.float32)
+    out, st, pad = U.igemm_conv(xs, kern, b, case["kind"], case["s"], "relu", 0.0, True, tile)
+    pre = U.ref_conv(xs, kern, b, case["kind"], case["s"])
+    assert rel(out, torch.relu(pre)) < 2e-3
+    assert pad == 0.0
+    assert rel(st[:, :case["cout"]], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-4
+
+
+@pytest.mark.parametrize("kind,k,s", [("conv", (3, 3), (1, 1)), ("convT", (4, 4), (2, 2)), ("convT", (1, 2), (1, 2))])
+def test_dgrad_lds_dma_pipeline(kind, k, s):
+    """16-tap strided gather (transposed-conv data gradient) and the 9-/2-tap ones on the pipelined kernel."""
+    N, H, W, cin, cout = (2, 16, 16, 64, 96) if k[0] > 1 else (4, 1, 128, 64, 96)
+    x = h16(torch.randn(N, H, W, cin)).requires_grad_(True)
+    kshape = (*k, cout, cin) if kind == "convT" else (*k, cin, cout)
+    kern = h16(torch.from_numpy(rng.standard_normal(kshape).astype(np.float32) * 0.1))
+    y = (K.conv2d_transpose_same if kind == "convT" else K.conv2d_same)(x, kern, None, s)
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    M = U.M
+    n_rows, T, Kpad = U.r8(cout), k[0] * k[1], U.r32(U.r8(cin))
+    E = M.pack_gemm_weight(kern.numpy(), [cin], [0], n_rows, Kpad, kind == "convT")
+    rows_pad = U.r32(n_rows)
+    wt = torch.zeros(Kpad * T * rows_pad, dtype=torch.float16, device="cuda")
+    Ed = dev_f32(E.reshape(-1))
+    ffi.call("seg_transpose_w", P(Ed), P(wt), n_rows, T, Kpad, rows_pad, stream())
+    g = (M.geom_convT_dgrad if kind == "convT" else M.geom_conv_dgrad)(N, H, W, *k, *s)
+    dzd = to_dev_nhwc(dz)
+    for tile in [(256, 64), (128, 128)]:
+        dx = torch.zeros((N, H, W, cin), dtype=torch.float16, device="cuda")
+        a = ffi.IgemmFwdArgs()
+        a.g, a.nseg = g, 1
+        a.seg_c[0], a.seg_cs[0], a.seg_woff[0], a.seg_ptr[0] = n_rows, dzd.shape[3], 0, dzd.data_ptr()
+        a.w, a.Kpad, a.n_rows, a.n_valid = wt.data_ptr(), rows_pad, cin, cin
+        a.out, a.out_cs, a.out_coff = dx.data_ptr(), cin, 0
+        a.tile_m, a.tile_n = tile
+        ffi.call("seg_igemm_fwd", C.byref(a), stream())
+        torch.cuda.synchronize()
+        assert rel(from_dev(dx, cin), x.grad) < 2e-3, tile
+
+
 def test_igemm_fwd_accumulate():
     xs = [torch.randn(2, 16, 16, 32)]
     kern = rng.standard_normal((3, 3, 32, 64)).astype(np.float32) * 0.1

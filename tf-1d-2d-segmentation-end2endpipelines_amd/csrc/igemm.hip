@@ -10,6 +10,8 @@
 // ds_read_b128 16-lane group touches 16 distinct bank quads.  The epilogue stages each 32x32 accumulator
 // tile through a per-wave LDS slab so that global stores are 16 B per lane along the channel axis.
 #include "seg_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -70,6 +72,108 @@ constexpr int STG_LD = 36;        // floats per staging row (32 + 4 pad, keeps 1
 constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;   // 4 waves
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// ---------------------------------------------------------------------------------------------------------
+// shared epilogue of the forward kernels: bias, BN partial statistics, activation, channel-padding mask, then each
+// 32x32 accumulator tile goes through a per-wave LDS slab so that global stores are 8 channels (16 / 32 B) per lane.
+// row0 = first logical pixel of this wave's rows, col0 = first column of this wave inside the block's BN columns.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int TM, int TN, int NWM, int BN>
+__device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v (&acc)[TM][TN], unsigned char* smem, int tid, int row0,
+                                              int col0, int n0, int wm, int cls, int mblocks, int mb, int M, int HW) {
+  const seg_geom& g = p.g;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
+  float* sst = reinterpret_cast<float*>(smem + STG_BYTES);   // [NWM][BN][2]
+  const float* bias = p.bias;
+  T* out = (T*)p.out;
+  const bool do_stats = p.stats != nullptr;
+  float s_sum[TN], s_sq[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) { s_sum[b] = 0.f; s_sq[b] = 0.f; }
+  // rows this lane stores: (lane >> 2) + 16 * pass within each 32-row tile, 8 channels (lane & 3) * 8 ..
+  const int st_row = lane >> 2, st_ch = lane & 3;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    long opix[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      int m = row0 + a * 32 + st_row + 16 * ps;
+      if (m < M) {
+        int n = m / HW;
+        int rem = m - n * HW;
+        int i = rem / g.Wl;
+        int j = rem - i * g.Wl;
+        opix[ps] = ((long)n * g.Hout + (i * g.osy + g.oy[cls])) * g.Wout + (j * g.osx + g.ox[cls]);
+      } else {
+        opix[ps] = -1;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int nbase = n0 + col0 + b * 32;
+      const int ncol = nbase + fr;
+      float bv = 0.f;
+      if (bias != nullptr && ncol < p.n_rows) bv = bias[ncol];
+      const bool nzero = ncol >= p.n_valid;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rt = (q & 3) + 8 * (q >> 2) + 4 * fh;
+        float v = acc[a][b][q] + bv;
+        if (do_stats) {
+          const int m = row0 + a * 32 + rt;
+          if (m < M) { s_sum[b] += v; s_sq[b] += v * v; }
+        }
+        v = seg_act(v, p.act, p.alpha);
+        if (nzero) v = 0.f;
+        stg[rt * STG_LD + fr] = v;
+      }
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int rt = st_row + 16 * ps;
+        const int nn = nbase + st_ch * 8;
+        f4 v0 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8]);
+        f4 v1 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8 + 4]);
+        if (opix[ps] >= 0 && nn < p.n_rows) {
+          T* dst = out + (size_t)opix[ps] * p.out_cs + p.out_coff + nn;
+          float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if (p.accumulate) {
+            float o[8];
+            load8(dst, o);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) f[t] += o[t];
+          }
+          store8(dst, f);
+        }
+      }
+    }
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      float s = s_sum[b] + __shfl_xor(s_sum[b], 32);
+      float q = s_sq[b] + __shfl_xor(s_sq[b], 32);
+      if (fh == 0) {
+        int col = col0 + b * 32 + fr;
+        sst[(wm * BN + col) * 2 + 0] = s;
+        sst[(wm * BN + col) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      int ncol = n0 + tid;
+      if (ncol < p.n_rows) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) { s += sst[(w * BN + tid) * 2 + 0]; q += sst[(w * BN + tid) * 2 + 1]; }
+        size_t part = (size_t)cls * mblocks + mb;
+        p.stats[(part * 2 + 0) * p.n_rows + ncol] = s;
+        p.stats[(part * 2 + 1) * p.n_rows + ncol] = q;
+      }
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // forward / dgrad
@@ -192,98 +296,208 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
     __syncthreads();
   }
 
-  // ---- epilogue
-  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
-  float* sst = reinterpret_cast<float*>(smem + STG_BYTES);   // [2 (wm)][BN][2]
-  const float* bias = p.bias;
-  T* out = (T*)p.out;
-  const bool do_stats = p.stats != nullptr;
-  float s_sum[TN], s_sq[TN];
-#pragma unroll
-  for (int b = 0; b < TN; ++b) { s_sum[b] = 0.f; s_sq[b] = 0.f; }
+  conv_epilogue<T, TM, TN, 2, BN>(p, acc, smem, tid, m0 + wm * (BM / 2), wn * (BN / 2), n0, wm, cls, mblocks, mb, M, HW);
+}
 
-  // output pixel offsets of the rows this lane stores: row = (lane >> 2) + 16 * pass within each 32-row tile
-  const int st_row = lane >> 2, st_ch = lane & 3;
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    long opix[2];
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      int m = m0 + wm * (BM / 2) + a * 32 + st_row + 16 * ps;
-      if (m < M) {
-        int n = m / HW;
-        int rem = m - n * HW;
-        int i = rem / g.Wl;
-        int j = rem - i * g.Wl;
-        opix[ps] = ((long)n * g.Hout + (i * g.osy + g.oy[cls])) * g.Wout + (j * g.osx + g.ox[cls]);
-      } else {
-        opix[ps] = -1;
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int nbase = n0 + wn * (BN / 2) + b * 32;
-      const int ncol = nbase + fr;
-      float bv = 0.f;
-      if (bias != nullptr && ncol < p.n_rows) bv = bias[ncol];
-      const bool nzero = ncol >= p.n_valid;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int rt = (q & 3) + 8 * (q >> 2) + 4 * fh;
-        float v = acc[a][b][q] + bv;
-        if (do_stats) {
-          const int m = m0 + wm * (BM / 2) + a * 32 + rt;
-          if (m < M) { s_sum[b] += v; s_sq[b] += v * v; }
-        }
-        v = seg_act(v, p.act, p.alpha);
-        if (nzero) v = 0.f;
-        stg[rt * STG_LD + fr] = v;
-      }
-      // read back: lane -> (row, 8 consecutive channels)
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        const int rt = st_row + 16 * ps;
-        const int nn = nbase + st_ch * 8;
-        f4 v0 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8]);
-        f4 v1 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8 + 4]);
-        if (opix[ps] >= 0 && nn < p.n_rows) {
-          T* dst = out + (size_t)opix[ps] * p.out_cs + p.out_coff + nn;
-          float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if (p.accumulate) {
-            float o[8];
-            load8(dst, o);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) f[t] += o[t];
-          }
-          store8(dst, f);
-        }
-      }
-    }
-  }
-  if (do_stats) {
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      float s = s_sum[b] + __shfl_xor(s_sum[b], 32);
-      float q = s_sq[b] + __shfl_xor(s_sq[b], 32);
-      if (fh == 0) {
-        int col = wn * (BN / 2) + b * 32 + fr;
-        sst[(wm * BN + col) * 2 + 0] = s;
-        sst[(wm * BN + col) * 2 + 1] = q;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      int ncol = n0 + tid;
-      if (ncol < p.n_rows) {
-        float s = sst[(0 * BN + tid) * 2 + 0] + sst[(1 * BN + tid) * 2 + 0];
-        float q = sst[(0 * BN + tid) * 2 + 1] + sst[(1 * BN + tid) * 2 + 1];
-        size_t part = (size_t)cls * mblocks + mb;
-        p.stats[(part * 2 + 0) * p.n_rows + ncol] = s;
-        p.stats[(part * 2 + 1) * p.n_rows + ncol] = q;
-      }
-    }
+// ---------------------------------------------------------------------------------------------------------
+// forward / dgrad, v2 (fp16): LDS-DMA staging (buffer_load_dwordx4 ... lds) into a 3-stage LDS ring, counted
+// vmcnt + raw s_barrier (one barrier per K step, two steps of loads always in flight), kernel taps unrolled at
+// compile time so that per-step address work is one scalar multiply per operand and two VALU ops per LDS-DMA
+// (tap mask select + add).  Out-of-image taps, rows past M and channel padding use the buffer range check:
+// an offset beyond num_records makes the hardware write zeros.  Tiles: 128x128 (2x2 waves) and 256x64 (4x1
+// waves), every wave owns a 64x64 accumulator block.
+// ---------------------------------------------------------------------------------------------------------
+constexpr unsigned OOB_OFF = 0x60000000u;   // beyond any legal byte offset (operands are checked to be < 1 GiB)
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
 }
+
+template <int AL>
+struct ChunkDesc {      // one (segment, 32-channel chunk) of the K loop
+  const void* ptr;      // segment base
+  int bytes;            // segment size
+  int cs2;              // bytes per pixel
+  int wsoff;            // byte offset of this chunk inside a weight row's K axis
+  int seg, c0;
+  bool valid;
+  unsigned vbase[AL];   // per-lane byte offset of (centre pixel, this lane's 16-B chunk), OOB_OFF when masked
+};
+
+template <int BM, int BN, int NT>
+__global__ __launch_bounds__(256) void igemm_fwd2_kernel(const seg_igemm_fwd_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type only exists for the gfx950 pass; the host pass needs just the stub
+  constexpr int WMv = BM / 64, WNv = BN / 64;
+  static_assert(WMv * WNv == 4, "four waves, 64x64 each");
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+  constexpr int AL = BM / 64, BL = BN / 64;      // 16-row LDS-DMA instructions per wave and stage
+  constexpr int LPI = AL + BL;                   // vector-memory operations per wave and K step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNv, wn = wave % WNv;
+  const int cls = blockIdx.y;
+  const seg_geom& g = p.g;
+  const int HW = g.Hl * g.Wl;
+  const int M = g.N * HW;
+  const int mblocks = (M + BM - 1) / BM;
+  const int mb = blockIdx.x % mblocks, nb = blockIdx.x / mblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+
+  int t_delta[NT], t_w[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int e = cls * NT + t;
+    t_delta[t] = g.tap_dy[e] * g.Win + g.tap_dx[e];
+    t_w[t] = g.tap_w[e] * p.Kpad * 2;
+  }
+
+  // ---- per-lane rows of the A tile: wave w, instruction i covers rows (w*AL + i)*16 .. +15, lane -> (row, chunk)
+  const int lrow = lane >> 2, lch = lane & 3;
+  int a_pix[AL], a_chs[AL];
+  unsigned a_mask[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int row = (wave * AL + i) * 16 + lrow;
+    const int m = m0 + row;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int n = mm / HW;
+    const int rem = mm - n * HW;
+    const int ii = rem / g.Wl;
+    const int jj = rem - ii * g.Wl;
+    const int cy = ii * g.isy, cx = jj * g.isx;
+    a_pix[i] = (n * g.Hin + cy) * g.Win + cx;
+    a_chs[i] = lch ^ ((row >> 2) & 3);
+    unsigned msk = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int e = cls * NT + t;
+      const int y = cy + g.tap_dy[e], x = cx + g.tap_dx[e];
+      if (ok && (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win) msk |= 1u << t;
+    }
+    a_mask[i] = msk;
+  }
+  unsigned b_voff[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int row = (wave * BL + i) * 16 + lrow;
+    const int nrow = n0 + row;
+    const int chs = lch ^ ((row >> 2) & 3);
+    b_voff[i] = nrow < p.n_rows ? (unsigned)((nrow * g.T_total * p.Kpad + chs * 8) * 2) : OOB_OFF;
+  }
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.n_rows * g.T_total * p.Kpad * 2, 0x00020000);
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  int nchunks = 0;
+  for (int s = 0; s < p.nseg; ++s) nchunks += (p.seg_c[s] + 31) / 32;
+  const int niter = nchunks * NT;
+  const int pixbytes = g.N * g.Hin * g.Win;
+
+  auto setup = [&](ChunkDesc<AL>& d, int seg, int c0) {
+    d.seg = seg;
+    d.c0 = c0;
+    d.valid = seg < p.nseg;
+    if (d.valid) {
+      const int cs = p.seg_cs[seg], sc = p.seg_c[seg];
+      d.ptr = p.seg_ptr[seg];
+      d.cs2 = cs * 2;
+      d.bytes = pixbytes * d.cs2;
+      d.wsoff = (p.seg_woff[seg] + c0) * 2;
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int cc = c0 + a_chs[i] * 8;
+        d.vbase[i] = cc < sc ? (unsigned)(a_pix[i] * d.cs2 + cc * 2) : OOB_OFF;
+      }
+    }
+  };
+  auto advance = [&](int& seg, int& c0) {
+    c0 += 32;
+    if (seg < p.nseg && c0 >= p.seg_c[seg]) { c0 = 0; ++seg; }
+  };
+  auto issue = [&](auto tc, const ChunkDesc<AL>& d, int stage) {
+    constexpr int t = decltype(tc)::value;
+    if (!d.valid) return;
+    unsigned char* sb = smem + stage * STAGE;
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.ptr), 0, d.bytes, 0x00020000);
+    const int sdelta = t_delta[t] * d.cs2;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const unsigned voff = ((a_mask[i] >> t) & 1u) ? d.vbase[i] + (unsigned)sdelta : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (wave * AL + i) * 1024), 16, voff, 0, 0, 0);
+    }
+    const int soff = t_w[t] + d.wsoff;
+#pragma unroll
+    for (int i = 0; i < BL; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + A_BYTES + (wave * BL + i) * 1024), 16, b_voff[i], soff, 0, 0);
+  };
+
+  ChunkDesc<AL> D[3];
+  int cseg = 0, cc0 = 0;
+  setup(D[0], cseg, cc0);
+  advance(cseg, cc0);
+  setup(D[1], cseg, cc0);
+  advance(cseg, cc0);
+  setup(D[2], cseg, cc0);
+
+  // prologue: K steps 0 and 1
+  issue(std::integral_constant<int, 0>{}, D[0], 0);
+  issue(std::integral_constant<int, 1 % NT>{}, D[1 / NT], 1);
+
+  const int fr = lane & 31, fh = lane >> 5;
+  int it = 0, stage = 0;
+  for (int ck = 0; ck < nchunks; ++ck) {
+    static_for<0, NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int t2 = (t + 2) % NT, k2 = (t + 2) / NT;
+      if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int st2 = stage + 2;
+      if (st2 >= 3) st2 -= 3;
+      issue(std::integral_constant<int, t2>{}, D[k2], st2);
+      const unsigned char* A = smem + stage * STAGE;
+      mma_step<half_t, 2, 2>(A, A + A_BYTES, wm * 64, wn * 64, fr, fh, acc);
+      stage = stage == 2 ? 0 : stage + 1;
+      ++it;
+    });
+    D[0] = D[1];
+    D[1] = D[2];
+    advance(cseg, cc0);
+    setup(D[2], cseg, cc0);
+  }
+  __syncthreads();
+  conv_epilogue<half_t, 2, 2, WMv, BN>(p, acc, smem, tid, m0 + wm * 64, wn * 64, n0, wm, cls, mblocks, mb, M, HW);
+#endif
+}
+
+// explicit instantiations (the launchers below live outside this namespace)
+template __global__ void igemm_fwd2_kernel<128, 128, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 4>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 9>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 16>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 4>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 9>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 16>(const seg_igemm_fwd_args);
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient:  D[n][k] = sum_pix dz[pix][n] * in[pix + tap][k]   (reduction dimension = pixels)
@@ -545,6 +759,42 @@ bool check_segs(const Args& a, const char* who) {
 
 }  // namespace
 
+// ---- v2 (LDS-DMA) dispatch
+static bool fwd2_eligible(const seg_igemm_fwd_args& a) {
+  static const bool force_v1 = std::getenv("SEG_IGEMM_V1") != nullptr;
+  if (force_v1) return false;
+  if (!((a.tile_m == 128 && a.tile_n == 128) || (a.tile_m == 256 && a.tile_n == 64))) return false;
+  const int nt = a.g.ntaps;
+  if (!(nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 9 || nt == 16)) return false;
+  const long lim = 1L << 30;
+  const long pix = (long)a.g.N * a.g.Hin * a.g.Win;
+  for (int s = 0; s < a.nseg; ++s)
+    if (pix * a.seg_cs[s] * 2 >= lim) return false;
+  if ((long)a.n_rows * a.g.T_total * a.Kpad * 2 >= lim) return false;
+  return true;
+}
+
+template <int BM, int BN>
+static void launch_fwd2_nt(const seg_igemm_fwd_args& a, dim3 grid, size_t lds, hipStream_t st) {
+  switch (a.g.ntaps) {
+    case 1: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 1>), grid, dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 2>), grid, dim3(256), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 3>), grid, dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 4>), grid, dim3(256), lds, st, a); break;
+    case 9: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 9>), grid, dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 16>), grid, dim3(256), lds, st, a); break;
+  }
+}
+
+static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hipStream_t st) {
+  dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a.g.ncls, 1);
+  const size_t lds = (size_t)3 * (a.tile_m + a.tile_n) * ROW_BYTES;      // >= epilogue staging
+  if (a.tile_m == 128) launch_fwd2_nt<128, 128>(a, grid, lds, st);
+  else launch_fwd2_nt<256, 64>(a, grid, lds, st);
+  SEG_CHECK_LAUNCH("seg_igemm_fwd (LDS-DMA)");
+  return SEG_OK;
+}
+
 template <typename T>
 static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_fwd: null args");
@@ -554,7 +804,7 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
                     a->out_coff + a->n_rows <= a->out_cs,
                 "seg_igemm_fwd: n_rows=%d out_cs=%d out_coff=%d", a->n_rows, a->out_cs, a->out_coff);
   SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_fwd: Kpad=%d not a multiple of 32", a->Kpad);
-  SEG_CHECK_ARG((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64),
+  SEG_CHECK_ARG((a->tile_m == 256 && a->tile_n == 64) || ((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64)),
                 "seg_igemm_fwd: tile %dx%d", a->tile_m, a->tile_n);
   SEG_CHECK_ARG(a->act >= SEG_ACT_NONE && a->act <= SEG_ACT_SIGMOID, "seg_igemm_fwd: act=%d", a->act);
   const long M = (long)a->g.N * a->g.Hl * a->g.Wl;
@@ -565,6 +815,10 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   const int lds_epi = STG_BYTES + 2 * a->tile_n * 2 * 4;
   const size_t lds = (size_t)(lds_main > lds_epi ? lds_main : lds_epi);
   hipStream_t st = (hipStream_t)stream;
+  if constexpr (sizeof(T) == 2) {
+    if (fwd2_eligible(*a)) return launch_fwd2(*a, mblocks, nblocks, st);
+  }
+  SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (fp16, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
   if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 128>), grid, block, lds, st, *a);
   else if (a->tile_m == 128 && a->tile_n == 64) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 64>), grid, block, lds, st, *a);
   else if (a->tile_m == 64 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 128>), grid, block, lds, st, *a);

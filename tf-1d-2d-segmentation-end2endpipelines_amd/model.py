@@ -256,6 +256,10 @@ def unpack_gemm_weight(flat: np.ndarray, shape, cin_l, woff, n_rows, Kpad, trans
 
 
 def pick_tile_fwd(M, n_rows, ncls):
+    """(tile_m, tile_n).  256x64 and 128x128 run on the LDS-DMA pipelined kernel (fp16); the 64-row tiles are the
+    register-staged kernel and keep >= 2 blocks per CU busy on the small deep layers."""
+    if n_rows <= 64 and ncls * _cdiv(M, 256) >= 512:
+        return 256, 64
     tn = 128 if n_rows > 64 else 64
     tm = 128
     blocks = lambda: ncls * _cdiv(M, tm) * _cdiv(n_rows, tn)
@@ -507,7 +511,7 @@ class ConvOp(Op):
     def forward(self, training):
         st, s = self.m.store, _stream()
         a = self.fwd_args if (training and self.has_bn) else self.fwd_args_eval
-        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, tag="fwd")
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, tag="fwd:" + self.node.name)
         if self.has_bn:
             bn = self.bn_name
             call("seg_bn_finalize", _p(self.stats), self.nparts, self.n_rows, self.z.npix, st.ptr(bn + "/gamma"),
@@ -585,9 +589,9 @@ class ConvOp(Op):
             if self.strided and not acc:
                 t.grad.zero_()
             a.seg_ptr[0] = dz.data_ptr()
-            call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad")
+            call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad:" + self.node.name + ">" + t.name)
         self.wg_args.dz = dz.data_ptr()
-        call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad")
+        call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
 
 
 def _pad_to(n):
