@@ -77,15 +77,13 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const T* x, int64_t npix,
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
   const int part = blockIdx.x;
-  int64_t per = (npix + nparts - 1) / nparts;
-  const int64_t p0 = part * per, p1 = min(npix, p0 + per);
   for (int grp = 0; grp < L.ngrp; ++grp) {
     const int ch = grp * L.CHP + col;
     float acc[2][8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
     if (ch < L.CH) {
-      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
+      for (int64_t pix = (int64_t)part * L.RP + rowi; pix < npix; pix += (int64_t)L.RP * nparts) {   // interleaved rows
         float f[8];
         load8(x + pix * cs + coff + ch * 8, f);
 #pragma unroll
@@ -169,24 +167,47 @@ __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* stats, in
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply (+pool)
+// Streaming kernels below process UNR items per thread and iteration with every load issued before the first
+// store (the output may alias an input element-for-element, so the compiler cannot hoist loads across stores on
+// its own), and keep the per-channel coefficients in registers whenever a thread's channel chunk is loop-invariant
+// (grid stride a multiple of the chunks per pixel - always true for power-of-two channel counts).
+constexpr int UNR = 4;
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs, int x_coff, T* y, int y_cs, int y_coff,
                                                            int64_t npix, int C, int c_valid, const float* scale, const float* shift,
                                                            int act, float alpha) {
   const int CH = C / 8;
-  const int64_t items = npix * CH;
-  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
-    const int64_t pix = it / CH;
-    const int ch = (int)(it - pix * CH);
-    float f[8];
-    load8(x + pix * x_cs + x_coff + ch * 8, f);
+  const int64_t items = npix * CH, stride = (int64_t)gridDim.x * TPB;
+  const int64_t it0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const bool fixed = (stride % CH) == 0;
+  const int chf = (int)(it0 % CH);
+  float sc[8], sh[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int c = ch * 8 + t;
-      float v = seg_act(f[t] * scale[c] + shift[c], act, alpha);
-      f[t] = c < c_valid ? v : 0.f;
+  for (int t = 0; t < 8; ++t) { sc[t] = scale[chf * 8 + t]; sh[t] = shift[chf * 8 + t]; }
+  for (int64_t it = it0; it < items; it += stride * UNR) {
+    float f[UNR][8];
+    int64_t pix[UNR];
+    int ch[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t idx = it + u * stride;
+      pix[u] = idx / CH;
+      ch[u] = fixed ? chf : (int)(idx - pix[u] * CH);
+      if (idx < items) load8(x + pix[u] * x_cs + x_coff + ch[u] * 8, f[u]);
     }
-    store8(y + pix * y_cs + y_coff + ch * 8, f);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (it + u * stride >= items) continue;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c = ch[u] * 8 + t;
+        const float a_ = fixed ? sc[t] : scale[c], b_ = fixed ? sh[t] : shift[c];
+        const float v = seg_act(f[u][t] * a_ + b_, act, alpha);
+        f[u][t] = c < c_valid ? v : 0.f;
+      }
+      store8(y + pix[u] * y_cs + y_coff + ch[u] * 8, f[u]);
+    }
   }
 }
 
@@ -241,8 +262,6 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
   const int part = blockIdx.x;
-  const int64_t per = (npix + nparts - 1) / nparts;
-  const int64_t p0 = part * per, p1 = min(npix, p0 + per);
   for (int grp = 0; grp < L.ngrp; ++grp) {
     const int ch = grp * L.CHP + col;
     float acc[2][8];
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int
         const int c = ch * 8 + t;
         sc[t] = scale[c]; sh[t] = shift[c]; mu[t] = mean[c]; is[t] = invstd[c];
       }
-      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
+      for (int64_t pix = (int64_t)part * L.RP + rowi; pix < npix; pix += (int64_t)L.RP * nparts) {   // interleaved rows
         float g[8], xv[8];
         load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
         load8(x + pix * x_cs + x_coff + ch * 8, xv);
@@ -302,30 +321,58 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
                                                                const float* invstd, const float* c1, const float* c2, int act,
                                                                float alpha, int accumulate) {
   const int CH = C / 8;
-  const int64_t items = npix * CH;
-  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
-    const int64_t pix = it / CH;
-    const int ch = (int)(it - pix * CH);
-    float g[8], xv[8], o[8];
-    load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
-    load8(x + pix * x_cs + x_coff + ch * 8, xv);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int c = ch * 8 + t;
-      const float sc = scale[c];
-      const float yv = seg_act(xv[t] * sc + shift[c], act, alpha);
-      float gg = g[t] * seg_act_grad_from_out(yv, act, alpha);
-      if (c1 != nullptr) gg = gg - c1[c] - (xv[t] - mean[c]) * invstd[c] * c2[c];
-      o[t] = gg * sc;
+  const int64_t items = npix * CH, stride = (int64_t)gridDim.x * TPB;
+  const int64_t it0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const bool fixed = (stride % CH) == 0;
+  const int chf = (int)(it0 % CH);
+  const bool train = c1 != nullptr;
+  // dx = sc * (g - c1 - (x - mu) * is * c2) = g * sc + x * ka + kb   with ka = -sc*is*c2, kb = sc*(mu*is*c2 - c1)
+  float sc[8], sh[8], ka[8], kb[8];
+  auto coef = [&](int c, float& s_, float& h_, float& a_, float& b_) {
+    s_ = scale[c];
+    h_ = shift[c];
+    if (train) {
+      const float k = invstd[c] * c2[c];
+      a_ = -s_ * k;
+      b_ = s_ * (mean[c] * k - c1[c]);
+    } else {
+      a_ = 0.f;
+      b_ = 0.f;
     }
-    T* dst = dx + pix * dx_cs + dx_coff + ch * 8;
-    if (accumulate) {
-      float old[8];
-      load8(dst, old);
+  };
 #pragma unroll
-      for (int t = 0; t < 8; ++t) o[t] += old[t];
+  for (int t = 0; t < 8; ++t) coef(chf * 8 + t, sc[t], sh[t], ka[t], kb[t]);
+  for (int64_t it = it0; it < items; it += stride * UNR) {
+    float g[UNR][8], xv[UNR][8], old[UNR][8];
+    int64_t pix[UNR];
+    int ch[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t idx = it + u * stride;
+      pix[u] = idx / CH;
+      ch[u] = fixed ? chf : (int)(idx - pix[u] * CH);
+      if (idx < items) {
+        load8(dy + pix[u] * dy_cs + dy_coff + ch[u] * 8, g[u]);
+        load8(x + pix[u] * x_cs + x_coff + ch[u] * 8, xv[u]);
+        if (accumulate) load8(dx + pix[u] * dx_cs + dx_coff + ch[u] * 8, old[u]);
+      }
     }
-    store8(dst, o);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (it + u * stride >= items) continue;
+      float o[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float s_, h_, a_, b_;
+        if (fixed) { s_ = sc[t]; h_ = sh[t]; a_ = ka[t]; b_ = kb[t]; }
+        else coef(ch[u] * 8 + t, s_, h_, a_, b_);
+        const float yv = seg_act(xv[u][t] * s_ + h_, act, alpha);
+        const float gg = g[u][t] * seg_act_grad_from_out(yv, act, alpha);
+        o[t] = train ? gg * s_ + xv[u][t] * a_ + b_ : gg * s_;
+        if (accumulate) o[t] += old[u][t];
+      }
+      store8(dx + pix[u] * dx_cs + dx_coff + ch[u] * 8, o);
+    }
   }
 }
 
@@ -336,8 +383,10 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(const T* dy, const T* y, T
                                                       ColLayout L) {
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
-  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  // blocks walk the tensor in interleaved chunks of RP*UNR pixels, so concurrently running blocks stream
+  // neighbouring addresses (DRAM page locality) instead of 1000+ far-apart private ranges
+  const int64_t p1 = npix;
+  const int64_t chunk = (int64_t)L.RP * UNR;
   float gs = gscale;
   if (gscale_ptr) gs *= *gscale_ptr;
   for (int grp = 0; grp < L.ngrp; ++grp) {
@@ -346,16 +395,27 @@ __global__ __launch_bounds__(TPB) void act_bwd_kernel(const T* dy, const T* y, T
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[0][t] = 0.f;
     if (ch < L.CH) {
-      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
-        float g[8], yv[8];
-        load8(dy + pix * cs + ch * 8, g);
-        load8(y + pix * cs + ch * 8, yv);
+      for (int64_t pb = blockIdx.x * chunk + rowi; pb < p1; pb += chunk * gridDim.x) {
+        float g[UNR][8], yv[UNR][8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          g[t] *= seg_act_grad_from_out(yv[t], act, alpha);
-          acc[0][t] += g[t];
+        for (int u = 0; u < UNR; ++u) {
+          const int64_t pix = pb + (int64_t)u * L.RP;
+          if (pix < p1) {
+            load8(dy + pix * cs + ch * 8, g[u]);
+            load8(y + pix * cs + ch * 8, yv[u]);
+          }
         }
-        store8(dx + pix * cs + ch * 8, g);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int64_t pix = pb + (int64_t)u * L.RP;
+          if (pix >= p1) continue;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            g[u][t] *= seg_act_grad_from_out(yv[u][t], act, alpha);
+            acc[0][t] += g[u][t];
+          }
+          store8(dx + pix * cs + ch * 8, g[u]);
+        }
       }
     }
     if (dbias != nullptr) {
@@ -704,7 +764,7 @@ __global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const T* dh, int
 // ------------------------------------------------------------------------------------------------ 1x1 heads (Cout <= 8)
 constexpr int HEAD_MAXC = 8;
 
-template <typename T>
+template <typename T, int CO>
 __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int Cin, int N, int H, int W, int sy, int sx,
                                                        const float* w, int w_ld, const float* b, int Cout, int act, float* y, int LPP) {
   const int CH = (Cin + 7) / 8;
@@ -712,74 +772,108 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int C
   const int64_t npix = (int64_t)N * HO * WO;
   const int gpb = TPB / LPP;
   const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
-  for (int64_t pix0 = (int64_t)blockIdx.x * gpb; pix0 < npix; pix0 += (int64_t)gridDim.x * gpb) {
-    const int64_t pix = pix0 + grp;
-    const bool ok = pix < npix;
-    float acc[HEAD_MAXC];
+  const bool one = CH <= LPP;            // one chunk per lane: keep its weights in registers
+  float wr[CO][8];
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k) acc[k] = 0.f;
-    if (ok) {
-      const int xo = (int)(pix % WO);
-      const int yo = (int)((pix / WO) % HO);
-      const int n = (int)(pix / ((int64_t)WO * HO));
-      const T* xp = x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
-      for (int ch = sub; ch < CH; ch += LPP) {
-        float f[8];
-        load8(xp + ch * 8, f);
+  for (int k = 0; k < CO; ++k)
 #pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k)
-          if (k < Cout) {
+    for (int t = 0; t < 8; ++t) wr[k][t] = (one && k < Cout && sub * 8 + t < Cin) ? w[k * w_ld + sub * 8 + t] : 0.f;
+  const int64_t pstride = (int64_t)gridDim.x * gpb;
+  for (int64_t pb = (int64_t)blockIdx.x * gpb; pb < npix; pb += pstride * UNR) {
+    float acc[UNR][CO];
+    float f[UNR][8];
+    bool ok[UNR];
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-              if (ch * 8 + t < Cin) acc[k] += f[t] * w[k * w_ld + ch * 8 + t];
-          }
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t pix = pb + u * pstride + grp;
+      ok[u] = pix < npix;
+#pragma unroll
+      for (int k = 0; k < CO; ++k) acc[u][k] = 0.f;
+      if (ok[u] && one && sub < CH) {
+        const int xo = (int)(pix % WO);
+        const int yo = (int)((pix / WO) % HO);
+        const int n = (int)(pix / ((int64_t)WO * HO));
+        load8(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + sub * 8, f[u]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k)
-      for (int o = LPP >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
-    if (ok && sub == 0) {
-      float v[HEAD_MAXC];
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t pix = pb + u * pstride + grp;
+      if (ok[u]) {
+        if (one) {
+          if (sub < CH) {
 #pragma unroll
-      for (int k = 0; k < HEAD_MAXC; ++k) v[k] = (k < Cout) ? acc[k] + (b ? b[k] : 0.f) : -3.0e38f;
-      if (act == SEG_ACT_SOFTMAX) {
-        float mx = v[0];
+            for (int k = 0; k < CO; ++k)
+              if (k < Cout) {
 #pragma unroll
-        for (int k = 1; k < HEAD_MAXC; ++k) mx = fmaxf(mx, v[k]);
-        float s = 0.f;
+                for (int t = 0; t < 8; ++t) acc[u][k] += f[u][t] * wr[k][t];
+              }
+          }
+        } else {
+          const int xo = (int)(pix % WO);
+          const int yo = (int)((pix / WO) % HO);
+          const int n = (int)(pix / ((int64_t)WO * HO));
+          const T* xp = x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+          for (int ch = sub; ch < CH; ch += LPP) {
+            float g[8];
+            load8(xp + ch * 8, g);
 #pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k) { v[k] = (k < Cout) ? __expf(v[k] - mx) : 0.f; s += v[k]; }
-        const float inv = 1.f / s;
+            for (int k = 0; k < CO; ++k)
+              if (k < Cout) {
 #pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k) v[k] *= inv;
-      } else {
-#pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k) v[k] = seg_act(v[k], act, 0.f);
+                for (int t = 0; t < 8; ++t)
+                  if (ch * 8 + t < Cin) acc[u][k] += g[t] * w[k * w_ld + ch * 8 + t];
+              }
+          }
+        }
       }
 #pragma unroll
-      for (int k = 0; k < HEAD_MAXC; ++k)
-        if (k < Cout) y[pix * Cout + k] = v[k];
+      for (int k = 0; k < CO; ++k)
+        for (int o = LPP >> 1; o > 0; o >>= 1) acc[u][k] += __shfl_xor(acc[u][k], o);
+      if (ok[u] && sub == 0) {
+        float v[CO];
+#pragma unroll
+        for (int k = 0; k < CO; ++k) v[k] = (k < Cout) ? acc[u][k] + (b ? b[k] : 0.f) : -3.0e38f;
+        if (act == SEG_ACT_SOFTMAX) {
+          float mx = v[0];
+#pragma unroll
+          for (int k = 1; k < CO; ++k) mx = fmaxf(mx, v[k]);
+          float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < CO; ++k) { v[k] = (k < Cout) ? __expf(v[k] - mx) : 0.f; sum += v[k]; }
+          const float inv = 1.f / sum;
+#pragma unroll
+          for (int k = 0; k < CO; ++k) v[k] *= inv;
+        } else {
+#pragma unroll
+          for (int k = 0; k < CO; ++k) v[k] = seg_act(v[k], act, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < CO; ++k)
+          if (k < Cout) y[pix * Cout + k] = v[k];
+      }
     }
   }
 }
 
 // gradient of the pre-activation given dy (wrt activated y) and y
+template <int CO>
 __device__ __forceinline__ void head_dpre(const float* dy, const float* y, int Cout, int act, float* d) {
   if (act == SEG_ACT_SOFTMAX) {
     float dot = 0.f;
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k)
+    for (int k = 0; k < CO; ++k)
       if (k < Cout) dot += dy[k] * y[k];
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k) d[k] = (k < Cout) ? y[k] * (dy[k] - dot) : 0.f;
+    for (int k = 0; k < CO; ++k) d[k] = (k < Cout) ? y[k] * (dy[k] - dot) : 0.f;
   } else {
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k) d[k] = (k < Cout) ? dy[k] * seg_act_grad_from_out(y[k], act, 0.f) : 0.f;
+    for (int k = 0; k < CO; ++k) d[k] = (k < Cout) ? dy[k] * seg_act_grad_from_out(y[k], act, 0.f) : 0.f;
   }
 }
 
 // dx (+)= gs * dpre . w      (one LPP-lane group per pixel, like the forward)
-template <typename T>
+template <typename T, int CO>
 __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const float* y, int cs, int Cin, int N, int H, int W, int sy,
                                                           int sx, const float* w, int w_ld, int Cout, int act, T* dx,
                                                           int accumulate, const float* gs_ptr, int LPP) {
@@ -789,46 +883,82 @@ __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const
   const int gpb = TPB / LPP;
   const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
   const float gs = gs_ptr ? *gs_ptr : 1.f;
-  for (int64_t pix0 = (int64_t)blockIdx.x * gpb; pix0 < npix; pix0 += (int64_t)gridDim.x * gpb) {
-    const int64_t pix = pix0 + grp;
-    if (pix >= npix) continue;
-    float dyv[HEAD_MAXC], yv[HEAD_MAXC], d[HEAD_MAXC];
+  const bool one = CH <= LPP;
+  float wr[CO][8];
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k) {
-      dyv[k] = (k < Cout) ? dy[pix * Cout + k] : 0.f;
-      yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
-    }
-    head_dpre(dyv, yv, Cout, act, d);
-    const int xo = (int)(pix % WO);
-    const int yo = (int)((pix / WO) % HO);
-    const int n = (int)(pix / ((int64_t)WO * HO));
-    T* dp = dx + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
-    for (int ch = sub; ch < CH; ch += LPP) {
-      float o[8];
+  for (int k = 0; k < CO; ++k)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float s = 0.f;
-        const int c = ch * 8 + t;
-        if (c < Cin) {
+    for (int t = 0; t < 8; ++t) wr[k][t] = (one && k < Cout && sub * 8 + t < Cin) ? w[k * w_ld + sub * 8 + t] * gs : 0.f;
+  const int64_t pstride = (int64_t)gridDim.x * gpb;
+  for (int64_t pb = (int64_t)blockIdx.x * gpb; pb < npix; pb += pstride * UNR) {
+    float d[UNR][CO], old[UNR][8];
+    T* dp[UNR];
+    bool ok[UNR];
 #pragma unroll
-          for (int k = 0; k < HEAD_MAXC; ++k)
-            if (k < Cout) s += d[k] * w[k * w_ld + c];
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t pix = pb + u * pstride + grp;
+      ok[u] = pix < npix;
+      dp[u] = dx;
+      if (ok[u]) {
+        float dyv[CO], yv[CO];
+#pragma unroll
+        for (int k = 0; k < CO; ++k) {
+          dyv[k] = (k < Cout) ? dy[pix * Cout + k] : 0.f;
+          yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
         }
-        o[t] = s * gs;
+        head_dpre<CO>(dyv, yv, Cout, act, d[u]);
+        const int xo = (int)(pix % WO);
+        const int yo = (int)((pix / WO) % HO);
+        const int n = (int)(pix / ((int64_t)WO * HO));
+        dp[u] = dx + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+        if (accumulate && one && sub < CH) load8(dp[u] + sub * 8, old[u]);
       }
-      if (accumulate) {
-        float old[8];
-        load8(dp + ch * 8, old);
+    }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] += old[t];
+    for (int u = 0; u < UNR; ++u) {
+      if (!ok[u]) continue;
+      if (one) {
+        if (sub < CH) {
+          float o[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < CO; ++k)
+              if (k < Cout) sacc += d[u][k] * wr[k][t];
+            o[t] = accumulate ? sacc + old[u][t] : sacc;
+          }
+          store8(dp[u] + sub * 8, o);
+        }
+      } else {
+        for (int ch = sub; ch < CH; ch += LPP) {
+          float o[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            float sacc = 0.f;
+            const int c = ch * 8 + t;
+            if (c < Cin) {
+#pragma unroll
+              for (int k = 0; k < CO; ++k)
+                if (k < Cout) sacc += d[u][k] * w[k * w_ld + c];
+            }
+            o[t] = sacc * gs;
+          }
+          if (accumulate) {
+            float oo[8];
+            load8(dp[u] + ch * 8, oo);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] += oo[t];
+          }
+          store8(dp[u] + ch * 8, o);
+        }
       }
-      store8(dp + ch * 8, o);
     }
   }
 }
 
 // dw[k][c] += sum_pix dpre[k] * x[c],  db[k] += sum_pix dpre[k]   ((rows x chunk-columns) layout + atomics)
-template <typename T>
+template <typename T, int CO>
 __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const float* y, const T* x, int cs, int Cin, int N, int H,
                                                           int W, int sy, int sx, int w_ld, int Cout, int act, float* dw, float* db,
                                                           ColLayout L) {
@@ -840,30 +970,30 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
   const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
   for (int grp = 0; grp < L.ngrp; ++grp) {
     const int ch = grp * L.CHP + col;
-    float acc[HEAD_MAXC][8];
-    float accb[HEAD_MAXC];
+    float acc[CO][8];
+    float accb[CO];
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXC; ++k) {
+    for (int k = 0; k < CO; ++k) {
       accb[k] = 0.f;
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[k][t] = 0.f;
     }
     if (ch < L.CH) {
       for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
-        float dyv[HEAD_MAXC], yv[HEAD_MAXC], d[HEAD_MAXC];
+        float dyv[CO], yv[CO], d[CO];
 #pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k) {
+        for (int k = 0; k < CO; ++k) {
           dyv[k] = (k < Cout) ? dy[pix * Cout + k] : 0.f;
           yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
         }
-        head_dpre(dyv, yv, Cout, act, d);
+        head_dpre<CO>(dyv, yv, Cout, act, d);
         const int xo = (int)(pix % WO);
         const int yo = (int)((pix / WO) % HO);
         const int n = (int)(pix / ((int64_t)WO * HO));
         float f[8];
         load8(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + ch * 8, f);
 #pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k)
+        for (int k = 0; k < CO; ++k)
           if (k < Cout) {
             accb[k] += d[k];
 #pragma unroll
@@ -871,10 +1001,10 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
           }
       }
     }
-    block_col_reduce<HEAD_MAXC>(acc, sm, rowi, col, L.CHP, L.RP);
+    block_col_reduce<CO>(acc, sm, rowi, col, L.CHP, L.RP);
     if (rowi == 0 && ch < L.CH) {
 #pragma unroll
-      for (int k = 0; k < HEAD_MAXC; ++k)
+      for (int k = 0; k < CO; ++k)
         if (k < Cout) {
 #pragma unroll
           for (int t = 0; t < 8; ++t)
@@ -885,12 +1015,12 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
       __syncthreads();
       if (col == 0) {
 #pragma unroll
-        for (int k = 0; k < HEAD_MAXC; ++k) sm[rowi * HEAD_MAXC + k] = accb[k];
+        for (int k = 0; k < CO; ++k) sm[rowi * CO + k] = accb[k];
       }
       __syncthreads();
       if (threadIdx.x < Cout) {
         float s = 0.f;
-        for (int r = 0; r < L.RP; ++r) s += sm[r * HEAD_MAXC + threadIdx.x];
+        for (int r = 0; r < L.RP; ++r) s += sm[r * CO + threadIdx.x];
         atomicAdd(db + threadIdx.x, s);
       }
     }
@@ -951,12 +1081,28 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
 
 __global__ __launch_bounds__(TPB) void absmax_kernel(const float* x, int64_t n, float* amax) {
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    const float v = fabsf(x[i]);
-    m = (v == v) ? fmaxf(m, v) : m;
+  const int64_t n4 = n / 4;
+  const f4* x4 = reinterpret_cast<const f4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    const f4 v = x4[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fabsf(v[k]);
+      m = (a == a) ? fmaxf(m, a) : m;
+    }
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float a = fabsf(x[i]);
+    m = (a == a) ? fmaxf(m, a) : m;
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));   // m >= 0: bit order == value order
+  __shared__ float sm[TPB / 64];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < TPB / 64; ++k) m = fmaxf(m, sm[k]);
+    atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));   // m >= 0: bit order == value order
+  }
 }
 
 __global__ void grad_scale_kernel(const float* amax, float target, float* gs) {
@@ -993,14 +1139,22 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* p, const float* g, flo
 
 template <typename T>
 __global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, T* wt, int rows, int Tn, int K, int rows_pad) {
-  // out[k][t][r] = in[r][t][k];   grid-stride over the OUTPUT so that stores are coalesced
-  const int64_t n = (int64_t)K * Tn * rows_pad;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    const int r = (int)(i % rows_pad);
-    const int64_t q = i / rows_pad;
-    const int t = (int)(q % Tn);
-    const int k = (int)(q / Tn);
-    wt[i] = (r < rows) ? (T)w[((int64_t)r * Tn + t) * K + k] : (T)0.f;
+  // out[k][t][r] = in[r][t][k]: 32 x 32 (r, k) tiles through LDS so that both the fp32 reads (k fastest) and the
+  // writes (r fastest) are coalesced.  grid = (ceil(K/32) * ceil(rows_pad/32), Tn)
+  __shared__ float tile[32][33];
+  const int kt = blockIdx.x % ((K + 31) / 32), rt = blockIdx.x / ((K + 31) / 32);
+  const int t = blockIdx.y;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = rt * 32 + ty + 8 * j, k = kt * 32 + tx;
+    tile[ty + 8 * j][tx] = (r < rows && k < K) ? w[((int64_t)r * Tn + t) * K + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = kt * 32 + ty + 8 * j, r = rt * 32 + tx;
+    if (k < K && r < rows_pad) wt[((int64_t)k * Tn + t) * rows_pad + r] = (T)tile[tx][ty + 8 * j];
   }
 }
 
@@ -1075,7 +1229,7 @@ static int seg_bn_act_apply_impl(const void* x, int32_t x_cs, int32_t x_coff, vo
                 "seg_bn_act_apply: bad arguments");
   const int64_t npix = (int64_t)N * H * W;
   if (pooled == nullptr) {
-    hipLaunchKernelGGL((bn_act_apply_kernel<T>), dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
+    hipLaunchKernelGGL((bn_act_apply_kernel<T>), dim3(grid_for((npix * (C / 8) + UNR - 1) / UNR)), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
                        (T*)y, y_cs, y_coff, npix, C, c_valid, scale, shift, act, alpha);
   } else {
     SEG_CHECK_ARG(ph >= 1 && pw >= 1 && y_coff == 0 && C == y_cs, "seg_bn_act_apply: fused pooling needs a dense output (C == y_cs)");
@@ -1121,7 +1275,7 @@ static int seg_bn_act_bwd_apply_impl(const void* dy, int32_t dy_cs, int32_t dy_c
   SEG_CHECK_ARG(dy && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
                     dx_coff + C <= dx_cs && (c1 == nullptr || (c2 && mean && invstd)),
                 "seg_bn_act_bwd_apply: bad arguments");
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(grid_for(npix * (C / 8))), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(grid_for((npix * (C / 8) + UNR - 1) / UNR)), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
                      (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
                      accumulate);
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply");
@@ -1287,10 +1441,18 @@ static int seg_head_fwd_impl(const void* x, int32_t cs, int32_t Cin, int32_t N, 
                 "seg_head_fwd: bad arguments (Cin=%d cs=%d Cout=%d)", Cin, cs, Cout);
   const int LPP = head_lpp(Cin), gpb = TPB / LPP;
   const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
-  int64_t blocks = (npix + gpb - 1) / gpb;
-  if (blocks > 4 * MAX_BLOCKS) blocks = 4 * MAX_BLOCKS;
-  hipLaunchKernelGGL((head_fwd_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout,
-                     act, y, LPP);
+  int64_t blocks = (npix + (int64_t)gpb * UNR - 1) / ((int64_t)gpb * UNR);
+  if (blocks > 2 * MAX_BLOCKS) blocks = 2 * MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+#define SEG_HEAD_CO(KERNEL, ...)                                                                        \
+  do {                                                                                                  \
+    if (Cout <= 1) hipLaunchKernelGGL((KERNEL<T, 1>), __VA_ARGS__);                                      \
+    else if (Cout <= 2) hipLaunchKernelGGL((KERNEL<T, 2>), __VA_ARGS__);                                 \
+    else if (Cout <= 4) hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__);                                 \
+    else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                                \
+  } while (0)
+  SEG_HEAD_CO(head_fwd_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout, act, y,
+              LPP);
   SEG_CHECK_LAUNCH("seg_head_fwd");
   return SEG_OK;
 }
@@ -1306,17 +1468,18 @@ static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int
   const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
   if (dx != nullptr) {
     const int LPP = head_lpp(cs), gpb = TPB / LPP;
-    int64_t blocks = (npix + gpb - 1) / gpb;
-    if (blocks > 4 * MAX_BLOCKS) blocks = 4 * MAX_BLOCKS;
-    hipLaunchKernelGGL((head_bwd_dx_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), dy, y, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act,
-                       (T*)dx, accumulate, gs_ptr, LPP);
+    int64_t blocks = (npix + (int64_t)gpb * UNR - 1) / ((int64_t)gpb * UNR);
+    if (blocks > 2 * MAX_BLOCKS) blocks = 2 * MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    SEG_HEAD_CO(head_bwd_dx_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), dy, y, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, (T*)dx,
+                accumulate, gs_ptr, LPP);
   }
   if (dw != nullptr) {
-    int blocks = (int)((npix + 511) / 512);
-    if (blocks > 512) blocks = 512;
+    int blocks = (int)((npix + 1023) / 1024);      // every block ends with Cout*Cin same-address atomics: keep the count low
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((head_bwd_dw_kernel<T>), dim3(blocks), dim3(TPB), 0, ST(stream), dy, y, (const T*)x, cs, Cin, N, H, W, sy, sx, w_ld,
-                       Cout, act, dw, db, col_layout(((Cin + 7) / 8) * 8));
+    SEG_HEAD_CO(head_bwd_dw_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), dy, y, (const T*)x, cs, Cin, N, H, W, sy, sx, w_ld, Cout, act, dw,
+                db, col_layout(((Cin + 7) / 8) * 8));
   }
   SEG_CHECK_LAUNCH("seg_head_bwd");
   return SEG_OK;
@@ -1338,7 +1501,9 @@ extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* ta
 
 extern "C" int seg_absmax(const float* x, int64_t n, float* amax, seg_stream_t stream) {
   SEG_CHECK_ARG(x && amax && n > 0, "seg_absmax: bad arguments");
-  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), x, n, amax);
+  int blocks = grid_for(n / 4 + 1);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), x, n, amax);
   SEG_CHECK_LAUNCH("seg_absmax");
   return SEG_OK;
 }
@@ -1361,8 +1526,8 @@ extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void*
 template <typename T>
 static int seg_transpose_w_impl(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) {
   SEG_CHECK_ARG(w && wt && rows > 0 && Tn > 0 && K > 0 && rows_pad >= rows, "seg_transpose_w: bad arguments");
-  hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(grid_for((int64_t)K * Tn * rows_pad)), dim3(TPB), 0, ST(stream), w, (T*)wt, rows, Tn, K,
-                     rows_pad);
+  hipLaunchKernelGGL((transpose_w_kernel<T>), dim3(((K + 31) / 32) * ((rows_pad + 31) / 32), Tn), dim3(TPB), 0, ST(stream), w, (T*)wt,
+                     rows, Tn, K, rows_pad);
   SEG_CHECK_LAUNCH("seg_transpose_w");
   return SEG_OK;
 }
