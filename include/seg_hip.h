@@ -79,7 +79,16 @@ typedef struct seg_igemm_fwd_args {
   float alpha;
   int32_t accumulate;            /* out += result instead of out = result                                  */
   float* stats;                  /* NULL or fp32 [nparts][2][n_rows], nparts = ncls * ceil(M / tile_m)     */
-  int32_t tile_m, tile_n;        /* 128 or 64                                                              */
+  int32_t tile_m, tile_n;        /* 128x128 | 128x64 | 64x128 | 64x64 | 256x64                              */
+  /* split output ("un-concat", used by data gradients of a virtual concat): when nout > 0 the N columns are cut
+   * into nout consecutive spans; span o covers out_span[o] columns (multiple of 32) of which the first
+   * out_cs_o[o] are stored to tensor out_ptr[o] (channel stride out_cs_o[o], NULL = discard), accumulating when
+   * out_acc[o] != 0.  out / out_cs / out_coff / accumulate are ignored in that mode.                          */
+  int32_t nout;
+  int32_t out_span[SEG_MAX_SEG];
+  int32_t out_cs_o[SEG_MAX_SEG];
+  int32_t out_acc[SEG_MAX_SEG];
+  void* out_ptr[SEG_MAX_SEG];
 } seg_igemm_fwd_args;
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
 

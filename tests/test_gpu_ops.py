@@ -131,6 +131,43 @@ def test_dgrad_lds_dma_pipeline(kind, k, s):
         assert rel(from_dev(dx, cin), x.grad) < 2e-3, tile
 
 
+@pytest.mark.parametrize("tile", [(64, 64), (128, 128), (256, 64)])
+def test_dgrad_split_output_over_concat_segments(tile):
+    """One data-gradient launch for a conv over a virtual concat [40ch, 64ch, 8ch]: N = K axis of the forward weight,
+    the epilogue writes span 0 plainly, accumulates into span 1 and discards span 2 (tensor needing no gradient)."""
+    N, H, W, cout = 2, 16, 16, 48
+    cins = [40, 64, 8]
+    xs = [h16(torch.randn(N, H, W, c)).requires_grad_(True) for c in cins]
+    kern = h16(torch.from_numpy(rng.standard_normal((3, 3, sum(cins), cout)).astype(np.float32) * 0.1))
+    y = K.conv2d_same(torch.cat(xs, -1), kern, None)
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    M = U.M
+    woff = [0, 64, 128]
+    Kpad, n_rows, T = 160, U.r8(cout), 9
+    E = M.pack_gemm_weight(kern.numpy(), cins, woff, n_rows, Kpad, False)
+    rows_pad = U.r32(n_rows)
+    wt = torch.zeros(Kpad * T * rows_pad, dtype=torch.float16, device="cuda")
+    Ed = dev_f32(E.reshape(-1))
+    ffi.call("seg_transpose_w", P(Ed), P(wt), n_rows, T, Kpad, rows_pad, stream())
+    dzd = to_dev_nhwc(dz)
+    prev = h16(torch.randn(N, H, W, 64))
+    g0 = torch.full((N, H, W, 40), 5.0, dtype=torch.float16, device="cuda")
+    g1 = to_dev_nhwc(prev)
+    a = ffi.IgemmFwdArgs()
+    a.g, a.nseg = M.geom_conv_dgrad(N, H, W, 3, 3, 1, 1), 1
+    a.seg_c[0], a.seg_cs[0], a.seg_woff[0], a.seg_ptr[0] = n_rows, dzd.shape[3], 0, dzd.data_ptr()
+    a.w, a.Kpad, a.n_rows, a.n_valid = wt.data_ptr(), rows_pad, Kpad, Kpad
+    a.nout = 3
+    for o, (span, cs, ptr, acc) in enumerate([(64, 40, g0.data_ptr(), 0), (64, 64, g1.data_ptr(), 1), (32, 8, None, 0)]):
+        a.out_span[o], a.out_cs_o[o], a.out_ptr[o], a.out_acc[o] = span, cs, ptr, acc
+    a.tile_m, a.tile_n = tile
+    ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    torch.cuda.synchronize()
+    assert rel(g0.float().cpu(), xs[0].grad) < 2e-3
+    assert rel(g1.float().cpu(), prev + xs[1].grad) < 2e-3
+
+
 def test_igemm_fwd_accumulate():
     xs = [torch.randn(2, 16, 16, 32)]
     kern = rng.standard_normal((3, 3, 32, 64)).astype(np.float32) * 0.1

@@ -44,9 +44,8 @@ def test_unetpp_fusion_counts():
     assert c["seg_adam_step"] == 1                   # ONE flat optimiser launch
     # no concat is ever materialised: every tensor in the registry is a real layer output
     assert not any(n.endswith("/cat") for n in m.tensors)
-    # data-gradient launches: one per concat segment that needs a gradient
-    segs = sum(len(op.segs) for op in m.ops if isinstance(op, M.ConvOp)) - 1      # the image needs none
-    assert c["seg_igemm_fwd"] == (convs + nodes) + segs
+    # data-gradient launches: ONE per conv (split output), none for the first layer (the image needs no gradient)
+    assert c["seg_igemm_fwd"] == 2 * (convs + nodes) - 1
 
 
 def test_accumulate_flags_follow_consumer_count():
@@ -55,12 +54,13 @@ def test_accumulate_flags_follow_consumer_count():
     acc = {}
     for op in m.ops:
         if isinstance(op, M.ConvOp) and getattr(op, "live", False):
-            for a, t, flag, _fl in op.dg_args:
-                acc.setdefault(t.name, []).append(flag)
-    # X01's output feeds X02 (dense skip) and nothing else in depth 2 with ds=0 -> written once
-    assert acc["X01/relu"] == [0]
-    # enc1 output: consumers X01 (skip), X02 (skip) + its pooled copy -> first writer plain, later ones accumulate
-    assert sorted(acc["enc1/relu"]) == [0, 1] or sorted(acc["enc1/relu"]) == [1, 1]
+            for a, _zero, _fl in op.dg_args:
+                for o, (t, _c) in enumerate(op.segs):
+                    if a.out_ptr[o]:
+                        acc.setdefault(t.name, []).append(a.out_acc[o])
+    assert acc["X01/relu"] == [0]                       # one consumer (X02's dense skip): written once
+    assert len(acc["enc1/relu"]) == 2                   # skip into X01 and X02 (+ the pooled path through maxpool_bwd)
+    # per tensor: at most one plain write, every other producer accumulates
     assert all(sorted(v)[1:] == [1] * (len(v) - 1) for v in acc.values())
 
 

@@ -29,7 +29,8 @@ class IgemmFwdArgs(C.Structure):
                 ("Kpad", C.c_int32), ("n_rows", C.c_int32), ("n_valid", C.c_int32), ("out", C.c_void_p),
                 ("out_cs", C.c_int32), ("out_coff", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
                 ("alpha", C.c_float), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("tile_m", C.c_int32),
-                ("tile_n", C.c_int32)]
+                ("tile_n", C.c_int32), ("nout", C.c_int32), ("out_span", C.c_int32 * MAX_SEG), ("out_cs_o", C.c_int32 * MAX_SEG),
+                ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG)]
 
 
 class IgemmWgradArgs(C.Structure):

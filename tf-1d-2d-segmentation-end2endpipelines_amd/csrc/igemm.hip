@@ -129,16 +129,33 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
         if (nzero) v = 0.f;
         stg[rt * STG_LD + fr] = v;
       }
+      // destination of this 32-column tile: the single output, or one span of the split output
+      T* obase = out;
+      int ocs = p.out_cs, ocol = p.out_coff + nbase, olim = p.n_rows - nbase, oacc = p.accumulate;
+      if (p.nout > 0) {
+        int start = 0;
+        obase = nullptr;
+        olim = 0;
+        for (int o = 0; o < p.nout; ++o) {
+          if (nbase >= start && nbase < start + p.out_span[o]) {
+            obase = (T*)p.out_ptr[o];
+            ocs = p.out_cs_o[o];
+            ocol = nbase - start;
+            olim = p.out_cs_o[o] - ocol;
+            oacc = p.out_acc[o];
+          }
+          start += p.out_span[o];
+        }
+      }
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const int rt = st_row + 16 * ps;
-        const int nn = nbase + st_ch * 8;
         f4 v0 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8]);
         f4 v1 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8 + 4]);
-        if (opix[ps] >= 0 && nn < p.n_rows) {
-          T* dst = out + (size_t)opix[ps] * p.out_cs + p.out_coff + nn;
+        if (opix[ps] >= 0 && obase != nullptr && st_ch * 8 < olim) {
+          T* dst = obase + (size_t)opix[ps] * ocs + ocol + st_ch * 8;
           float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if (p.accumulate) {
+          if (oacc) {
             float o[8];
             load8(dst, o);
 #pragma unroll
@@ -799,10 +816,20 @@ template <typename T>
 static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_fwd: null args");
   if (!check_geom(a->g, "seg_igemm_fwd") || !check_segs(*a, "seg_igemm_fwd")) return SEG_ERR_ARG;
-  SEG_CHECK_ARG(a->w && a->out, "seg_igemm_fwd: null weight/output pointer");
-  SEG_CHECK_ARG(a->n_rows > 0 && (a->n_rows & 7) == 0 && (a->out_cs & 7) == 0 && (a->out_coff & 7) == 0 &&
-                    a->out_coff + a->n_rows <= a->out_cs,
-                "seg_igemm_fwd: n_rows=%d out_cs=%d out_coff=%d", a->n_rows, a->out_cs, a->out_coff);
+  SEG_CHECK_ARG(a->w != nullptr && a->n_rows > 0 && (a->n_rows & 7) == 0, "seg_igemm_fwd: null weight pointer / n_rows=%d", a->n_rows);
+  if (a->nout == 0) {
+    SEG_CHECK_ARG(a->out && (a->out_cs & 7) == 0 && (a->out_coff & 7) == 0 && a->out_coff + a->n_rows <= a->out_cs,
+                  "seg_igemm_fwd: n_rows=%d out_cs=%d out_coff=%d", a->n_rows, a->out_cs, a->out_coff);
+  } else {
+    SEG_CHECK_ARG(a->nout > 0 && a->nout <= SEG_MAX_SEG && a->stats == nullptr, "seg_igemm_fwd: nout=%d (no statistics with a split output)", a->nout);
+    int tot = 0;
+    for (int o = 0; o < a->nout; ++o) {
+      SEG_CHECK_ARG(a->out_span[o] > 0 && (a->out_span[o] & 31) == 0 && (a->out_cs_o[o] & 7) == 0 && a->out_cs_o[o] <= a->out_span[o],
+                    "seg_igemm_fwd: output span %d: span=%d cs=%d", o, a->out_span[o], a->out_cs_o[o]);
+      tot += a->out_span[o];
+    }
+    SEG_CHECK_ARG(tot >= a->n_rows, "seg_igemm_fwd: output spans cover %d of %d columns", tot, a->n_rows);
+  }
   SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_fwd: Kpad=%d not a multiple of 32", a->Kpad);
   SEG_CHECK_ARG((a->tile_m == 256 && a->tile_n == 64) || ((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64)),
                 "seg_igemm_fwd: tile %dx%d", a->tile_m, a->tile_n);

@@ -550,24 +550,34 @@ class ConvOp(Op):
             return
         if self.kind == "convlstm":
             self.z.ensure_grad()
+        # one data-gradient launch for the whole (virtual) concat: GEMM N = the K axis of the forward weight,
+        # split back onto the segment tensors by the epilogue
         self.dg_args = []
-        for s_i, (t, _c) in enumerate(self.segs):
-            if not t.needs_grad:
-                continue
-            acc = t.claim()
+        if any(t.needs_grad for t, _c in self.segs):
             a = IgemmFwdArgs()
             a.g = self.g_dgrad
             a.nseg = 1
             a.seg_c[0], a.seg_cs[0], a.seg_woff[0] = self.n_rows, self.z.cs, 0
-            a.seg_ptr[0] = None     # dz pointer filled below
-            a.w = self.wt.data_ptr() + self.woff[s_i] * self.T * self.rows_pad * self.wt.element_size()
-            a.Kpad, a.n_rows, a.n_valid = self.rows_pad, t.cs, t.cs
-            a.out, a.out_cs, a.out_coff = t.grad.data_ptr(), t.cs, 0
+            a.seg_ptr[0] = None     # dz pointer filled in backward()
+            a.w = self.wt.data_ptr()
+            a.Kpad, a.n_rows, a.n_valid = self.rows_pad, self.Kpad, self.Kpad
+            a.out, a.out_cs, a.out_coff, a.accumulate = None, 0, 0, 0
             a.bias, a.act, a.alpha, a.stats = None, 0, 0.0, None
-            a.accumulate = acc
+            a.nout = len(self.segs)
+            zero_first, fl = [], 0.0
+            for s_i, (t, _c) in enumerate(self.segs):
+                a.out_span[s_i], a.out_cs_o[s_i] = _r32(t.cs), t.cs
+                if t.needs_grad:
+                    acc = t.claim()
+                    a.out_ptr[s_i], a.out_acc[s_i] = t.grad.data_ptr(), acc
+                    fl += self.flops_seg[s_i]
+                    if self.strided and not acc:
+                        zero_first.append(t)
+                else:
+                    a.out_ptr[s_i], a.out_acc[s_i] = None, 0
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
-            a.tile_m, a.tile_n = pick_tile_fwd(Md, t.cs, 1)
-            self.dg_args.append((a, t, acc, self.flops_seg[s_i]))
+            a.tile_m, a.tile_n = pick_tile_fwd(Md, self.Kpad, 1)
+            self.dg_args.append((a, zero_first, fl))
 
     def backward(self):
         st, s = self.m.store, _stream()
@@ -599,11 +609,11 @@ class ConvOp(Op):
                 call("seg_act_bwd", _p(dz), _p(self.out.buf), _p(dz), self.out.npix, self.out.cs, self.cout, ACT[self.act],
                      float(self.alpha), None, 1.0, None, s)
             self._bias_grad(dz, s, gs_inv)
-        for a, t, acc, fl in self.dg_args:
-            if self.strided and not acc:
+        for a, zero_first, fl in self.dg_args:
+            for t in zero_first:
                 t.grad.zero_()
             a.seg_ptr[0] = dz.data_ptr()
-            call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad:" + self.node.name + ">" + t.name)
+            call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad:" + self.node.name)
         self.wg_args.dz = dz.data_ptr()
         call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
 
