@@ -111,6 +111,9 @@ typedef struct seg_igemm_wgrad_args {
   int32_t variant;               /* 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores         */
 } seg_igemm_wgrad_args;
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
+/* taps one block of seg_igemm_wgrad handles for this tile (layers with <= 64 output channels use a multi-tap
+ * kernel that reads the dz tile once for 3 / 4 / 9 taps); the host sizes `splitk` with it.                       */
+int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int variant);
 
 /* ---- BatchNormalization() (unet_variants.py:11,70,72,76,96,99), eps 1e-3, momentum 0.99 ------------------ */
 /* per-channel partial sums of an existing tensor: stats[part][0][c] = sum x, [1][c] = sum x^2 over the part   */

@@ -60,6 +60,17 @@ def test_struct_layout_matches_header():
         assert names == [f[0] for f in cls._fields_], (struct, names, [f[0] for f in cls._fields_])
 
 
+def test_host_and_library_agree_on_wgrad_taps_per_block(built):
+    ffi = importlib.import_module(PKG + "._ffi")
+    M = importlib.import_module(PKG + ".model")
+    L = ffi.lib()
+    for tm in (64, 128):
+        for tn in (64, 128):
+            for nt in (1, 2, 3, 4, 9, 16):
+                for v in (0, 1):
+                    assert L.seg_wgrad_taps_per_block(tm, tn, nt, v) == M.wgrad_taps_per_block(tm, tn, nt, v)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     ffi = importlib.import_module(PKG + "._ffi")
     monkeypatch.setattr(ffi, "_lib", None)

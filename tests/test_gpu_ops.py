@@ -222,7 +222,13 @@ def test_dgrad_matches_autograd(kind, k, s, shape, cin, cout):
     dict(shape=(2, 8, 8), cins=[64], cout=32, k=(4, 4), kind="convT", s=(2, 2), sk=None, tile=None),
     dict(shape=(2, 16, 16), cins=[64], cout=32, k=(1, 1), kind="conv", s=(2, 2), sk=None, tile=None),
     dict(shape=(4, 1, 64), cins=[32], cout=16, k=(1, 2), kind="convT", s=(1, 2), sk=None, tile=None),
-], ids=lambda c: f"{c['kind']}{c['k']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
+    # multi-tap kernel (<= 64 output channels): 9 taps x 64-wide K tile, 3 groups of 3 taps x 128-wide, 4 taps per class
+    dict(shape=(2, 24, 32), cins=[64, 64, 8], cout=64, k=(3, 3), kind="conv", s=(1, 1), sk=5, tile=(64, 64)),
+    dict(shape=(2, 16, 24), cins=[128, 72], cout=40, k=(3, 3), kind="conv", s=(1, 1), sk=3, tile=(64, 128)),
+    dict(shape=(2, 12, 16), cins=[128], cout=64, k=(4, 4), kind="convT", s=(2, 2), sk=2, tile=(64, 128)),
+    dict(shape=(2, 12, 16), cins=[64], cout=24, k=(4, 4), kind="convT", s=(2, 2), sk=3, tile=(64, 64)),
+    dict(shape=(4, 1, 160), cins=[48], cout=16, k=(1, 3), kind="conv", s=(1, 1), sk=2, tile=(64, 64)),
+], ids=lambda c: f"{c['kind']}{c['k']}-{c['cins']}->{c['cout']}-sk{c['sk']}-{c['tile']}")
 def test_wgrad_matches_autograd(case, variant):
     N, H, W = case["shape"]
     xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]

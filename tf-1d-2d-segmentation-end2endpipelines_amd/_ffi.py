@@ -47,6 +47,7 @@ _PROTOS = {
     "seg_abi_version": ([], C.c_int),
     "seg_igemm_fwd": ([C.POINTER(IgemmFwdArgs), vp], C.c_int),
     "seg_igemm_wgrad": ([C.POINTER(IgemmWgradArgs), vp], C.c_int),
+    "seg_wgrad_taps_per_block": ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),
@@ -108,6 +109,7 @@ def lib():
             fn.restype = rest
         L.seg_last_error.argtypes = []
         L.seg_last_error.restype = C.c_char_p
+        L.seg_wgrad_taps_per_block.restype = C.c_int
         if L.seg_abi_version() != 1:
             raise ImportError("libseg_hip.so ABI version mismatch; rebuild")
         _lib = L

@@ -733,6 +733,182 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient, multi-tap form for layers with <= 64 output channels (the full-resolution level, 36 % of the
+// UNet++ MACs): one block owns a 64 (n) x BN (k) tile for NTB taps at once, so the dz tile is read once per
+// NTB taps instead of once per tap and the NTB shifted input tiles hit the same L1/L2 lines.  fp16, transposed
+// LDS reads, single LDS buffer + register prefetch of the next 32-pixel step.
+// ---------------------------------------------------------------------------------------------------------
+template <int BN, int NTB>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_mt_kernel(const seg_igemm_wgrad_args p) {
+  constexpr int BM = 64, PK = 32, TN = BN / 64;
+  constexpr int ZLD = BM * 2 + 64, ALD = BN * 2 + 64;
+  constexpr int Z_BYTES = PK * ZLD, A_BYTES = PK * ALD;
+  constexpr int ACH = BN / 8, APT = (PK * ACH) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef half_t T;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const seg_geom& g = p.g;
+  const int HW = g.Hl * g.Wl;
+  const int M = g.N * HW;
+
+  const int rtiles = (p.n_rows + BM - 1) / BM;
+  const int rt = blockIdx.x % rtiles;
+  int kt = blockIdx.x / rtiles;
+  int seg = 0;
+  for (; seg < p.nseg; ++seg) {
+    int t = (p.seg_c[seg] + BN - 1) / BN;
+    if (kt < t) break;
+    kt -= t;
+  }
+  if (seg >= p.nseg) return;
+  const int groups = g.ntaps / NTB;
+  const int cls = blockIdx.y / groups, tgrp = blockIdx.y % groups;
+  const int e0 = cls * g.ntaps + tgrp * NTB;
+  int t_dy[NTB], t_dx[NTB], t_w[NTB];
+#pragma unroll
+  for (int t = 0; t < NTB; ++t) { t_dy[t] = g.tap_dy[e0 + t]; t_dx[t] = g.tap_dx[e0 + t]; t_w[t] = g.tap_w[e0 + t]; }
+  const int oy = g.oy[cls], ox = g.ox[cls];
+  const int r0 = rt * BM, k0 = kt * BN;
+  const int sc = p.seg_c[seg], cs = p.seg_cs[seg];
+  const T* sp = (const T*)p.seg_ptr[seg];
+  const T* dz = (const T*)p.dz;
+
+  int per = (M + p.splitk - 1) / p.splitk;
+  per = (per + PK - 1) / PK * PK;
+  const int pbeg = blockIdx.z * per;
+  const int pend = min(M, pbeg + per);
+  if (pbeg >= pend) return;
+
+  // ---- per-thread rows: one dz chunk (pixel tid / 8, chunk tid % 8), APT input chunks per tap
+  const int z_p = tid >> 3, z_c = tid & 7;
+  int zn, zi, zj;
+  {
+    int m = pbeg + z_p;
+    zn = m / HW; int rem = m - zn * HW; zi = rem / g.Wl; zj = rem - zi * g.Wl;
+  }
+  int a_p[APT], a_c[APT], an[APT], ai[APT], aj[APT];
+#pragma unroll
+  for (int r = 0; r < APT; ++r) {
+    int q = tid + 256 * r;
+    a_p[r] = q / ACH; a_c[r] = q % ACH;
+    int m = pbeg + a_p[r];
+    an[r] = m / HW; int rem = m - an[r] * HW; ai[r] = rem / g.Wl; aj[r] = rem - ai[r] * g.Wl;
+  }
+  auto advance = [&](int& n, int& i, int& j) {
+    j += PK;
+    while (j >= g.Wl) { j -= g.Wl; ++i; if (i >= g.Hl) { i = 0; ++n; } }
+  };
+
+  f16v acc[NTB][TN];
+#pragma unroll
+  for (int t = 0; t < NTB; ++t)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][b][q] = 0.f;
+
+  u4 rz, ra[NTB][APT];
+  auto gload = [&](int pb) {
+    {
+      u4 v = {0u, 0u, 0u, 0u};
+      const int m = pb + z_p, col = r0 + z_c * 8;
+      if (m < pend && col < p.n_rows) {
+        size_t off = (((size_t)zn * g.Hout + (zi * g.osy + oy)) * g.Wout + (zj * g.osx + ox)) * p.dz_cs + p.dz_coff + col;
+        v = ld16(dz + off);
+      }
+      rz = v;
+      advance(zn, zi, zj);
+    }
+#pragma unroll
+    for (int r = 0; r < APT; ++r) {
+      const int m = pb + a_p[r], col = k0 + a_c[r] * 8;
+      const bool rok = m < pend && col < sc;
+      const int cy = ai[r] * g.isy, cx = aj[r] * g.isx;
+      const size_t base = ((size_t)an[r] * g.Hin) * g.Win;
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) {
+        u4 v = {0u, 0u, 0u, 0u};
+        const int y = cy + t_dy[t], x = cx + t_dx[t];
+        if (rok && (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win) v = ld16(sp + (base + (size_t)y * g.Win + x) * cs + col);
+        ra[t][r] = v;
+      }
+      advance(an[r], ai[r], aj[r]);
+    }
+  };
+  unsigned char* Z = smem;
+  unsigned char* A0 = smem + Z_BYTES;
+  auto lstore = [&]() {
+    st16(Z + z_p * ZLD + z_c * 16, rz);
+#pragma unroll
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+      for (int r = 0; r < APT; ++r) st16(A0 + t * A_BYTES + a_p[r] * ALD + a_c[r] * 16, ra[t][r]);
+  };
+  const int tg = lane >> 4, tt = lane & 15, tq = tt >> 2, tp = tt & 3;
+  typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+  typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
+  auto trfrag = [&](const unsigned char* ad, int ld) -> h8 {
+    s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
+    s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * ld));
+    h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
+    return h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int krow = ks * 16 + 8 * (tg >> 1) + tq;
+      const h8 af = trfrag(Z + krow * ZLD + (wm * 32 + 16 * (tg & 1) + 4 * tp) * 2, ZLD);
+#pragma unroll
+      for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const h8 bf = trfrag(A0 + t * A_BYTES + krow * ALD + (wn * (BN / 2) + b * 32 + 16 * (tg & 1) + 4 * tp) * 2, ALD);
+          acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t][b], 0, 0, 0);
+        }
+    }
+  };
+
+  const int niter = (pend - pbeg + PK - 1) / PK;
+  gload(pbeg);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (it + 1 < niter) gload(pbeg + (it + 1) * PK);
+    compute();
+  }
+
+  float sc_mul = p.scale;
+  if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
+  float* dw = p.dw;
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NTB; ++t)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int kcol = k0 + wn * (BN / 2) + b * 32 + fr;
+      if (kcol < sc) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+          if (row < p.n_rows) {
+            size_t off = ((size_t)row * g.T_total + t_w[t]) * p.Kpad + p.seg_woff[seg] + kcol;
+            atomicAdd(dw + off, acc[t][b][q] * sc_mul);
+          }
+        }
+      }
+    }
+}
+
+template __global__ void igemm_wgrad_mt_kernel<64, 9>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_mt_kernel<64, 4>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_mt_kernel<64, 3>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_mt_kernel<128, 4>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_mt_kernel<128, 3>(const seg_igemm_wgrad_args);
+
 bool check_geom(const seg_geom& g, const char* who) {
   if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Hl <= 0 || g.Wl <= 0 || g.Hout <= 0 || g.Wout <= 0) {
     seg_set_error("%s: non-positive dimension", who);
@@ -856,6 +1032,16 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
 extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) { return igemm_fwd_launch<half_t>(a, stream); }
 extern "C" int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t stream) { return igemm_fwd_launch<float>(a, stream); }
 
+// taps handled per block by the weight-gradient kernels (1 = the per-tap kernel); exported so that the host can
+// size the pixel split with the same rule
+extern "C" int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int variant) {
+  static const bool force_v1 = std::getenv("SEG_WGRAD_V1") != nullptr;
+  if (force_v1 || variant != 0 || tile_m != 64) return 1;
+  if (tile_n == 64) return (ntaps == 9 || ntaps == 4 || ntaps == 3) ? ntaps : 1;
+  if (tile_n == 128) return ntaps == 4 ? 4 : (ntaps == 9 || ntaps == 3) ? 3 : 1;
+  return 1;
+}
+
 template <typename T>
 static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_wgrad: null args");
@@ -873,6 +1059,21 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
   int ktiles = 0;
   for (int s = 0; s < a->nseg; ++s) ktiles += (a->seg_c[s] + a->tile_n - 1) / a->tile_n;
+  if constexpr (sizeof(T) == 2) {
+    const int ntb = seg_wgrad_taps_per_block(a->tile_m, a->tile_n, a->g.ntaps, a->variant);
+    if (ntb > 1) {
+      dim3 gridm((unsigned)(rtiles * ktiles), (unsigned)(a->g.ncls * (a->g.ntaps / ntb)), (unsigned)a->splitk);
+      const size_t ldsm = (size_t)32 * (64 * 2 + 64) + (size_t)ntb * 32 * (a->tile_n * 2 + 64);
+      hipStream_t stm = (hipStream_t)stream;
+      if (a->tile_n == 64 && ntb == 9) hipLaunchKernelGGL((igemm_wgrad_mt_kernel<64, 9>), gridm, dim3(256), ldsm, stm, *a);
+      else if (a->tile_n == 64 && ntb == 4) hipLaunchKernelGGL((igemm_wgrad_mt_kernel<64, 4>), gridm, dim3(256), ldsm, stm, *a);
+      else if (a->tile_n == 64 && ntb == 3) hipLaunchKernelGGL((igemm_wgrad_mt_kernel<64, 3>), gridm, dim3(256), ldsm, stm, *a);
+      else if (a->tile_n == 128 && ntb == 4) hipLaunchKernelGGL((igemm_wgrad_mt_kernel<128, 4>), gridm, dim3(256), ldsm, stm, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_mt_kernel<128, 3>), gridm, dim3(256), ldsm, stm, *a);
+      SEG_CHECK_LAUNCH("seg_igemm_wgrad (multi-tap)");
+      return SEG_OK;
+    }
+  }
   dim3 grid((unsigned)(rtiles * ktiles), (unsigned)(a->g.ncls * a->g.ntaps), (unsigned)a->splitk), block(256, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const int bm = a->tile_m, bn = a->tile_n;

@@ -270,11 +270,23 @@ def pick_tile_fwd(M, n_rows, ncls):
     return tm, tn
 
 
-def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], nentries):
+def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
+    """Mirror of seg_wgrad_taps_per_block() (csrc/igemm.hip); tests/test_cabi.py keeps the two in step."""
+    if variant != 0 or tile_m != 64:
+        return 1
+    if tile_n == 64:
+        return ntaps if ntaps in (9, 4, 3) else 1
+    if tile_n == 128:
+        return 4 if ntaps == 4 else 3 if ntaps in (9, 3) else 1
+    return 1
+
+
+def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0):
     tm = 128 if n_rows > 64 else 64
     tn = 128 if max(seg_cs) > 64 else 64
-    tiles = _cdiv(n_rows, tm) * sum(_cdiv(c, tn) for c in seg_cs) * nentries
-    splitk = max(1, min(_cdiv(1536, tiles), _cdiv(M, 256)))
+    ntb = wgrad_taps_per_block(tm, tn, ntaps, variant)
+    tiles = _cdiv(n_rows, tm) * sum(_cdiv(c, tn) for c in seg_cs) * ncls * (ntaps // ntb)
+    splitk = max(1, min(_cdiv(1536, tiles), _cdiv(M, 512)))
     return tm, tn, splitk
 
 
@@ -500,7 +512,7 @@ class ConvOp(Op):
         wg.dz_cs, wg.dz_coff = self.z.cs, 0
         wg.dw = st.ptr(self.wname, "G").value
         wg.Kpad, wg.n_rows = self.Kpad, self.n_rows
-        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs], self.g_fwd.ncls * self.g_fwd.ntaps)
+        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs], self.g_fwd.ncls, self.g_fwd.ntaps, WGRAD_VARIANT)
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = WGRAD_VARIANT
