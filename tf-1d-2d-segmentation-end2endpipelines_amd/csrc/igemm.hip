@@ -29,19 +29,22 @@ __device__ __forceinline__ void mma_step(const unsigned char* A, const unsigned 
                                          f16v (&acc)[TM][TN]) {
   const int fswz = (fr >> 2) & 3;
   if constexpr (sizeof(T) == 2) {
+    // all eight fragment reads of the 32-deep step are issued before the first MFMA: the LDS latency is paid once
+    h8 af[2][TM], bf[2][TN];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = ((ks * 2 + fh) ^ fswz) << 4;
-      h8 af[TM], bf[TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * ROW_BYTES + ch);
+      for (int a = 0; a < TM; ++a) af[ks][a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * ROW_BYTES + ch);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * ROW_BYTES + ch);
+      for (int b = 0; b < TN; ++b) bf[ks][b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * ROW_BYTES + ch);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
   } else {
     const int c0 = ((2 * fh) ^ fswz) << 4, c1 = ((2 * fh + 1) ^ fswz) << 4;
     f4 a0[TM], a1[TM], b0[TN], b1[TN];
@@ -346,7 +349,7 @@ struct ChunkDesc {      // one (segment, 32-channel chunk) of the K loop
 };
 
 template <int BM, int BN, int NT>
-__global__ __launch_bounds__(256) void igemm_fwd2_kernel(const seg_igemm_fwd_args p) {
+__global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type only exists for the gfx950 pass; the host pass needs just the stub
   constexpr int WMv = BM / 64, WNv = BN / 64;
   static_assert(WMv * WNv == 4, "four waves, 64x64 each");
@@ -449,14 +452,18 @@ __global__ __launch_bounds__(256) void igemm_fwd2_kernel(const seg_igemm_fwd_arg
     constexpr int t = decltype(tc)::value;
     if (!d.valid) return;
     unsigned char* sb = smem + stage * STAGE;
-    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.ptr), 0, d.bytes, 0x00020000);
-    const int sdelta = t_delta[t] * d.cs2;
+    // make the descriptor provably wave-uniform (otherwise hipcc wraps every buffer op in a waterfall loop)
+    const unsigned long long pa = (unsigned long long)d.ptr;
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pa), phi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+    void* ubase = (void*)(((unsigned long long)phi << 32) | plo);
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, __builtin_amdgcn_readfirstlane(d.bytes), 0x00020000);
+    const int sdelta = t_delta[t] * __builtin_amdgcn_readfirstlane(d.cs2);
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const unsigned voff = ((a_mask[i] >> t) & 1u) ? d.vbase[i] + (unsigned)sdelta : OOB_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (wave * AL + i) * 1024), 16, voff, 0, 0, 0);
     }
-    const int soff = t_w[t] + d.wsoff;
+    const int soff = t_w[t] + __builtin_amdgcn_readfirstlane(d.wsoff);
 #pragma unroll
     for (int i = 0; i < BL; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + A_BYTES + (wave * BL + i) * 1024), 16, b_voff[i], soff, 0, 0);
