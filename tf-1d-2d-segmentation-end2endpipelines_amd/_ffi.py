@@ -98,6 +98,9 @@ def lib():
     """Load libseg_hip.so once.  Raises (never falls back) when the HIP extension is missing."""
     global _lib
     if _lib is None:
+        # torch first: its wheel bundles a HIP runtime (libamdhip64); loading ours before it would pull in a second
+        # copy from /opt/rocm and kernels would be launched on a runtime that never saw torch's device / streams
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
