@@ -74,6 +74,14 @@ __device__ __forceinline__ void mma_step(const unsigned char* A, const unsigned 
 constexpr int STG_LD = 36;        // floats per staging row (32 + 4 pad, keeps 16-B alignment)
 constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;   // 4 waves
 
+// XCD-aware block order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin over them): physical
+// block b runs on XCD b % 8; give each XCD one contiguous range of logical tiles so that neighbouring tiles (which
+// share halo rows / the dz tile / weight panels) meet in the same L2.  Bijective for any block count.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -207,12 +215,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int cls = blockIdx.y;
   const seg_geom& g = p.g;
   const int HW = g.Hl * g.Wl;
   const int M = g.N * HW;
   const int mblocks = (M + BM - 1) / BM;
-  const int mb = blockIdx.x % mblocks, nb = blockIdx.x / mblocks;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int cls = lin / gridDim.x, bx = lin - cls * gridDim.x;
+  const int mb = bx % mblocks, nb = bx / mblocks;
   const int m0 = mb * BM, n0 = nb * BN;
 
   // ---- per-thread load coordinates: row = (tid >> 2) + 64 r, 16-B chunk = tid & 3
@@ -362,12 +371,13 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNv, wn = wave % WNv;
-  const int cls = blockIdx.y;
   const seg_geom& g = p.g;
   const int HW = g.Hl * g.Wl;
   const int M = g.N * HW;
   const int mblocks = (M + BM - 1) / BM;
-  const int mb = blockIdx.x % mblocks, nb = blockIdx.x / mblocks;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int cls = lin / gridDim.x, bx = lin - cls * gridDim.x;
+  const int mb = bx % mblocks, nb = bx / mblocks;
   const int m0 = mb * BM, n0 = nb * BN;
 
   int t_delta[NT], t_w[NT];
@@ -550,8 +560,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
 
   // ---- which (row tile, segment, K tile, tap entry, pixel split) is this block
   const int rtiles = (p.n_rows + BM - 1) / BM;
-  const int rt = blockIdx.x % rtiles;
-  int kt = blockIdx.x / rtiles;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int bz = lin / (gridDim.x * gridDim.y), by = (lin / gridDim.x) % gridDim.y, bx = lin % gridDim.x;
+  const int rt = bx % rtiles;
+  int kt = bx / rtiles;
   int seg = 0;
   for (; seg < p.nseg; ++seg) {
     int t = (p.seg_c[seg] + BN - 1) / BN;
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
     kt -= t;
   }
   if (seg >= p.nseg) return;
-  const int e = blockIdx.y;                        // cls * ntaps + tap
+  const int e = by;                                // cls * ntaps + tap
   const int cls = e / g.ntaps;
   const int dy = g.tap_dy[e], dx = g.tap_dx[e], widx = g.tap_w[e];
   const int oy = g.oy[cls], ox = g.ox[cls];
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
 
   int per = (M + p.splitk - 1) / p.splitk;
   per = (per + PK - 1) / PK * PK;
-  const int pbeg = blockIdx.z * per;
+  const int pbeg = bz * per;
   const int pend = min(M, pbeg + per);
   if (pbeg >= pend) return;
 
@@ -762,8 +774,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_mt_kernel(const seg_igemm_
   const int M = g.N * HW;
 
   const int rtiles = (p.n_rows + BM - 1) / BM;
-  const int rt = blockIdx.x % rtiles;
-  int kt = blockIdx.x / rtiles;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int bz = lin / (gridDim.x * gridDim.y), by = (lin / gridDim.x) % gridDim.y, bx = lin % gridDim.x;
+  const int rt = bx % rtiles;
+  int kt = bx / rtiles;
   int seg = 0;
   for (; seg < p.nseg; ++seg) {
     int t = (p.seg_c[seg] + BN - 1) / BN;
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_mt_kernel(const seg_igemm_
   }
   if (seg >= p.nseg) return;
   const int groups = g.ntaps / NTB;
-  const int cls = blockIdx.y / groups, tgrp = blockIdx.y % groups;
+  const int cls = by / groups, tgrp = by % groups;
   const int e0 = cls * g.ntaps + tgrp * NTB;
   int t_dy[NTB], t_dx[NTB], t_w[NTB];
 #pragma unroll
@@ -785,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_mt_kernel(const seg_igemm_
 
   int per = (M + p.splitk - 1) / p.splitk;
   per = (per + PK - 1) / PK * PK;
-  const int pbeg = blockIdx.z * per;
+  const int pbeg = bz * per;
   const int pend = min(M, pbeg + per);
   if (pbeg >= pend) return;
 
