@@ -174,6 +174,13 @@ int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, in
 int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
                     float alpha, int32_t accumulate_mask, seg_stream_t stream);
 
+/* ---- channel-slice copy (materialised concatenate(axis=-1), unet_variants.py:95, when a consumer cannot walk the
+ * pieces: BatchNormalization over cat[c3x3,c5x5,c7x7] in MultiResBlock).  dst[p][dst_coff+c] (+)= src[p][src_coff+c],
+ * c < C; element granular (the pieces need not start on 8-channel boundaries).  The backward is the same call with
+ * src/dst swapped and accumulate set.                                                                         */
+int seg_copy_channels(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff,
+                      int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream);
+
 /* ---- attention gating multiply (unet_variants.py:81): y[p][c] = a[p][c] * r[p][0]                           */
 int seg_mul_bcast_fwd(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs,
                       seg_stream_t stream);
@@ -274,6 +281,8 @@ int seg_head_fwd_f32(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t 
 int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H,
                      int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act,
                      void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream);
+int seg_copy_channels_f32(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff,
+                          int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream);
 int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                         seg_stream_t stream);
 int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);

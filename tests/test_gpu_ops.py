@@ -474,6 +474,24 @@ def test_add_act_fwd_bwd(n, act):
         assert rel(from_dev(dxs[k], 16), ref) < 2e-3
 
 
+def test_copy_channels_unaligned_concat():
+    """cat[5ch, 10ch, 16ch] -> 31 channels (MultiResBlock widths for w = 32): pieces start at channel 5 and 15."""
+    N, H, W = 2, 6, 7
+    parts = [h16(torch.randn(N, H, W, c)) for c in (5, 10, 16)]
+    dst = torch.zeros((N, H, W, 32), dtype=torch.float16, device="cuda")
+    devs = [to_dev_nhwc(t) for t in parts]
+    off = 0
+    for t, d in zip(parts, devs):
+        ffi.call("seg_copy_channels", P(d), d.shape[3], 0, P(dst), 32, off, t.shape[3], N * H * W, 0, stream())
+        off += t.shape[3]
+    back = to_dev_nhwc(h16(torch.randn(N, H, W, 10)))
+    ref_back = back[..., :10].float().cpu() + parts[1]
+    ffi.call("seg_copy_channels", P(dst), 32, 5, P(back), 16, 0, 10, N * H * W, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dst[..., :31].float().cpu(), torch.cat(parts, -1)) and float(dst[..., 31:].abs().max()) == 0.0
+    assert rel(back[..., :10].float().cpu(), ref_back) < 1e-3 and float(back[..., 10:].abs().max()) == 0.0
+
+
 def test_mul_bcast_fwd_bwd():
     N, H, W, Cc = 2, 6, 5, 40
     a = h16(torch.randn(N, H, W, Cc)).requires_grad_(True)

@@ -1182,6 +1182,21 @@ __global__ __launch_bounds__(TPB) void unpack_kernel(const T* x, float* y, int64
   }
 }
 
+// channel-slice copy at element granularity (materialises a concatenation whose pieces do not start on 8-channel
+// boundaries: MultiResBlock's cat[c3x3, c5x5, c7x7] feeding BatchNormalization, unet_variants.py:95-96)
+template <typename T>
+__global__ __launch_bounds__(TPB) void copy_channels_kernel(const T* src, int src_cs, int src_coff, T* dst, int dst_cs, int dst_coff,
+                                                            int C, int64_t npix, int accumulate) {
+  const int64_t n = npix * C;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const int64_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const float v = (float)src[pix * src_cs + src_coff + c];
+    T* d = dst + pix * dst_cs + dst_coff + c;
+    *d = (T)(accumulate ? v + (float)*d : v);
+  }
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -1560,3 +1575,16 @@ static int seg_unpack_f32_impl(const void* x, float* y, int64_t npix, int32_t C,
 }
 extern "C" int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<half_t>(x, y, npix, C, cs, coff, stream); }
 extern "C" int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<float>(x, y, npix, C, cs, coff, stream); }
+
+template <typename T>
+static int seg_copy_channels_impl(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C,
+                                  int64_t npix, int32_t accumulate, seg_stream_t stream) {
+  SEG_CHECK_ARG(src && dst && C > 0 && npix > 0 && src_coff >= 0 && dst_coff >= 0 && src_coff + C <= src_cs && dst_coff + C <= dst_cs,
+                "seg_copy_channels: bad arguments (C=%d src %d+%d/%d dst %d+%d/%d)", C, src_coff, C, src_cs, dst_coff, C, dst_cs);
+  hipLaunchKernelGGL((copy_channels_kernel<T>), dim3(grid_for(npix * C)), dim3(TPB), 0, ST(stream), (const T*)src, src_cs, src_coff, (T*)dst,
+                     dst_cs, dst_coff, C, npix, accumulate);
+  SEG_CHECK_LAUNCH("seg_copy_channels");
+  return SEG_OK;
+}
+extern "C" int seg_copy_channels(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream) { return seg_copy_channels_impl<half_t>(src, src_cs, src_coff, dst, dst_cs, dst_coff, C, npix, accumulate, stream); }
+extern "C" int seg_copy_channels_f32(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream) { return seg_copy_channels_impl<float>(src, src_cs, src_coff, dst, dst_cs, dst_coff, C, npix, accumulate, stream); }

@@ -723,6 +723,35 @@ class BNOp(Op):
              float(self.alpha), self.acc, s)
 
 
+class ConcatOp(Op):
+    """Materialised concatenate(axis=-1) for consumers that cannot walk the pieces (BatchNormalization over a
+    concatenation: MultiResBlock, unet_variants.py:95-96).  Convolutions never need it (virtual concat)."""
+
+    def __init__(self, m, segs: List[Tuple[DevTensor, int]], out: DevTensor):
+        self.m, self.segs, self.out = m, segs, out
+
+    def forward(self, training):
+        off = 0
+        for t, c in self.segs:
+            call("seg_copy_channels", _p(t.buf), t.cs, 0, _p(self.out.buf), self.out.cs, off, c, t.npix, 0, _stream())
+            off += c
+
+    def plan_backward(self):
+        self.live = self.out.gw
+        self.accs = [t.claim() if (self.live and t.needs_grad) else None for t, _c in self.segs]
+
+    def backward(self):
+        if not self.live:
+            return
+        off = 0
+        for (t, c), acc in zip(self.segs, self.accs):
+            if acc is not None:
+                if not acc and t.cs > c:
+                    t.grad.zero_()                     # keep the channel padding of a freshly written gradient at zero
+                call("seg_copy_channels", _p(self.out.grad), self.out.cs, off, _p(t.grad), t.cs, 0, c, t.npix, acc, _stream())
+            off += c
+
+
 class AddOp(Op):
     """add([...]) / Add() (+ activation); also used with one input as a plain Activation layer."""
 
@@ -1027,7 +1056,11 @@ class SegModel:
     def _materialise(self, val, i) -> DevTensor:
         v = val[i]
         if isinstance(v, list):
-            raise NotImplementedError("BatchNormalization over a concatenation (MultiResBlock) is not lowered yet")
+            n = self.graph.nodes[i]
+            out = DevTensor(n.name, self.N, *n.shape)
+            self.ops.append(ConcatOp(self, v, out))
+            val[i] = out
+            return out
         return v
 
     # ---------------------------------------------------------------- weights
