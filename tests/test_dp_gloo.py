@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
         m.seed = rank                                   # different initial weights per rank ...
         m.build(2)
         before = m.store.P.clone()
-        d = dp.DataParallel(m, bucket_elems=1 << 16)
+        d = dp.DataParallel(m, bucket_elems=1 << 16, overlap=False)
         gathered = [torch.zeros_like(m.store.P) for _ in range(world)]
         dist.all_gather(gathered, m.store.P)
         ok2 = all(torch.equal(gathered[0], g) for g in gathered)        # ... identical after the broadcast from rank 0
@@ -51,7 +51,24 @@ def _worker(rank, world, port, q):
         m.backward = noop_backward                       # keep the per-rank gradient we planted
         m.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m.out_heads])
         ok3 = bool((m.store.G == 3.0).all()) and m.world_size == world and "seg_adam_step" in M._DryRun.log
-        q.put((rank, ok1, ok2, ok3, None))
+        # 3. overlapped exchange: the backward sweep hands over op-aligned slices as they become final
+        m2 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
+        m2.build(2)
+        d2 = dp.DataParallel(m2, bucket_elems=20000, overlap=True)
+        bk = m2.grad_buckets()
+        tiles = bk[0][0] == 0 and bk[-1][1] == m2.store.n_train and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
+        order = [oi for _lo, _hi, oi in bk]
+        seen = []
+        orig_hook = m2.bucket_hook
+        m2.bucket_hook = lambda lo, hi: (seen.append((lo, hi)), orig_hook(lo, hi))
+        for op in m2.ops:                                  # plant a per-rank gradient instead of running kernels
+            op.backward = (lambda: None)
+        real_zero = m2.store.G.zero_
+        m2.store.G.zero_ = lambda: m2.store.G.fill_(float(rank + 1))
+        m2.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m2.out_heads])
+        ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen == [(lo, hi) for lo, hi, _ in reversed(bk)] \
+            and bool((m2.store.G[:m2.store.n_train] == 3.0).all()) and not d2.pending
+        q.put((rank, ok1, ok2, ok3 and ok4, None))
         dist.destroy_process_group()
     except Exception as e:      # pragma: no cover
         import traceback

@@ -59,14 +59,25 @@ def broadcast_flat(buf: torch.Tensor, src: int = 0, group=None):
 
 
 class DataParallel:
-    """Wraps a built SegModel: identical initial weights on every rank, gradient all-reduce before Adam."""
+    """Wraps a built SegModel: identical initial weights on every rank, gradient all-reduce before Adam.
 
-    def __init__(self, model, bucket_elems: int = 64 << 20, group=None):
+    overlap=True (default): the backward sweep hands over each slice of the flat gradient buffer as soon as the
+    ops that own it are done (model.grad_buckets(): slices follow op boundaries; the backward order is reverse
+    creation order, so the decoder's slices become final first) and the all-reduce of that slice is launched
+    asynchronously on RCCL's stream while the remaining backward kernels keep running; Adam waits for all of them."""
+
+    def __init__(self, model, bucket_elems: int = 32 << 20, group=None, overlap: bool = True):
         self.model, self.group, self.bucket_elems = model, group, bucket_elems
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.pending = []
         model.world_size = self.world_size
-        model.allreduce = self._allreduce
+        model.bucket_elems = bucket_elems
+        if overlap and self.world_size > 1:
+            model.bucket_hook = self._bucket_ready
+            model.allreduce = self._wait_all
+        else:
+            model.allreduce = self._allreduce
         if self.world_size > 1:
             st = model.store
             broadcast_flat(st.P, 0, group)
@@ -75,6 +86,14 @@ class DataParallel:
 
     def _allreduce(self, flat_grads: torch.Tensor):
         allreduce_flat(flat_grads, self.bucket_elems, self.group)
+
+    def _bucket_ready(self, lo: int, hi: int):
+        self.pending.append(dist.all_reduce(self.model.store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _wait_all(self, flat_grads: torch.Tensor):
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
 
     def train_step(self, x_local, targets_local, loss=None):
         return self.model.train_step(x_local, targets_local, loss)

@@ -336,6 +336,7 @@ class ParamStore:
 
     def __init__(self):
         self.slots: Dict[str, Slot] = {}
+        self.order: List[Tuple[int, int]] = []
         self.n_train = 0
         self.n_state = 0
         self.P = self.G = self.M = self.V = self.P16 = self.S = None
@@ -343,6 +344,7 @@ class ParamStore:
     def add(self, spec, numel, to_engine, from_engine):
         s = Slot(spec, numel, to_engine, from_engine, spec.trainable)
         if spec.trainable:
+            self.order.append((self.n_train, _cdiv(numel, self.ALIGN) * self.ALIGN))    # creation order == op order
             s.off = self.n_train
             self.n_train += _cdiv(numel, self.ALIGN) * self.ALIGN
         else:
@@ -865,7 +867,9 @@ class SegModel:
         self.lr, self.beta_1, self.beta_2, self.epsilon = 2e-4, 0.9, 0.999, 1e-7
         self.loss_name = "mse"
         self.world_size = 1
-        self.allreduce = None          # set by dp.DataParallel
+        self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
+        self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
+        self.bucket_elems = 32 << 20
         if batch_size is not None:
             self.build(batch_size)
 
@@ -938,7 +942,18 @@ class SegModel:
                                           "(not implemented yet)")
             return v
 
+        self._op_grad_range: Dict[int, Tuple[int, int]] = {}     # index in self.ops -> [lo, hi) of its slice of G
+        n_ops_seen, n_train_seen = 0, 0
+
+        def note_ranges():
+            nonlocal n_ops_seen, n_train_seen
+            if len(self.ops) > n_ops_seen:
+                if self.store.n_train > n_train_seen:
+                    self._op_grad_range[len(self.ops) - 1] = (n_train_seen, self.store.n_train)
+                n_ops_seen, n_train_seen = len(self.ops), self.store.n_train
+
         for i in live:
+            note_ranges()
             if i in done:
                 continue
             n = g.nodes[i]
@@ -1035,11 +1050,12 @@ class SegModel:
                 val[i] = out
             else:
                 raise NotImplementedError(f"layer kind {k!r} ({n.name}) is not lowered to HIP yet")
+        note_ranges()
         for oi in g.outputs:
             if not isinstance(val[oi], HeadOp):
                 raise NotImplementedError("model outputs must be 1x1 conv heads")
         self.out_heads = [val[oi] for oi in g.outputs]
-        # ---- parameters
+        # ---- parameters: ops allocate in creation order, so each op owns one contiguous slice of the flat buffers
         self.store.allocate()
         for op in self.ops:
             if isinstance(op, ConvOp):
@@ -1137,6 +1153,22 @@ class SegModel:
         outs = [o.cpu().numpy() for o in self.forward(x, training=False)]
         return outs if len(outs) > 1 else outs[0]
 
+    def grad_buckets(self) -> List[Tuple[int, int, int]]:
+        """[(lo, hi, op_index)]: contiguous slices of the flat gradient buffer, each complete once the backward sweep
+        (which walks the ops in reverse) has finished op `op_index`.  Slices follow op boundaries, are at least
+        bucket_elems long (except the last) and tile [0, n_train) exactly."""
+        owners = sorted(self._op_grad_range.items())          # ascending op index == ascending offsets
+        out, lo, first = [], None, None
+        for oi, (a, b) in owners:
+            if lo is None:
+                lo, first = a, oi
+            if b - lo >= self.bucket_elems:
+                out.append((lo, b, first))
+                lo = None
+        if lo is not None:
+            out.append((lo, owners[-1][1][1], first))
+        return out
+
     def backward(self, grads: Optional[Sequence[torch.Tensor]] = None):
         """Backward pass.  grads[i] = dLoss/d output_i (fp32, same shape as the output); None: use the gradients the
         loss kernels left in the heads' dy buffers."""
@@ -1150,8 +1182,14 @@ class SegModel:
             call("seg_absmax", _p(h.dy), h.dy.numel(), _p(self.amax), s)
         call("seg_grad_scale", _p(self.amax), GRAD_TARGET, _p(self.gs), s)
         self.store.G.zero_()
-        for op in reversed(self.ops):
-            op.backward()
+        ready = {}
+        if self.bucket_hook is not None:
+            for lo, hi, oi in self.grad_buckets():
+                ready.setdefault(oi, []).append((lo, hi))
+        for oi in range(len(self.ops) - 1, -1, -1):
+            self.ops[oi].backward()
+            for lo, hi in ready.get(oi, ()):
+                self.bucket_hook(lo, hi)
 
     def compute_loss(self, targets: Sequence[torch.Tensor], loss: Optional[str] = None) -> torch.Tensor:
         """Sum over outputs of the mean-reduced loss (unit weights, 2DCNN/Train.py:322); fills the heads' dy buffers."""
