@@ -73,7 +73,7 @@ def test_igemm_fwd_cases(case):
     assert rel(st[:, :case["cout"]], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (256, 64)])
+@pytest.mark.parametrize("tile", [(128, 128), (256, 64), (128, 64)])
 @pytest.mark.parametrize("case", [
     dict(shape=(2, 24, 20), cins=[64, 32, 64], cout=128, k=(3, 3), kind="conv", s=(1, 1)),      # 9 taps, concat, ragged M
     dict(shape=(2, 16, 16), cins=[3], cout=64, k=(3, 3), kind="conv", s=(1, 1)),                 # channel padding via range check
@@ -83,6 +83,12 @@ def test_igemm_fwd_cases(case):
     dict(shape=(2, 12, 8), cins=[64], cout=32, k=(4, 4), kind="convT", s=(2, 2)),                # 4 classes x 4 taps
     dict(shape=(4, 1, 96), cins=[32], cout=16, k=(1, 2), kind="convT", s=(1, 2)),                # 2 classes x 1 tap
     dict(shape=(2, 8, 8), cins=[256], cout=160, k=(3, 3), kind="conv", s=(1, 1)),                # two N tiles, one ragged
+    # every segment >= 64 channels and Kpad % 64 == 0 -> the 64-deep K step (128-B LDS rows, 2-stage ring)
+    dict(shape=(2, 20, 24), cins=[64, 128, 64], cout=128, k=(3, 3), kind="conv", s=(1, 1)),
+    dict(shape=(3, 9, 13), cins=[96, 96], cout=72, k=(3, 3), kind="conv", s=(1, 1)),             # 96 = 64 + 32: partial second step
+    dict(shape=(2, 12, 8), cins=[128], cout=64, k=(4, 4), kind="convT", s=(2, 2)),
+    dict(shape=(4, 1, 200), cins=[64], cout=64, k=(1, 3), kind="conv", s=(1, 1)),
+    dict(shape=(2, 16, 16), cins=[192], cout=48, k=(1, 1), kind="conv", s=(1, 1)),               # 1 tap: prefetch crosses 1 chunk per step
 ], ids=lambda c: f"{c['kind']}{c['k']}s{c['s']}-{c['cins']}->{c['cout']}")
 def test_igemm_fwd_lds_dma_pipeline(case, tile):
     """The 3-stage LDS-DMA kernel (tiles 128x128 / 256x64) on every tap count it is instantiated for."""
@@ -118,7 +124,7 @@ def test_dgrad_lds_dma_pipeline(kind, k, s):
     ffi.call("seg_transpose_w", P(Ed), P(wt), n_rows, T, Kpad, rows_pad, stream())
     g = (M.geom_convT_dgrad if kind == "convT" else M.geom_conv_dgrad)(N, H, W, *k, *s)
     dzd = to_dev_nhwc(dz)
-    for tile in [(256, 64), (128, 128)]:
+    for tile in [(256, 64), (128, 128), (128, 64)]:
         dx = torch.zeros((N, H, W, cin), dtype=torch.float16, device="cuda")
         a = ffi.IgemmFwdArgs()
         a.g, a.nseg = g, 1
@@ -131,7 +137,7 @@ def test_dgrad_lds_dma_pipeline(kind, k, s):
         assert rel(from_dev(dx, cin), x.grad) < 2e-3, tile
 
 
-@pytest.mark.parametrize("tile", [(64, 64), (128, 128), (256, 64)])
+@pytest.mark.parametrize("tile", [(64, 64), (128, 128), (256, 64), (128, 64)])
 def test_dgrad_split_output_over_concat_segments(tile):
     """One data-gradient launch for a conv over a virtual concat [40ch, 64ch, 8ch]: N = K axis of the forward weight,
     the epilogue writes span 0 plainly, accumulates into span 1 and discards span 2 (tensor needing no gradient)."""

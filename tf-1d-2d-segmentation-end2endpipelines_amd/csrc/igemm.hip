@@ -84,6 +84,32 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
+// 64-deep K step on 128-B LDS rows (fp16): 8 chunks per row, chunk index XOR (row >> 1) & 7, so that the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.  4 x (TM x TN) MFMAs.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_step64(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
+                                           f16v (&acc)[TM][TN]) {
+  const int fswz = (fr >> 1) & 7;      // tile rows start at multiples of 32, so (row >> 1) & 7 depends on fr only
+#pragma unroll
+  for (int kp = 0; kp < 2; ++kp) {     // two pairs of 16-deep MFMA steps; fragment reads of a pair issued together
+    h8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = (((kp * 2 + ks) * 2 + fh) ^ fswz) << 4;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[ks][a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * 128 + ch);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[ks][b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * 128 + ch);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // shared epilogue of the forward kernels: bias, BN partial statistics, activation, channel-padding mask, then each
 // 32x32 accumulator tile goes through a per-wave LDS slab so that global stores are 8 channels (16 / 32 B) per lane.
@@ -357,14 +383,20 @@ struct ChunkDesc {      // one (segment, 32-channel chunk) of the K loop
   unsigned vbase[AL];   // per-lane byte offset of (centre pixel, this lane's 16-B chunk), OOB_OFF when masked
 };
 
-template <int BM, int BN, int NT>
-__global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(const seg_igemm_fwd_args p) {
+template <int BM, int BN, int NT, int BKE, int NSTAGE>
+__global__ __launch_bounds__(256, ((BM == 128 && (BKE == 32 || BN == 64)) ? 3 : 2)) void igemm_fwd2_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type only exists for the gfx950 pass; the host pass needs just the stub
-  constexpr int WMv = BM / 64, WNv = BN / 64;
-  static_assert(WMv * WNv == 4, "four waves, 64x64 each");
-  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
-  constexpr int AL = BM / 64, BL = BN / 64;      // 16-row LDS-DMA instructions per wave and stage
+  constexpr int WMv = BM / 64, WNv = 4 / WMv;     // waves along M / N; every wave owns 64 rows x (BN / WNv) columns
+  constexpr int TNw = BN / (32 * WNv);            // 32-column accumulator tiles per wave (2, or 1 for the 128x64 tile)
+  static_assert(WMv * WNv == 4 && TNw >= 1 && TNw * 32 * WNv == BN, "tile / wave layout");
+  static_assert(BKE == 32 || BKE == 64, "K step of 32 or 64 channels");
+  constexpr int ROWB = BKE * 2;                  // bytes per LDS row (one K step of one pixel / one output channel)
+  constexpr int CPR = ROWB / 16;                 // 16-B chunks per row
+  constexpr int RPI = 1024 / ROWB;               // rows per LDS-DMA wave instruction (64 lanes x 16 B)
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int AL = BM / (4 * RPI), BL = BN / (4 * RPI);     // LDS-DMA instructions per wave and stage
   constexpr int LPI = AL + BL;                   // vector-memory operations per wave and K step
+  constexpr int DIST = NSTAGE - 1;               // K steps of loads in flight
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -389,12 +421,13 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
   }
 
   // ---- per-lane rows of the A tile: wave w, instruction i covers rows (w*AL + i)*16 .. +15, lane -> (row, chunk)
-  const int lrow = lane >> 2, lch = lane & 3;
+  const int lrow = lane / CPR, lch = lane % CPR;
+  auto swz = [](int row) { return CPR == 4 ? (row >> 2) & 3 : (row >> 1) & 7; };
   int a_pix[AL], a_chs[AL];
   unsigned a_mask[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
-    const int row = (wave * AL + i) * 16 + lrow;
+    const int row = (wave * AL + i) * RPI + lrow;
     const int m = m0 + row;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
@@ -404,7 +437,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
     const int jj = rem - ii * g.Wl;
     const int cy = ii * g.isy, cx = jj * g.isx;
     a_pix[i] = (n * g.Hin + cy) * g.Win + cx;
-    a_chs[i] = lch ^ ((row >> 2) & 3);
+    a_chs[i] = lch ^ swz(row);
     unsigned msk = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -417,23 +450,23 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
   unsigned b_voff[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    const int row = (wave * BL + i) * 16 + lrow;
+    const int row = (wave * BL + i) * RPI + lrow;
     const int nrow = n0 + row;
-    const int chs = lch ^ ((row >> 2) & 3);
+    const int chs = lch ^ swz(row);
     b_voff[i] = nrow < p.n_rows ? (unsigned)((nrow * g.T_total * p.Kpad + chs * 8) * 2) : OOB_OFF;
   }
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.n_rows * g.T_total * p.Kpad * 2, 0x00020000);
 
-  f16v acc[2][2];
+  f16v acc[2][TNw];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TNw; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
   int nchunks = 0;
-  for (int s = 0; s < p.nseg; ++s) nchunks += (p.seg_c[s] + 31) / 32;
+  for (int s = 0; s < p.nseg; ++s) nchunks += (p.seg_c[s] + BKE - 1) / BKE;
   const int niter = nchunks * NT;
   const int pixbytes = g.N * g.Hin * g.Win;
 
@@ -455,7 +488,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
     }
   };
   auto advance = [&](int& seg, int& c0) {
-    c0 += 32;
+    c0 += BKE;
     if (seg < p.nseg && c0 >= p.seg_c[seg]) { c0 = 0; ++seg; }
   };
   auto issue = [&](auto tc, const ChunkDesc<AL>& d, int stage) {
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const unsigned voff = ((a_mask[i] >> t) & 1u) ? d.vbase[i] + (unsigned)sdelta : OOB_OFF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (wave * AL + i) * 1024), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (wave * AL + i) * 1024), 16, voff, 0, 0, 0);   // RPI rows
     }
     const int soff = t_w[t] + __builtin_amdgcn_readfirstlane(d.wsoff);
 #pragma unroll
@@ -487,26 +520,27 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
   advance(cseg, cc0);
   setup(D[2], cseg, cc0);
 
-  // prologue: K steps 0 and 1
+  // prologue: the first DIST K steps
   issue(std::integral_constant<int, 0>{}, D[0], 0);
-  issue(std::integral_constant<int, 1 % NT>{}, D[1 / NT], 1);
+  if constexpr (DIST == 2) issue(std::integral_constant<int, 1 % NT>{}, D[1 / NT], 1);
 
   const int fr = lane & 31, fh = lane >> 5;
   int it = 0, stage = 0;
   for (int ck = 0; ck < nchunks; ++ck) {
     static_for<0, NT>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      constexpr int t2 = (t + 2) % NT, k2 = (t + 2) / NT;
-      if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPI) : "memory");
+      constexpr int t2 = (t + DIST) % NT, k2 = (t + DIST) / NT;
+      if (DIST == 2 && it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      int st2 = stage + 2;
-      if (st2 >= 3) st2 -= 3;
+      int st2 = stage + DIST;
+      if (st2 >= NSTAGE) st2 -= NSTAGE;
       issue(std::integral_constant<int, t2>{}, D[k2], st2);
       const unsigned char* A = smem + stage * STAGE;
-      mma_step<half_t, 2, 2>(A, A + A_BYTES, wm * 64, wn * 64, fr, fh, acc);
-      stage = stage == 2 ? 0 : stage + 1;
+      if constexpr (BKE == 32) mma_step<half_t, 2, TNw>(A, A + A_BYTES, wm * 64, wn * (32 * TNw), fr, fh, acc);
+      else mma_step64<2, TNw>(A, A + A_BYTES, wm * 64, wn * (32 * TNw), fr, fh, acc);
+      stage = stage == NSTAGE - 1 ? 0 : stage + 1;
       ++it;
     });
     D[0] = D[1];
@@ -515,23 +549,47 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm_fwd2_kernel(co
     setup(D[2], cseg, cc0);
   }
   __syncthreads();
-  conv_epilogue<half_t, 2, 2, WMv, BN>(p, acc, smem, tid, m0 + wm * 64, wn * 64, n0, wm, cls, mblocks, mb, M, HW);
+  conv_epilogue<half_t, 2, TNw, WMv, BN>(p, acc, smem, tid, m0 + wm * 64, wn * (32 * TNw), n0, wm, cls, mblocks, mb, M, HW);
 #endif
 }
 
 // explicit instantiations (the launchers below live outside this namespace)
-template __global__ void igemm_fwd2_kernel<128, 128, 1>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<128, 128, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<128, 128, 3>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<128, 128, 4>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<128, 128, 9>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<128, 128, 16>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<256, 64, 1>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<256, 64, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<256, 64, 3>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<256, 64, 4>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<256, 64, 9>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd2_kernel<256, 64, 16>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 1, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 1, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 2, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 2, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 3, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 3, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 4, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 4, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 9, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 9, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 16, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 128, 16, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 1, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 1, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 2, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 2, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 3, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 3, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 4, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 4, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 9, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 9, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 16, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<256, 64, 16, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 1, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 1, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 2, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 2, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 3, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 3, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 4, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 4, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 9, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 9, 64, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 16, 32, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 16, 64, 2>(const seg_igemm_fwd_args);
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient:  D[n][k] = sum_pix dz[pix][n] * in[pix + tap][k]   (reduction dimension = pixels)
@@ -977,7 +1035,7 @@ bool check_segs(const Args& a, const char* who) {
 static bool fwd2_eligible(const seg_igemm_fwd_args& a) {
   static const bool force_v1 = std::getenv("SEG_IGEMM_V1") != nullptr;
   if (force_v1) return false;
-  if (!((a.tile_m == 128 && a.tile_n == 128) || (a.tile_m == 256 && a.tile_n == 64))) return false;
+  if (!((a.tile_m == 128 && (a.tile_n == 128 || a.tile_n == 64)) || (a.tile_m == 256 && a.tile_n == 64))) return false;
   const int nt = a.g.ntaps;
   if (!(nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 9 || nt == 16)) return false;
   const long lim = 1L << 30;
@@ -988,23 +1046,42 @@ static bool fwd2_eligible(const seg_igemm_fwd_args& a) {
   return true;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BKE, int NS>
 static void launch_fwd2_nt(const seg_igemm_fwd_args& a, dim3 grid, size_t lds, hipStream_t st) {
   switch (a.g.ntaps) {
-    case 1: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 1>), grid, dim3(256), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 2>), grid, dim3(256), lds, st, a); break;
-    case 3: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 3>), grid, dim3(256), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 4>), grid, dim3(256), lds, st, a); break;
-    case 9: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 9>), grid, dim3(256), lds, st, a); break;
-    default: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 16>), grid, dim3(256), lds, st, a); break;
+    case 1: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 1, BKE, NS>), grid, dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 2, BKE, NS>), grid, dim3(256), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 3, BKE, NS>), grid, dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 4, BKE, NS>), grid, dim3(256), lds, st, a); break;
+    case 9: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 9, BKE, NS>), grid, dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 16, BKE, NS>), grid, dim3(256), lds, st, a); break;
   }
+}
+
+// K-step depth of the LDS-DMA kernel: 64 channels (128-B rows = whole cache lines per pixel, half the barriers,
+// 2-stage ring) when every segment has at least 64 channels, else 32 (3-stage ring).  SEG_V2_BK=32|64 overrides.
+static int fwd2_bk(const seg_igemm_fwd_args& a) {
+  static const char* env = std::getenv("SEG_V2_BK");
+  if (env != nullptr) return std::atoi(env) == 64 ? 64 : 32;
+  if (a.Kpad & 63) return 32;
+  for (int s = 0; s < a.nseg; ++s)
+    if (a.seg_c[s] < 64) return 32;
+  return 64;
 }
 
 static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hipStream_t st) {
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a.g.ncls, 1);
-  const size_t lds = (size_t)3 * (a.tile_m + a.tile_n) * ROW_BYTES;      // >= epilogue staging
-  if (a.tile_m == 128) launch_fwd2_nt<128, 128>(a, grid, lds, st);
-  else launch_fwd2_nt<256, 64>(a, grid, lds, st);
+  if (fwd2_bk(a) == 64) {
+    const size_t lds = (size_t)2 * (a.tile_m + a.tile_n) * 128;     // >= epilogue staging (20.5 KB)
+    if (a.tile_m == 128 && a.tile_n == 128) launch_fwd2_nt<128, 128, 64, 2>(a, grid, lds, st);
+    else if (a.tile_m == 128) launch_fwd2_nt<128, 64, 64, 2>(a, grid, lds, st);
+    else launch_fwd2_nt<256, 64, 64, 2>(a, grid, lds, st);
+  } else {
+    const size_t lds = (size_t)3 * (a.tile_m + a.tile_n) * 64;
+    if (a.tile_m == 128 && a.tile_n == 128) launch_fwd2_nt<128, 128, 32, 3>(a, grid, lds, st);
+    else if (a.tile_m == 128) launch_fwd2_nt<128, 64, 32, 3>(a, grid, lds, st);
+    else launch_fwd2_nt<256, 64, 32, 3>(a, grid, lds, st);
+  }
   SEG_CHECK_LAUNCH("seg_igemm_fwd (LDS-DMA)");
   return SEG_OK;
 }

@@ -256,18 +256,18 @@ def unpack_gemm_weight(flat: np.ndarray, shape, cin_l, woff, n_rows, Kpad, trans
 
 
 def pick_tile_fwd(M, n_rows, ncls):
-    """(tile_m, tile_n).  256x64 and 128x128 run on the LDS-DMA pipelined kernel (fp16); the 64-row tiles are the
-    register-staged kernel and keep >= 2 blocks per CU busy on the small deep layers."""
-    if n_rows <= 64 and ncls * _cdiv(M, 256) >= 512:
-        return 256, 64
-    tn = 128 if n_rows > 64 else 64
-    tm = 128
-    blocks = lambda: ncls * _cdiv(M, tm) * _cdiv(n_rows, tn)
-    if blocks() < 512:
-        tm = 64
-    if blocks() < 512 and tn == 128:
-        tn = 64
-    return tm, tn
+    """(tile_m, tile_n).  256x64, 128x128 and 128x64 run on the LDS-DMA pipelined kernel (fp16); the 64-row tiles are
+    the register-staged kernel for problems too small to fill 256 CUs otherwise."""
+    blocks = lambda tm, tn: ncls * _cdiv(M, tm) * _cdiv(n_rows, tn)
+    if n_rows <= 64:
+        if blocks(256, 64) >= 512:
+            return 256, 64
+        return (128, 64) if blocks(128, 64) >= 256 else (64, 64)
+    if blocks(128, 128) >= 384:
+        return 128, 128
+    if blocks(128, 64) >= 256:
+        return 128, 64
+    return (64, 128) if blocks(64, 128) >= 256 else (64, 64)
 
 
 def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
