@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import zlib
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -629,7 +630,15 @@ class ConvOp(Op):
             a.seg_ptr[0] = dz.data_ptr()
             call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad:" + self.node.name)
         self.wg_args.dz = dz.data_ptr()
-        call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+        side = self.m.side_stream
+        if side is None:
+            call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+        else:
+            # the weight gradient is only needed by the optimiser: run it on a second stream so that this MFMA-bound
+            # kernel overlaps the HBM-bound BN / activation backward kernels of the layers that follow
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call("seg_igemm_wgrad", C.byref(self.wg_args), _stream(), flops=self.flops_fwd, tag="wgrad:" + self.node.name)
 
 
 def _pad_to(n):
@@ -869,6 +878,8 @@ class SegModel:
         self.world_size = 1
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
+        self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
+        self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
         if batch_size is not None:
             self.build(batch_size)
@@ -1066,6 +1077,8 @@ class SegModel:
             op.plan_backward()
         DevTensor.registry = None
         DevTensor.dtype = torch.float16
+        if self.use_side_stream and not _DryRun.on:
+            self.side_stream = torch.cuda.Stream()
         self.built = True
         return self
 
@@ -1189,7 +1202,11 @@ class SegModel:
         for oi in range(len(self.ops) - 1, -1, -1):
             self.ops[oi].backward()
             for lo, hi in ready.get(oi, ()):
+                if self.side_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self.side_stream)     # the slice includes weight gradients
                 self.bucket_hook(lo, hi)
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def compute_loss(self, targets: Sequence[torch.Tensor], loss: Optional[str] = None) -> torch.Tensor:
         """Sum over outputs of the mean-reduced loss (unit weights, 2DCNN/Train.py:322); fills the heads' dy buffers."""
