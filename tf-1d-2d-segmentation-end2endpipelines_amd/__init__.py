@@ -10,7 +10,10 @@ from .builders2d import unet_model_builder, model_selector, ENCODER_METHODS, SUP
 from . import builders1d
 from .builders1d import BCDUNet
 from .builders1d import UNet as UNet1D
+from . import harness
+from .harness import EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, fit, masks_from_predictions, mask_grey_levels
 
 __all__ = ["Graph", "Node", "ParamSpec", "Sym", "unet_model_builder", "model_selector", "ENCODER_METHODS",
-           "SUPPORTED_DECODERS", "builders1d", "BCDUNet", "UNet1D"]
+           "SUPPORTED_DECODERS", "builders1d", "BCDUNet", "UNet1D", "harness", "EarlyStopping", "ModelCheckpoint",
+           "ReduceLROnPlateau", "fit", "masks_from_predictions", "mask_grey_levels"]
 __version__ = "0.1.0"

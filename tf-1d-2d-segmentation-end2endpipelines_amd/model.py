@@ -1121,6 +1121,16 @@ class SegModel:
             out[name] = np.asarray(s.from_engine(src[s.off:s.off + s.numel]), np.float32).reshape(s.spec.shape)
         return out
 
+    def save_weights(self, path: str):
+        """.npz keyed by structural parameter names, Keras layouts (the reference saves .keras files, Train.py:375)."""
+        from .harness import save_weights_npz
+        save_weights_npz(self.get_weights(), path)
+
+    def load_weights(self, path: str):
+        """model.load_weights (Train.py:363,367)."""
+        from .harness import load_weights_npz
+        self.set_weights(load_weights_npz(path))
+
     def get_grads(self) -> Dict[str, np.ndarray]:
         """Gradients of the last backward pass, Keras layout (already divided by the internal gradient scale)."""
         st = self.store
