@@ -164,7 +164,9 @@ def main():
         KP = modelmod.KernelProfile
         KP.records.clear()
         KP.on = True
+        side, model.side_stream = model.side_stream, None     # per-kernel durations: every launch alone on one stream
         model.train_step(x, targets)
+        model.side_stream = side
         KP.on = False
         summ = KP.summary()
         if args.dump_launches:

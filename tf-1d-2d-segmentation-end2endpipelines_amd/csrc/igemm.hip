@@ -110,6 +110,32 @@ __device__ __forceinline__ void mma_step64(const unsigned char* A, const unsigne
   }
 }
 
+// eight stored elements kept in their memory format (16 B of fp16 / 32 B of fp32) until they are needed
+template <typename T> struct Raw8;
+template <> struct Raw8<half_t> {
+  typedef u4 type;
+  static __device__ __forceinline__ void zero(type& r) { r = u4{0u, 0u, 0u, 0u}; }
+  static __device__ __forceinline__ void load(const half_t* p, type& r) { r = ld16(p); }
+  static __device__ __forceinline__ void add(const type& r, float* f) {
+    float o[8];
+    unpack8(r, o);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] += o[t];
+  }
+};
+template <> struct Raw8<float> {
+  struct type { f4 a, b; };
+  static __device__ __forceinline__ void zero(type& r) { r.a = f4{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+  static __device__ __forceinline__ void load(const float* p, type& r) {
+    r.a = *reinterpret_cast<const f4*>(p);
+    r.b = *reinterpret_cast<const f4*>(p + 4);
+  }
+  static __device__ __forceinline__ void add(const type& r, float* f) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { f[t] += r.a[t]; f[4 + t] += r.b[t]; }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // shared epilogue of the forward kernels: bias, BN partial statistics, activation, channel-padding mask, then each
 // 32x32 accumulator tile goes through a per-wave LDS slab so that global stores are 8 channels (16 / 32 B) per lane.
@@ -131,9 +157,35 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   for (int b = 0; b < TN; ++b) { s_sum[b] = 0.f; s_sq[b] = 0.f; }
   // rows this lane stores: (lane >> 2) + 16 * pass within each 32-row tile, 8 channels (lane & 3) * 8 ..
   const int st_row = lane >> 2, st_ch = lane & 3;
+  // destination of each 32-column tile: the single output, or one span of the split output (wave-uniform)
+  T* obase[TN];
+  int ocs[TN], ocol[TN], olim[TN], oacc[TN];
+  bool any_acc = false;
 #pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    long opix[2];
+  for (int b = 0; b < TN; ++b) {
+    const int nbase = n0 + col0 + b * 32;
+    obase[b] = out;
+    ocs[b] = p.out_cs; ocol[b] = p.out_coff + nbase; olim[b] = p.n_rows - nbase; oacc[b] = p.accumulate;
+    if (p.nout > 0) {
+      int start = 0;
+      obase[b] = nullptr;
+      olim[b] = 0;
+      for (int o = 0; o < p.nout; ++o) {
+        if (nbase >= start && nbase < start + p.out_span[o]) {
+          obase[b] = (T*)p.out_ptr[o];
+          ocs[b] = p.out_cs_o[o];
+          ocol[b] = nbase - start;
+          olim[b] = p.out_cs_o[o] - ocol[b];
+          oacc[b] = p.out_acc[o];
+        }
+        start += p.out_span[o];
+      }
+    }
+    any_acc |= oacc[b] != 0;
+  }
+  long opix[TM][2];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       int m = row0 + a * 32 + st_row + 16 * ps;
@@ -142,11 +194,28 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
         int rem = m - n * HW;
         int i = rem / g.Wl;
         int j = rem - i * g.Wl;
-        opix[ps] = ((long)n * g.Hout + (i * g.osy + g.oy[cls])) * g.Wout + (j * g.osx + g.ox[cls]);
+        opix[a][ps] = ((long)n * g.Hout + (i * g.osy + g.oy[cls])) * g.Wout + (j * g.osx + g.ox[cls]);
       } else {
-        opix[ps] = -1;
+        opix[a][ps] = -1;
       }
     }
+  // accumulating outputs (data gradients summed over the consumers of a tensor): fetch every old value up front, so
+  // the read-modify-write costs one memory latency per block instead of one per 32x32 tile and row pass
+  typename Raw8<T>::type oldv[TM][TN][2];
+  if (any_acc) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          Raw8<T>::zero(oldv[a][b][ps]);
+          if (oacc[b] && opix[a][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b])
+            Raw8<T>::load(obase[b] + (size_t)opix[a][ps] * ocs[b] + ocol[b] + st_ch * 8, oldv[a][b][ps]);
+        }
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int nbase = n0 + col0 + b * 32;
@@ -166,38 +235,15 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
         if (nzero) v = 0.f;
         stg[rt * STG_LD + fr] = v;
       }
-      // destination of this 32-column tile: the single output, or one span of the split output
-      T* obase = out;
-      int ocs = p.out_cs, ocol = p.out_coff + nbase, olim = p.n_rows - nbase, oacc = p.accumulate;
-      if (p.nout > 0) {
-        int start = 0;
-        obase = nullptr;
-        olim = 0;
-        for (int o = 0; o < p.nout; ++o) {
-          if (nbase >= start && nbase < start + p.out_span[o]) {
-            obase = (T*)p.out_ptr[o];
-            ocs = p.out_cs_o[o];
-            ocol = nbase - start;
-            olim = p.out_cs_o[o] - ocol;
-            oacc = p.out_acc[o];
-          }
-          start += p.out_span[o];
-        }
-      }
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const int rt = st_row + 16 * ps;
         f4 v0 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8]);
         f4 v1 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8 + 4]);
-        if (opix[ps] >= 0 && obase != nullptr && st_ch * 8 < olim) {
-          T* dst = obase + (size_t)opix[ps] * ocs + ocol + st_ch * 8;
+        if (opix[a][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b]) {
+          T* dst = obase[b] + (size_t)opix[a][ps] * ocs[b] + ocol[b] + st_ch * 8;
           float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          if (oacc) {
-            float o[8];
-            load8(dst, o);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) f[t] += o[t];
-          }
+          if (any_acc) Raw8<T>::add(oldv[a][b][ps], f);
           store8(dst, f);
         }
       }
@@ -1058,20 +1104,25 @@ static void launch_fwd2_nt(const seg_igemm_fwd_args& a, dim3 grid, size_t lds, h
   }
 }
 
-// K-step depth of the LDS-DMA kernel: 64 channels (128-B rows = whole cache lines per pixel, half the barriers,
-// 2-stage ring) when every segment has at least 64 channels, else 32 (3-stage ring).  SEG_V2_BK=32|64 overrides.
-static int fwd2_bk(const seg_igemm_fwd_args& a) {
-  static const char* env = std::getenv("SEG_V2_BK");
+// K-step depth of the LDS-DMA kernel.  64 channels = 128-B rows (whole cache lines per pixel), half the barriers, but a
+// 2-stage ring (one K step of loads in flight) and, for the 128x128 tile, 2 instead of 3 blocks per CU.  Measured on
+// MI355X (tools/op_bench.py): it wins when the K loop is long and the grid deep enough that other blocks of the CU cover a
+// block's load latency; 32 wins for short K loops (transposed convs, data gradients of 64-channel layers, whose
+// read-modify-write epilogue wants the third block) and for grids of about one block per CU.  SEG_V2_BK=32|64 overrides.
+static int fwd2_bk(const seg_igemm_fwd_args& a, long nblocks) {
+  const char* env = std::getenv("SEG_V2_BK");     // read per call: tools/op_bench.py flips it between launches
   if (env != nullptr) return std::atoi(env) == 64 ? 64 : 32;
   if (a.Kpad & 63) return 32;
-  for (int s = 0; s < a.nseg; ++s)
-    if (a.seg_c[s] < 64) return 32;
-  return 64;
+  int cmin = 1 << 30;
+  for (int s = 0; s < a.nseg; ++s) cmin = a.seg_c[s] < cmin ? a.seg_c[s] : cmin;
+  if (a.tile_m == 128 && a.tile_n == 128) return cmin >= 128 ? 64 : 32;
+  if (cmin < 64) return 32;
+  return (nblocks >= 512 && (long)a.g.ntaps * a.Kpad >= 1024) ? 64 : 32;
 }
 
 static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hipStream_t st) {
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a.g.ncls, 1);
-  if (fwd2_bk(a) == 64) {
+  if (fwd2_bk(a, (long)mblocks * nblocks * a.g.ncls) == 64) {
     const size_t lds = (size_t)2 * (a.tile_m + a.tile_n) * 128;     // >= epilogue staging (20.5 KB)
     if (a.tile_m == 128 && a.tile_n == 128) launch_fwd2_nt<128, 128, 64, 2>(a, grid, lds, st);
     else if (a.tile_m == 128) launch_fwd2_nt<128, 64, 64, 2>(a, grid, lds, st);

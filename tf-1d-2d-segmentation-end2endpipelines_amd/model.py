@@ -256,12 +256,14 @@ def unpack_gemm_weight(flat: np.ndarray, shape, cin_l, woff, n_rows, Kpad, trans
     return out_k.reshape(shape)
 
 
-def pick_tile_fwd(M, n_rows, ncls):
+def pick_tile_fwd(M, n_rows, ncls, ktot=1 << 30):
     """(tile_m, tile_n).  256x64, 128x128 and 128x64 run on the LDS-DMA pipelined kernel (fp16); the 64-row tiles are
-    the register-staged kernel for problems too small to fill 256 CUs otherwise."""
+    the register-staged kernel for problems too small to fill 256 CUs otherwise.  ktot = taps x K channels: with a
+    short reduction (the 2x2 transposed convs) the smaller tile's extra blocks per CU hide more of the prologue /
+    epilogue latency than the larger tile saves in weight re-reads (measured, tools/op_bench.py)."""
     blocks = lambda tm, tn: ncls * _cdiv(M, tm) * _cdiv(n_rows, tn)
     if n_rows <= 64:
-        if blocks(256, 64) >= 512:
+        if blocks(256, 64) >= 512 and ktot >= 1024:
             return 256, 64
         return (128, 64) if blocks(128, 64) >= 256 else (64, 64)
     if blocks(128, 128) >= 384:
@@ -467,7 +469,7 @@ class ConvOp(Op):
             self.bn_name = bn.name
             self.eps, self.momentum = float(bn.attrs["eps"]), float(bn.attrs["momentum"])
         # ---- tiles and scratch
-        self.tm, self.tn = pick_tile_fwd(self.M, n_rows, self.g_fwd.ncls)
+        self.tm, self.tn = pick_tile_fwd(self.M, n_rows, self.g_fwd.ncls, self.g_fwd.ntaps * self.Kpad)
         self.nparts = self.g_fwd.ncls * _cdiv(self.M, self.tm)
         dev = _dev()
         if self.has_bn:
@@ -591,7 +593,7 @@ class ConvOp(Op):
                 else:
                     a.out_ptr[s_i], a.out_acc[s_i] = None, 0
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
-            a.tile_m, a.tile_n = pick_tile_fwd(Md, self.Kpad, 1)
+            a.tile_m, a.tile_n = pick_tile_fwd(Md, self.Kpad, 1, self.g_dgrad.ntaps * self.rows_pad)
             self.dg_args.append((a, zero_first, fl))
 
     def backward(self):
