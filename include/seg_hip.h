@@ -108,9 +108,14 @@ typedef struct seg_igemm_wgrad_args {
   float scale;
   const float* scale_ptr;        /* device scalar or NULL                                                  */
   int32_t tile_m, tile_n;        /* rows (n) x K-columns tile: 128 or 64                                   */
-  int32_t variant;               /* 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores         */
+  int32_t variant;               /* 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores,
+                                    2: LDS-DMA halo tiles (3x3 stride-1 'same' only, fp16; tile_m/tile_n ignored:
+                                       64 rows x 64-channel planes x 9 taps per block, splitk splits the
+                                       64-pixel patches; requires seg_wgrad_halo_patch(&g) != 0)              */
 } seg_igemm_wgrad_args;
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
+/* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */
+int seg_wgrad_halo_patch(const seg_geom* g);
 /* taps one block of seg_igemm_wgrad handles for this tile (layers with <= 64 output channels use a multi-tap
  * kernel that reads the dz tile once for 3 / 4 / 9 taps); the host sizes `splitk` with it.                       */
 int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int variant);

@@ -71,6 +71,21 @@ def test_host_and_library_agree_on_wgrad_taps_per_block(built):
                     assert L.seg_wgrad_taps_per_block(tm, tn, nt, v) == M.wgrad_taps_per_block(tm, tn, nt, v)
 
 
+def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
+    ffi = importlib.import_module(PKG + "._ffi")
+    M = importlib.import_module(PKG + ".model")
+    L = ffi.lib()
+    geoms = [M.geom_conv(2, h, w, kh, kw, s, s) for (h, w) in ((2, 32), (4, 16), (8, 8), (6, 48), (3, 32), (16, 24), (1, 64))
+             for (kh, kw) in ((3, 3), (1, 3), (1, 1)) for s in (1, 2)]
+    geoms += [M.geom_convT(2, 8, 32, 4, 4, 2, 2), M.geom_conv_dgrad(2, 8, 32, 3, 3, 1, 1), M.geom_convT_dgrad(2, 8, 32, 4, 4, 2, 2)]
+    seen = set()
+    for g in geoms:
+        got = L.seg_wgrad_halo_patch(ctypes.byref(g))
+        assert got == M.wgrad_halo_patch(g)
+        seen.add(got)
+    assert seen == {0, 16, 32}
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     ffi = importlib.import_module(PKG + "._ffi")
     monkeypatch.setattr(ffi, "_lib", None)

@@ -248,6 +248,36 @@ def test_wgrad_matches_autograd(case, variant):
     assert rel(torch.from_numpy(got), kern.grad) < 1e-4          # fp32 accumulate of exact fp16 products
 
 
+@pytest.mark.parametrize("case", [
+    dict(shape=(2, 8, 32), cins=[64], cout=64, sk=1),                     # 32-wide patches, 2 rows
+    dict(shape=(3, 6, 64), cins=[64, 64, 8], cout=64, sk=5),              # several planes, a ragged one, uneven split
+    dict(shape=(2, 16, 16), cins=[128, 72], cout=40, sk=3),               # 16-wide patches (4 rows), rows / channels padded
+    dict(shape=(1, 4, 96), cins=[24], cout=136, sk=2),                    # three row tiles, the last ragged
+    dict(shape=(2, 12, 48), cins=[192], cout=128, sk=7),                  # W = 48 -> 16-wide patches
+    dict(shape=(1, 2, 32), cins=[8], cout=8, sk=1),                       # a single patch: every tap but the centre row is border
+], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
+def test_wgrad_halo_kernel_matches_autograd(case):
+    """variant 2: LDS-DMA halo tiles + transposed LDS reads, 3x3 stride-1 'same' convs."""
+    N, H, W = case["shape"]
+    xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]
+    cin = sum(case["cins"])
+    kshape = (3, 3, cin, case["cout"])
+    kern = torch.zeros(kshape, requires_grad=True)
+    y = K.conv2d_same(torch.cat(xs, -1), kern, None, (1, 1))
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    got = U.igemm_wgrad(xs, dz, kshape, "conv", (1, 1), 2, case["sk"], None)
+    assert rel(torch.from_numpy(got), kern.grad) < 1e-4
+
+
+def test_wgrad_halo_kernel_refuses_other_geometries():
+    xs = [h16(torch.randn(2, 8, 8, 64))]
+    with pytest.raises(U.ffi.SegHipError, match="variant 2"):
+        U.igemm_wgrad(xs, h16(torch.randn(2, 8, 8, 64)), (3, 3, 64, 64), "conv", (1, 1), 2, 1, None)       # W = 8
+    with pytest.raises(U.ffi.SegHipError, match="variant 2"):
+        U.igemm_wgrad([h16(torch.randn(2, 8, 32, 64))], h16(torch.randn(2, 16, 64, 32)), (4, 4, 32, 64), "convT", (2, 2), 2, 1, None)
+
+
 # ------------------------------------------------------------------------------------------------ BatchNormalization
 def _bn_setup(N, H, W, Cc, act):
     cs = U.r8(Cc)

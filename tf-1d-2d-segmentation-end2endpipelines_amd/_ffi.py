@@ -48,6 +48,7 @@ _PROTOS = {
     "seg_igemm_fwd": ([C.POINTER(IgemmFwdArgs), vp], C.c_int),
     "seg_igemm_wgrad": ([C.POINTER(IgemmWgradArgs), vp], C.c_int),
     "seg_wgrad_taps_per_block": ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+    "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),
@@ -114,6 +115,7 @@ def lib():
         L.seg_last_error.argtypes = []
         L.seg_last_error.restype = C.c_char_p
         L.seg_wgrad_taps_per_block.restype = C.c_int
+        L.seg_wgrad_halo_patch.restype = C.c_int
         if L.seg_abi_version() != 1:
             raise ImportError("libseg_hip.so ABI version mismatch; rebuild")
         _lib = L

@@ -1034,6 +1034,180 @@ template __global__ void igemm_wgrad_mt_kernel<64, 3>(const seg_igemm_wgrad_args
 template __global__ void igemm_wgrad_mt_kernel<128, 4>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_mt_kernel<128, 3>(const seg_igemm_wgrad_args);
 
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient of the 3x3 / stride-1 / 'same' convolutions (variant 2, fp16) - 95 % of the UNet-family MACs.
+// One block owns 64 output channels x one 64-channel plane of one concat segment x all 9 taps, and walks a range of
+// 64-pixel patches (R rows x C columns, C = 32 or 16).  Per patch the dz tile [64 px][64 co] and ONE input halo tile
+// [(R+2)(C+2) px][64 ci] are brought in by LDS-DMA (2-stage ring, one barrier per patch); the nine shifted input
+// operands are nine row offsets into that halo tile, read - like dz - with the transposing ds_read_b64_tr_b16.
+// LDS rows are 128 B with the 32-B units XOR-swizzled by bit 1 of the row, which keeps the four rows x two units a
+// 32-lane group reads on 64 distinct banks for every tap shift; with the shift a compile-time constant the swizzled
+// lane offset is one of four precomputed registers and the rest of the address is the instruction's immediate.
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igemm_wgrad_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int R = 64 / C, HC = C + 2, HROWS = (R + 2) * HC;
+  constexpr int NI_IN = (HROWS + 7) / 8;                  // LDS-DMA wave instructions per halo tile (8 rows of 128 B each)
+  constexpr int NI_W = (NI_IN + 3) / 4;                   // ... per wave
+  constexpr int Z_BYTES = 64 * 128, IN_BYTES = NI_IN * 1024, STAGE = Z_BYTES + IN_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+  typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const seg_geom& g = p.g;
+  const int H = g.Hin, W = g.Win;
+
+  // ---- which (64-row tile, 64-channel plane, patch range) is this block
+  const int rtiles = (p.n_rows + 63) / 64;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+  const int bz = lin / gridDim.x, bx = lin - bz * gridDim.x;
+  const int rt = bx % rtiles;
+  int pl = bx / rtiles;
+  int seg = 0;
+  for (; seg < p.nseg; ++seg) {
+    const int t = (p.seg_c[seg] + 63) / 64;
+    if (pl < t) break;
+    pl -= t;
+  }
+  if (seg >= p.nseg) return;
+  const int r0 = rt * 64, c0 = pl * 64;
+  const int sc = p.seg_c[seg], cs2 = p.seg_cs[seg] * 2, dzcs2 = p.dz_cs * 2;
+  const int PW = W / C, PH = H / R;
+  const int npatch = g.N * PH * PW;
+  const int per = (npatch + p.splitk - 1) / p.splitk;
+  const int q0 = bz * per, q1 = min(npatch, q0 + per);
+  if (q0 >= q1) return;
+
+  // wave-uniform descriptors (readfirstlane returns int: keep the halves unsigned, or a low word with bit 31 set
+  // sign-extends into the high word of the base address)
+  auto uniform_ptr = [](const void* q) -> void* {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+  };
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.seg_ptr[seg]), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * cs2), 0x00020000);
+  const auto rsrc_dz = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.dz), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * dzcs2), 0x00020000);
+
+  // ---- LDS-DMA lane constants.  A wave instruction fills 8 LDS rows (lane >> 3) x 8 chunks (lane & 7); the chunk a
+  // lane fetches from memory is its LDS chunk XOR the row's swizzle
+  const int lrow = lane >> 3, lch = lane & 7;
+  unsigned z_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + lrow;
+    const int gch = lch ^ (((row >> 1) & 1) << 2);
+    const int yy = row / C, xx = row % C;
+    z_voff[i] = (r0 + gch * 8 < p.n_rows) ? (unsigned)((yy * W + xx) * dzcs2 + (p.dz_coff + r0 + gch * 8) * 2) : OOB_OFF;
+  }
+  int in_dy[NI_W], in_dx[NI_W], in_cb[NI_W];      // halo pixel relative to the patch origin, channel byte offset (-1: no load)
+#pragma unroll
+  for (int k = 0; k < NI_W; ++k) {
+    const int i = wave + 4 * k;
+    const int row = i * 8 + lrow;
+    const int gch = lch ^ (((row >> 1) & 1) << 2);
+    const int yy = row / HC, xx = row - yy * HC;
+    in_dy[k] = yy - 1;
+    in_dx[k] = xx - 1;
+    in_cb[k] = (i < NI_IN && row < HROWS && c0 + gch * 8 < sc) ? (c0 + gch * 8) * 2 : -1;
+  }
+  auto issue = [&](int q, int stage) {
+    const int n = q / (PH * PW);
+    const int rem = q - n * (PH * PW);
+    const int py = rem / PW;
+    const int y0 = py * R, x0 = (rem - py * PW) * C;
+    unsigned char* sb = smem + stage * STAGE;
+    const int zs = ((n * H + y0) * W + x0) * dzcs2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dz, (lds_ptr_t)(sb + (wave * 2 + i) * 1024), 16, z_voff[i], zs, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NI_W; ++k) {
+      if (wave + 4 * k < NI_IN) {
+        const int y = y0 + in_dy[k], x = x0 + in_dx[k];
+        const bool ok = in_cb[k] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)(((n * H + y) * W + x) * cs2 + in_cb[k]) : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(sb + Z_BYTES + (wave + 4 * k) * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- transposed-read lane offsets: pixel j = 8 (tg >> 1) + tq of a 16-pixel MFMA K block, 8 bytes at column
+  // 16 (tg & 1) + 4 tp of the wave's 32-channel slice.  Row = base + j: bit 1 of the row (the swizzle) depends on
+  // (base & 3) + j only, so four lane offsets cover every base.
+  const int tg = lane >> 4, tt = lane & 15, tq = tt >> 2, tp = tt & 3;
+  const int j = 8 * (tg >> 1) + tq;
+  const int cbA = (wm * 32 + 16 * (tg & 1) + 4 * tp) * 2, cbB = (wn * 32 + 16 * (tg & 1) + 4 * tp) * 2;
+  const int offA = j * 128 + (cbA ^ (((j >> 1) & 1) << 6));
+  int offB[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) offB[r] = j * 128 + (cbB ^ ((((r + j) >> 1) & 1) << 6));
+  auto trfrag = [&](const unsigned char* ad) -> h8 {
+    s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
+    s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * 128));
+    h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
+    return h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
+  };
+
+  f16v acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  auto compute = [&](int stage) {
+    const unsigned char* Zs = smem + stage * STAGE;
+    const unsigned char* Is = Zs + Z_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      constexpr int KPR = C / 16;                                  // K blocks per patch row
+      const int yy = kb / KPR, xx0 = (kb % KPR) * 16;
+      const h8 af = trfrag(Zs + kb * 16 * 128 + offA);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
+        const h8 bf = trfrag(Is + hb * 128 + offB[hb & 3]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  int stage = 0;
+  issue(q0, 0);
+  for (int q = q0; q < q1; ++q) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (q + 1 < q1) issue(q + 1, stage ^ 1);
+    compute(stage);
+    stage ^= 1;
+  }
+
+  float sc_mul = p.scale;
+  if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
+  float* dw = p.dw;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int kcol = c0 + wn * 32 + fr;
+  if (kcol < sc) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int widx = g.tap_w[t];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+        if (row < p.n_rows) atomicAdd(dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol, acc[t][q] * sc_mul);
+      }
+    }
+  }
+#endif
+}
+template __global__ void igemm_wgrad_halo_kernel<32>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<16>(const seg_igemm_wgrad_args);
+
 bool check_geom(const seg_geom& g, const char* who) {
   if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Hl <= 0 || g.Wl <= 0 || g.Hout <= 0 || g.Wout <= 0) {
     seg_set_error("%s: non-positive dimension", who);
@@ -1191,6 +1365,18 @@ extern "C" int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int v
   return 1;
 }
 
+// patch width (32 or 16 pixels; the patch is 64 / width rows high) of the halo-tile weight-gradient kernel for this
+// geometry, 0 when the geometry is not a 3x3 / stride-1 / 'same' convolution it can tile
+extern "C" int seg_wgrad_halo_patch(const seg_geom* g) {
+  if (g == nullptr || g->ncls != 1 || g->ntaps != 9 || g->isy != 1 || g->isx != 1 || g->osy != 1 || g->osx != 1) return 0;
+  if (g->Hl != g->Hin || g->Wl != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->oy[0] != 0 || g->ox[0] != 0) return 0;
+  for (int t = 0; t < 9; ++t)
+    if (g->tap_dy[t] != t / 3 - 1 || g->tap_dx[t] != t % 3 - 1) return 0;
+  if (g->Win % 32 == 0 && g->Hin % 2 == 0) return 32;
+  if (g->Win % 16 == 0 && g->Hin % 4 == 0) return 16;
+  return 0;
+}
+
 template <typename T>
 static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_wgrad: null args");
@@ -1203,7 +1389,27 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   SEG_CHECK_ARG((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64),
                 "seg_igemm_wgrad: tile %dx%d", a->tile_m, a->tile_n);
   SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "seg_igemm_wgrad: splitk=%d", a->splitk);
-  SEG_CHECK_ARG(a->variant == 0 || a->variant == 1, "seg_igemm_wgrad: variant=%d", a->variant);
+  SEG_CHECK_ARG(a->variant >= 0 && a->variant <= 2, "seg_igemm_wgrad: variant=%d", a->variant);
+  if (a->variant == 2) {
+    SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_wgrad: variant 2 (LDS-DMA halo tiles) is fp16 only");
+    const int pc = seg_wgrad_halo_patch(&a->g);
+    SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' geometry with W %% 16 == 0 and H %% 4 == 0 (or W %% 32 == 0, H %% 2 == 0)");
+    const long pix = (long)a->g.N * a->g.Hin * a->g.Win;
+    SEG_CHECK_ARG(pix * a->dz_cs * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
+    int planes = 0;
+    for (int s = 0; s < a->nseg; ++s) {
+      SEG_CHECK_ARG(pix * a->seg_cs[s] * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
+      planes += (a->seg_c[s] + 63) / 64;
+    }
+    if constexpr (sizeof(T) == 2) {
+      dim3 gridh((unsigned)(((a->n_rows + 63) / 64) * planes), 1, (unsigned)a->splitk);
+      hipStream_t sth = (hipStream_t)stream;
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32>), gridh, dim3(256), (size_t)2 * (8192 + 17 * 1024), sth, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16>), gridh, dim3(256), (size_t)2 * (8192 + 14 * 1024), sth, *a);
+    }
+    SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
+    return SEG_OK;
+  }
   const int variant = (sizeof(T) == 4) ? 1 : a->variant;      // fp32: transposing-store form only
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
   int ktiles = 0;

@@ -41,6 +41,7 @@ from .graph import Graph, Node
 BN_PARTS_BWD = 512
 GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
 WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
+WGRAD_HALO = os.environ.get("SEG_WGRAD_HALO", "1") != "0"      # variant 2 (LDS-DMA halo tiles) for the 3x3 stride-1 layers
 
 
 def _r8(v):
@@ -284,7 +285,42 @@ def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
     return 1
 
 
+def wgrad_halo_patch(g: Geom) -> int:
+    """Mirror of seg_wgrad_halo_patch() (csrc/igemm.hip): patch width of the LDS-DMA halo-tile weight-gradient kernel
+    (variant 2) for this geometry, 0 when it is not a 3x3 / stride-1 / 'same' convolution the kernel can tile."""
+    if g.ncls != 1 or g.ntaps != 9 or (g.isy, g.isx, g.osy, g.osx) != (1, 1, 1, 1):
+        return 0
+    if (g.Hl, g.Wl, g.Hout, g.Wout) != (g.Hin, g.Win, g.Hin, g.Win) or g.oy[0] != 0 or g.ox[0] != 0:
+        return 0
+    if any(g.tap_dy[t] != t // 3 - 1 or g.tap_dx[t] != t % 3 - 1 for t in range(9)):
+        return 0
+    if g.Win % 32 == 0 and g.Hin % 2 == 0:
+        return 32
+    if g.Win % 16 == 0 and g.Hin % 4 == 0:
+        return 16
+    return 0
+
+
+HALO_BLOCKS = 512          # resident blocks of the variant-2 kernel: 2 per CU x 256 CUs
+
+
+def pick_split_halo(M, n_rows, seg_cs: Sequence[int]):
+    """Patch-range split of the variant-2 kernel: fill whole rounds of HALO_BLOCKS co-resident blocks, keep at least 8
+    patches (512 pixels) per block."""
+    tiles = _cdiv(n_rows, 64) * sum(_cdiv(c, 64) for c in seg_cs)
+    npatch = M // 64
+    best, best_eff = 1, 0.0
+    for sk in range(1, max(1, min(npatch // 8, _cdiv(2 * HALO_BLOCKS, tiles))) + 1):
+        blocks = tiles * sk
+        eff = blocks / (_cdiv(blocks, HALO_BLOCKS) * HALO_BLOCKS)
+        if eff > best_eff + 1e-9:
+            best, best_eff = sk, eff
+    return best
+
+
 def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0):
+    if variant == 2:
+        return 64, 64, pick_split_halo(M, n_rows, seg_cs)
     tm = 128 if n_rows > 64 else 64
     tn = 128 if max(seg_cs) > 64 else 64
     ntb = wgrad_taps_per_block(tm, tn, ntaps, variant)
@@ -517,10 +553,13 @@ class ConvOp(Op):
         wg.dz_cs, wg.dz_coff = self.z.cs, 0
         wg.dw = st.ptr(self.wname, "G").value
         wg.Kpad, wg.n_rows = self.Kpad, self.n_rows
-        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs], self.g_fwd.ncls, self.g_fwd.ntaps, WGRAD_VARIANT)
+        variant = WGRAD_VARIANT
+        if variant == 0 and self.m.dtype == "f16" and WGRAD_HALO and wgrad_halo_patch(self.g_fwd):
+            variant = 2         # 3x3 stride-1 layers: LDS-DMA halo-tile kernel
+        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs], self.g_fwd.ncls, self.g_fwd.ntaps, variant)
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
-        wg.variant = WGRAD_VARIANT
+        wg.variant = variant
         self.wg_args = wg
 
     def post_step(self):
