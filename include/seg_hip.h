@@ -89,8 +89,13 @@ typedef struct seg_igemm_fwd_args {
   int32_t out_cs_o[SEG_MAX_SEG];
   int32_t out_acc[SEG_MAX_SEG];
   void* out_ptr[SEG_MAX_SEG];
+  int32_t variant;               /* 0: per-tap kernels (any geometry); 3: halo-tile kernel - fp16, 3x3 taps with
+                                    offsets in {-1,0,1}^2, stride 1, 'same'; a block owns a 256-pixel patch, so
+                                    tile_m must be 256 (tile_n 64 | 128) and seg_fwd_halo_patch(&g) != 0          */
 } seg_igemm_fwd_args;
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
+/* patch width (32: 8x32 pixels, 16: 16x16 pixels) the variant-3 kernel uses for this geometry; 0: not eligible   */
+int seg_fwd_halo_patch(const seg_geom* g);
 
 /* ---- implicit-GEMM weight gradient of the same layers:
  *   dw[n][tap_w][woff_seg + c] += scale * (*scale_ptr) * sum_pix dz[outpix][n] * in_seg[pix+tap][c]

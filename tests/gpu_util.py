@@ -46,7 +46,7 @@ def h16(x: torch.Tensor) -> torch.Tensor:
 
 
 def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0, want_stats=False, tile=None,
-               accumulate_into=None, f32=False):
+               accumulate_into=None, f32=False, variant=0):
     """xs: list of fp32 NHWC CPU tensors (virtual concat); kern: Keras layout numpy.  Returns (out fp32 NHWC CPU, stats)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kern.shape[:2]
@@ -85,7 +85,7 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
     a.act, a.alpha = ffi.ACT[act], alpha
     Mtot = N * g.Hl * g.Wl
     tm, tn = tile if tile else M.pick_tile_fwd(Mtot, n_rows, g.ncls)
-    a.tile_m, a.tile_n = tm, tn
+    a.tile_m, a.tile_n, a.variant = tm, tn, variant
     stats = None
     if want_stats:
         nparts = g.ncls * (-(-Mtot // tm))

@@ -249,6 +249,47 @@ def test_wgrad_matches_autograd(case, variant):
 
 
 @pytest.mark.parametrize("case", [
+    dict(shape=(2, 8, 32), cins=[64], cout=64, tile=(256, 64)),                     # one 8x32 patch per image, 3 taps per step
+    dict(shape=(1, 16, 64), cins=[64, 32, 8], cout=64, tile=(256, 64)),            # virtual concat, ragged chunks
+    dict(shape=(2, 16, 16), cins=[96], cout=40, tile=(256, 64)),                   # 16x16 patches, padded output channels
+    dict(shape=(2, 8, 64), cins=[64, 64], cout=128, tile=(256, 128)),              # 2x2 waves of 128 px x 64 channels
+    dict(shape=(1, 32, 32), cins=[40], cout=200, tile=(256, 128)),                 # two N tiles, the second ragged
+    dict(shape=(3, 16, 16), cins=[128, 24], cout=136, tile=(256, 128)),            # 16x16 patches, 128-wide tile
+    dict(shape=(1, 8, 32), cins=[8], cout=8, tile=(256, 64)),                      # smallest: one chunk of 8 channels
+], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-{c['tile']}")
+@pytest.mark.parametrize("mode", ["plain", "bias_relu_stats", "accumulate"])
+def test_conv_fwd_halo_kernel(case, mode):
+    """variant 3: one LDS-DMA halo tile per 32-channel chunk serves all nine taps."""
+    N, H, W = case["shape"]
+    xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]
+    cin, cout = sum(case["cins"]), case["cout"]
+    kern = h16(torch.from_numpy(rng.standard_normal((3, 3, cin, cout)).astype(np.float32) * 0.1)).numpy()
+    bias = rng.standard_normal(cout).astype(np.float32) if mode == "bias_relu_stats" else None
+    pre = K.conv2d_same(torch.cat(xs, -1), torch.from_numpy(kern), torch.from_numpy(bias) if bias is not None else None)
+    if mode == "accumulate":
+        base = h16(torch.randn(N, H, W, U.r8(cout)))
+        out, _, _ = U.igemm_conv(xs, kern, None, "conv", (1, 1), None, 0.0, False, case["tile"], accumulate_into=base, variant=3)
+        assert rel(out, pre + base[..., :cout]) < 2e-3
+        return
+    act = "relu" if mode == "bias_relu_stats" else None
+    out, st, pad = U.igemm_conv(xs, kern, bias, "conv", (1, 1), act, 0.0, mode == "bias_relu_stats", case["tile"], variant=3)
+    want = torch.relu(pre) if act else pre
+    assert rel(out, want) < 2e-3 and pad == 0.0        # fp16 output rounding
+    if st is not None:
+        assert rel(st[:, :cout], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-3
+
+
+def test_conv_fwd_halo_kernel_refuses_other_geometries():
+    kern = np.zeros((3, 3, 64, 64), np.float32)
+    with pytest.raises(U.ffi.SegHipError, match="variant 3"):
+        U.igemm_conv([h16(torch.randn(2, 8, 8, 64))], kern, None, "conv", (1, 1), None, 0.0, False, (256, 64), variant=3)        # W = 8
+    with pytest.raises(U.ffi.SegHipError, match="variant 3"):
+        U.igemm_conv([h16(torch.randn(2, 8, 32, 64))], kern, None, "conv", (1, 1), None, 0.0, False, (128, 64), variant=3)      # tile
+    with pytest.raises(U.ffi.SegHipError, match="variant 3"):
+        U.igemm_conv([h16(torch.randn(2, 16, 32, 64))], kern, None, "conv", (2, 2), None, 0.0, False, (256, 64), variant=3)     # stride
+
+
+@pytest.mark.parametrize("case", [
     dict(shape=(2, 8, 32), cins=[64], cout=64, sk=1),                     # 32-wide patches, 2 rows
     dict(shape=(3, 6, 64), cins=[64, 64, 8], cout=64, sk=5),              # several planes, a ragged one, uneven split
     dict(shape=(2, 16, 16), cins=[128, 72], cout=40, sk=3),               # 16-wide patches (4 rows), rows / channels padded

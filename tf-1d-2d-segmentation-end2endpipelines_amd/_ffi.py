@@ -30,7 +30,7 @@ class IgemmFwdArgs(C.Structure):
                 ("out_cs", C.c_int32), ("out_coff", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
                 ("alpha", C.c_float), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("tile_m", C.c_int32),
                 ("tile_n", C.c_int32), ("nout", C.c_int32), ("out_span", C.c_int32 * MAX_SEG), ("out_cs_o", C.c_int32 * MAX_SEG),
-                ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG)]
+                ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG), ("variant", C.c_int32)]
 
 
 class IgemmWgradArgs(C.Structure):
@@ -49,6 +49,7 @@ _PROTOS = {
     "seg_igemm_wgrad": ([C.POINTER(IgemmWgradArgs), vp], C.c_int),
     "seg_wgrad_taps_per_block": ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),
+    "seg_fwd_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),

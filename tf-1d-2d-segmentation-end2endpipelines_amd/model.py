@@ -285,6 +285,37 @@ def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
     return 1
 
 
+def fwd_halo_patch(g: Geom) -> int:
+    """Mirror of seg_fwd_halo_patch() (csrc/igemm.hip): patch width of the halo-tile forward / data-gradient kernel
+    (variant 3; 32 = 8x32-pixel patches, 16 = 16x16), 0 when the geometry is not a stride-1 'same' convolution with the
+    nine tap offsets {-1,0,1}^2 (in any order) on an image those patches tile."""
+    if g.ncls != 1 or g.ntaps != 9 or (g.isy, g.isx, g.osy, g.osx) != (1, 1, 1, 1):
+        return 0
+    if (g.Hl, g.Wl, g.Hout, g.Wout) != (g.Hin, g.Win, g.Hin, g.Win) or g.oy[0] != 0 or g.ox[0] != 0:
+        return 0
+    if {(g.tap_dy[t], g.tap_dx[t]) for t in range(9)} != {(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)}:
+        return 0
+    if g.Win % 32 == 0 and g.Hin % 8 == 0:
+        return 32
+    if g.Win % 16 == 0 and g.Hin % 16 == 0:
+        return 16
+    return 0
+
+
+FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
+FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
+
+
+def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
+    """(tile_m, tile_n, variant) of a forward / data-gradient launch."""
+    if f16 and FWD_HALO and fwd_halo_patch(g):
+        tn = 64 if n_rows <= 64 else 128
+        if (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
+            return 256, tn, 3
+    tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
+    return tm, tn, 0
+
+
 def wgrad_halo_patch(g: Geom) -> int:
     """Mirror of seg_wgrad_halo_patch() (csrc/igemm.hip): patch width of the LDS-DMA halo-tile weight-gradient kernel
     (variant 2) for this geometry, 0 when it is not a 3x3 / stride-1 / 'same' convolution the kernel can tile."""
@@ -505,7 +536,7 @@ class ConvOp(Op):
             self.bn_name = bn.name
             self.eps, self.momentum = float(bn.attrs["eps"]), float(bn.attrs["momentum"])
         # ---- tiles and scratch
-        self.tm, self.tn = pick_tile_fwd(self.M, n_rows, self.g_fwd.ncls, self.g_fwd.ntaps * self.Kpad)
+        self.tm, self.tn, self.fwd_variant = pick_fwd(self.M, n_rows, self.g_fwd, self.g_fwd.ntaps * self.Kpad, m.dtype == "f16")
         self.nparts = self.g_fwd.ncls * _cdiv(self.M, self.tm)
         dev = _dev()
         if self.has_bn:
@@ -540,7 +571,7 @@ class ConvOp(Op):
         a.act, a.alpha = (ACT[self.act] if fused_act else 0), float(self.alpha)
         a.accumulate = 0
         a.stats = self.stats.data_ptr() if self.has_bn else None
-        a.tile_m, a.tile_n = self.tm, self.tn
+        a.tile_m, a.tile_n, a.variant = self.tm, self.tn, self.fwd_variant
         self.fwd_args = a
         self.fwd_args_eval = IgemmFwdArgs.from_buffer_copy(a)
         self.fwd_args_eval.stats = None
@@ -632,7 +663,7 @@ class ConvOp(Op):
                 else:
                     a.out_ptr[s_i], a.out_acc[s_i] = None, 0
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
-            a.tile_m, a.tile_n = pick_tile_fwd(Md, self.Kpad, 1, self.g_dgrad.ntaps * self.rows_pad)
+            a.tile_m, a.tile_n, a.variant = pick_fwd(Md, self.Kpad, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
             self.dg_args.append((a, zero_first, fl))
 
     def backward(self):
