@@ -86,6 +86,7 @@ def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
     assert seen == {0, 16, 32}
     geoms += [M.geom_conv(2, h, w, 3, 3, 1, 1) for (h, w) in ((8, 32), (16, 16), (24, 64), (32, 48), (12, 32))]
     geoms += [M.geom_conv_dgrad(2, h, w, 3, 3, 1, 1) for (h, w) in ((8, 32), (16, 16), (4, 32))]
+    geoms += [M.geom_convT(2, h, w, k, k, 2, 2) for (h, w) in ((8, 32), (16, 16), (4, 32)) for k in (4, 2)]
     seen = set()
     for g in geoms:
         got = L.seg_fwd_halo_patch(ctypes.byref(g))

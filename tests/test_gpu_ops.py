@@ -279,6 +279,23 @@ def test_conv_fwd_halo_kernel(case, mode):
         assert rel(st[:, :cout], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-3
 
 
+@pytest.mark.parametrize("case", [
+    dict(shape=(2, 8, 32), cin=128, cout=64, tile=(256, 64)),
+    dict(shape=(1, 16, 16), cin=72, cout=24, tile=(256, 64)),
+    dict(shape=(2, 8, 64), cin=64, cout=128, tile=(256, 128)),
+    dict(shape=(1, 16, 16), cin=160, cout=136, tile=(256, 128)),
+], ids=lambda c: f"{c['shape']}-{c['cin']}->{c['cout']}-{c['tile']}")
+def test_conv_transpose_fwd_halo_kernel(case):
+    """variant 3 on Conv2DTranspose(4x4, stride 2): four sub-pixel classes of 2x2 taps from the same halo tile."""
+    N, H, W = case["shape"]
+    xs = [h16(torch.randn(N, H, W, case["cin"]))]
+    kern = h16(torch.from_numpy(rng.standard_normal((4, 4, case["cout"], case["cin"])).astype(np.float32) * 0.1)).numpy()
+    bias = rng.standard_normal(case["cout"]).astype(np.float32)
+    want = F.leaky_relu(K.conv2d_transpose_same(xs[0], torch.from_numpy(kern), torch.from_numpy(bias), (2, 2)), 0.3)
+    out, _, pad = U.igemm_conv(xs, kern, bias, "convT", (2, 2), "leaky_relu", 0.3, False, case["tile"], variant=3)
+    assert rel(out, want) < 2e-3 and pad == 0.0
+
+
 def test_conv_fwd_halo_kernel_refuses_other_geometries():
     kern = np.zeros((3, 3, 64, 64), np.float32)
     with pytest.raises(U.ffi.SegHipError, match="variant 3"):

@@ -764,6 +764,16 @@ __global__ __launch_bounds__(TPB) void convlstm_gate_bwd_kernel(const T* dh, int
 // ------------------------------------------------------------------------------------------------ 1x1 heads (Cout <= 8)
 constexpr int HEAD_MAXC = 8;
 
+// element offset of input pixel (n, yo*sy, xo*sx) for output pixel index pix; the full-resolution heads (stride 1)
+// skip the three integer divisions, the strided ones (UNet 3+ deep supervision) use 32-bit ones (npix < 2^31, host-checked)
+__device__ __forceinline__ int64_t head_in_off(int64_t pix, int H, int W, int HO, int WO, int sy, int sx, int cs) {
+  if (sy == 1 && sx == 1) return pix * cs;
+  const unsigned pp = (unsigned)pix;
+  const unsigned r = pp / (unsigned)WO, xo = pp - r * (unsigned)WO;
+  const unsigned n = r / (unsigned)HO, yo = r - n * (unsigned)HO;
+  return (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+}
+
 template <typename T, int CO>
 __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int Cin, int N, int H, int W, int sy, int sx,
                                                        const float* w, int w_ld, const float* b, int Cout, int act, float* y, int LPP) {
@@ -790,10 +800,8 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int C
 #pragma unroll
       for (int k = 0; k < CO; ++k) acc[u][k] = 0.f;
       if (ok[u] && one && sub < CH) {
-        const int xo = (int)(pix % WO);
-        const int yo = (int)((pix / WO) % HO);
-        const int n = (int)(pix / ((int64_t)WO * HO));
-        load8(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + sub * 8, f[u]);
+        const int64_t ioff = head_in_off(pix, H, W, HO, WO, sy, sx, cs);
+        load8(x + ioff + sub * 8, f[u]);
       }
     }
 #pragma unroll
@@ -810,10 +818,8 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int C
               }
           }
         } else {
-          const int xo = (int)(pix % WO);
-          const int yo = (int)((pix / WO) % HO);
-          const int n = (int)(pix / ((int64_t)WO * HO));
-          const T* xp = x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+          const int64_t ioff = head_in_off(pix, H, W, HO, WO, sy, sx, cs);
+          const T* xp = x + ioff;
           for (int ch = sub; ch < CH; ch += LPP) {
             float g[8];
             load8(xp + ch * 8, g);
@@ -907,10 +913,8 @@ __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const
           yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
         }
         head_dpre<CO>(dyv, yv, Cout, act, d[u]);
-        const int xo = (int)(pix % WO);
-        const int yo = (int)((pix / WO) % HO);
-        const int n = (int)(pix / ((int64_t)WO * HO));
-        dp[u] = dx + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs;
+        const int64_t ioff = head_in_off(pix, H, W, HO, WO, sy, sx, cs);
+        dp[u] = dx + ioff;
         if (accumulate && one && sub < CH) load8(dp[u] + sub * 8, old[u]);
       }
     }
@@ -979,26 +983,39 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
       for (int t = 0; t < 8; ++t) acc[k][t] = 0.f;
     }
     if (ch < L.CH) {
-      for (int64_t pix = p0 + rowi; pix < p1; pix += L.RP) {
-        float dyv[CO], yv[CO], d[CO];
+      // UNR pixels per trip, every load issued before the first use (a block walks thousands of pixels: one load
+      // in flight per thread leaves the kernel latency-bound)
+      for (int64_t pb = p0 + rowi; pb < p1; pb += (int64_t)L.RP * UNR) {
+        float dyv[UNR][CO], yv[UNR][CO], f[UNR][8];
+        bool ok[UNR];
 #pragma unroll
-        for (int k = 0; k < CO; ++k) {
-          dyv[k] = (k < Cout) ? dy[pix * Cout + k] : 0.f;
-          yv[k] = (k < Cout) ? y[pix * Cout + k] : 0.f;
-        }
-        head_dpre<CO>(dyv, yv, Cout, act, d);
-        const int xo = (int)(pix % WO);
-        const int yo = (int)((pix / WO) % HO);
-        const int n = (int)(pix / ((int64_t)WO * HO));
-        float f[8];
-        load8(x + (((int64_t)n * H + yo * sy) * W + xo * sx) * cs + ch * 8, f);
+        for (int u = 0; u < UNR; ++u) {
+          const int64_t pix = pb + (int64_t)u * L.RP;
+          ok[u] = pix < p1;
 #pragma unroll
-        for (int k = 0; k < CO; ++k)
-          if (k < Cout) {
-            accb[k] += d[k];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[k][t] += d[k] * f[t];
+          for (int k = 0; k < CO; ++k) {
+            dyv[u][k] = (ok[u] && k < Cout) ? dy[pix * Cout + k] : 0.f;
+            yv[u][k] = (ok[u] && k < Cout) ? y[pix * Cout + k] : 0.f;
           }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) f[u][t] = 0.f;
+          if (ok[u]) {
+            const int64_t ioff = head_in_off(pix, H, W, HO, WO, sy, sx, cs);
+            load8(x + ioff + ch * 8, f[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          float d[CO];
+          head_dpre<CO>(dyv[u], yv[u], Cout, act, d);
+#pragma unroll
+          for (int k = 0; k < CO; ++k)
+            if (k < Cout) {
+              accb[k] += d[k];
+#pragma unroll
+              for (int t = 0; t < 8; ++t) acc[k][t] += d[k] * f[u][t];
+            }
+        }
       }
     }
     block_col_reduce<CO>(acc, sm, rowi, col, L.CHP, L.RP);
@@ -1456,6 +1473,7 @@ static int seg_head_fwd_impl(const void* x, int32_t cs, int32_t Cin, int32_t N, 
                 "seg_head_fwd: bad arguments (Cin=%d cs=%d Cout=%d)", Cin, cs, Cout);
   const int LPP = head_lpp(Cin), gpb = TPB / LPP;
   const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
+  SEG_CHECK_ARG(npix < (1LL << 31), "seg_head_fwd: more than 2^31 output pixels");
   int64_t blocks = (npix + (int64_t)gpb * UNR - 1) / ((int64_t)gpb * UNR);
   if (blocks > 2 * MAX_BLOCKS) blocks = 2 * MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
@@ -1481,6 +1499,7 @@ static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int
   SEG_CHECK_ARG(dy && y && x && w && Cin > 0 && Cin <= cs && (cs & 7) == 0 && Cout >= 1 && Cout <= HEAD_MAXC && w_ld >= Cin,
                 "seg_head_bwd: bad arguments");
   const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
+  SEG_CHECK_ARG(npix < (1LL << 31), "seg_head_bwd: more than 2^31 output pixels");
   if (dx != nullptr) {
     const int LPP = head_lpp(cs), gpb = TPB / LPP;
     int64_t blocks = (npix + (int64_t)gpb * UNR - 1) / ((int64_t)gpb * UNR);

@@ -194,7 +194,7 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
       if constexpr (PWE > 0) {
         const int r = st_row + 16 * ps;
         const int yy = row0 + (PWE == 32 ? a : 2 * a + (r >> 4)), xx = PWE == 32 ? r : (r & 15);
-        opix[a][ps] = ((long)pn * g.Hout + (py0 + yy)) * g.Wout + (px0 + xx);
+        opix[a][ps] = ((long)pn * g.Hout + ((py0 + yy) * g.osy + g.oy[cls])) * g.Wout + ((px0 + xx) * g.osx + g.ox[cls]);
       } else {
         int m = row0 + a * 32 + st_row + 16 * ps;
         if (m < M) {
@@ -657,7 +657,7 @@ template __global__ void igemm_fwd2_kernel<128, 64, 16, 64, 2>(const seg_igemm_f
 // traffic per MFMA 2-3x and, with TG = 3, the barriers per MFMA 3x against the per-tap kernel above.
 // Waves: BN = 128: 2 (M) x 2 (N), each 128 px x 64 channels; BN = 64: 4 x 1, each 64 px x 64 channels.
 // ---------------------------------------------------------------------------------------------------------
-template <int PW, int BN, int TG>
+template <int PW, int BN, int NT, int TG>
 __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PH = 256 / PW, HC = PW + 2, HROWS = (PH + 2) * HC;
@@ -665,9 +665,9 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   constexpr int NA_HI = (NI_A + 3) / 4, NA_REM = NI_A % 4;  // per wave: NA_HI for waves < NA_REM (all when NA_REM == 0), else NA_HI - 1
   constexpr int A_BYTES = NI_A * 1024;
   constexpr int B_BYTES = TG * BN * 64, NB_W = B_BYTES / 4096;     // weight stage, wave instructions per wave and stage
-  constexpr int NSTEP = 9 / TG;
+  constexpr int NSTEP = NT / TG;
   constexpr int WMv = BN == 64 ? 4 : 2, WNv = 4 / WMv, TMw = 8 / WMv;   // A tiles (32 px) per wave; 2 B tiles (64 channels) per wave
-  static_assert(TG * NSTEP == 9 && NB_W * 4096 == B_BYTES, "tap groups / weight stage");
+  static_assert(TG * NSTEP == NT && NSTEP >= 2 && NB_W * 4096 == B_BYTES, "tap groups / weight stage");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   unsigned char* const Abuf = smem;                         // 2 halo tiles
@@ -680,7 +680,8 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   const int H = g.Hin, W = g.Win;
   const int PWn = W / PW, PHn = H / PH;
   const int npatch = g.N * PHn * PWn;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int lin0 = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int cls = lin0 / gridDim.x, lin = lin0 - cls * gridDim.x;      // sub-pixel class of a transposed conv (0 otherwise)
   const int mb = lin % npatch, nb = lin / npatch;
   const int n0 = nb * BN;
   const int pn = mb / (PHn * PWn);
@@ -689,11 +690,11 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   const int y0 = ppy * PH, x0 = (prem - ppy * PWn) * PW;
 
   // tap t of the geometry = halo row shift dy * HC + dx (offsets in {-1, 0, 1}) and weight tap index
-  int t_shift[9], t_w[9];
+  int t_shift[NT], t_w[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    t_shift[t] = g.tap_dy[t] * HC + g.tap_dx[t];
-    t_w[t] = g.tap_w[t] * p.Kpad * 2;
+  for (int t = 0; t < NT; ++t) {
+    t_shift[t] = g.tap_dy[cls * NT + t] * HC + g.tap_dx[cls * NT + t];
+    t_w[t] = g.tap_w[cls * NT + t] * p.Kpad * 2;
   }
 
   // ---- halo-tile LDS-DMA lane constants: instruction i fills LDS rows 16 i .. 16 i + 15, lane -> (row, 16-B chunk)
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
     for (int j = 0; j < NB_W; ++j) {
       int tw = 0;
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < NT; ++t)
         if (t == tg * TG + b_tap[j]) tw = t_w[t];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + (j * 4 + wave) * 1024), 16, b_voff[j], __builtin_amdgcn_readfirstlane(tw + kof), 0, 0);
     }
@@ -873,13 +874,18 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
     abuf ^= 1;
   }
   __syncthreads();
-  conv_epilogue<half_t, TMw, 2, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, 0, npatch, mb, 0, 0, pn, y0, x0);
+  conv_epilogue<half_t, TMw, 2, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, cls, npatch, mb, 0, 0, pn, y0, x0);
 #endif
 }
-template __global__ void igemm_fwd3_kernel<32, 128, 1>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 128, 1>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<32, 64, 3>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 64, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 128, 9, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 128, 9, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 9, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 9, 3>(const seg_igemm_fwd_args);
+// the four sub-pixel classes of a 4x4 / stride-2 transposed conv: 2x2 taps each out of the same halo tile
+template __global__ void igemm_fwd3_kernel<32, 128, 4, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 128, 4, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 4, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 4, 2>(const seg_igemm_fwd_args);
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient:  D[n][k] = sum_pix dz[pix][n] * in[pix + tap][k]   (reduction dimension = pixels)
@@ -1497,40 +1503,59 @@ bool check_segs(const Args& a, const char* who) {
 
 // ---- v3 (halo tiles) dispatch
 extern "C" int seg_fwd_halo_patch(const seg_geom* g) {
-  if (g == nullptr || g->ncls != 1 || g->ntaps != 9 || g->isy != 1 || g->isx != 1 || g->osy != 1 || g->osx != 1) return 0;
-  if (g->Hl != g->Hin || g->Wl != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->oy[0] != 0 || g->ox[0] != 0) return 0;
-  unsigned seen = 0;
-  for (int t = 0; t < 9; ++t) {
-    const int dy = g->tap_dy[t], dx = g->tap_dx[t];
-    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return 0;
-    seen |= 1u << ((dy + 1) * 3 + dx + 1);
+  if (g == nullptr || g->isy != 1 || g->isx != 1 || g->Hl != g->Hin || g->Wl != g->Win) return 0;
+  if (g->ncls == 1 && g->ntaps == 9) {                    // 3x3 stride-1 'same' conv or its data gradient: all nine offsets
+    if (g->osy != 1 || g->osx != 1 || g->Hout != g->Hin || g->Wout != g->Win || g->oy[0] != 0 || g->ox[0] != 0) return 0;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+      const int dy = g->tap_dy[t], dx = g->tap_dx[t];
+      if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return 0;
+      seen |= 1u << ((dy + 1) * 3 + dx + 1);
+    }
+    if (seen != 0x1ffu) return 0;
+  } else if (g->ncls == 4 && g->ntaps == 4) {             // 4x4 stride-2 transposed conv: four classes of 2x2 taps
+    if (g->osy != 2 || g->osx != 2 || g->Hout != 2 * g->Hin || g->Wout != 2 * g->Win) return 0;
+    for (int c = 0; c < 4; ++c) {
+      if (g->oy[c] < 0 || g->oy[c] > 1 || g->ox[c] < 0 || g->ox[c] > 1) return 0;
+      for (int t = 0; t < 4; ++t) {
+        const int dy = g->tap_dy[c * 4 + t], dx = g->tap_dx[c * 4 + t];
+        if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return 0;
+      }
+    }
+  } else {
+    return 0;
   }
-  if (seen != 0x1ffu) return 0;
   if (g->Win % 32 == 0 && g->Hin % 8 == 0) return 32;
   if (g->Win % 16 == 0 && g->Hin % 16 == 0) return 16;
   return 0;
 }
 
+template <int NT, int TG128, int TG64>
+static void launch_fwd3_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st) {
+  const int ni_a = pw == 32 ? 22 : 21;
+  if (a.tile_n == 128) {
+    const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (TG128 * 8192);
+    if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 128, NT, TG128>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 128, NT, TG128>), grid, dim3(256), lds, st, a);
+  } else {
+    const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (TG64 * 4096);
+    if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 64, NT, TG64>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 64, NT, TG64>), grid, dim3(256), lds, st, a);
+  }
+}
+
 static int launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   const int pw = seg_fwd_halo_patch(&a.g);
-  SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd: variant 3 needs 3x3 taps with offsets in {-1,0,1}^2, stride 1, 'same', and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
+  SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd: variant 3 needs a stride-1 3x3 'same' conv (or its data gradient) or a 4x4 / stride-2 transposed conv, and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
   SEG_CHECK_ARG(a.tile_m == 256 && (a.tile_n == 64 || a.tile_n == 128), "seg_igemm_fwd: variant 3 tiles are 256x64 and 256x128, not %dx%d", a.tile_m, a.tile_n);
   const long pix = (long)a.g.N * a.g.Hin * a.g.Win;
   for (int s = 0; s < a.nseg; ++s) SEG_CHECK_ARG(pix * a.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd: variant 3 needs operands below 1 GiB");
   SEG_CHECK_ARG((long)a.n_rows * a.g.T_total * a.Kpad * 2 < (1L << 30), "seg_igemm_fwd: variant 3 needs operands below 1 GiB");
   const int npatch = (int)(pix / 256);
   const int nblocks = (a.n_rows + a.tile_n - 1) / a.tile_n;
-  dim3 grid((unsigned)(npatch * nblocks), 1, 1);
-  const int ni_a = pw == 32 ? 22 : 21;
-  if (a.tile_n == 128) {
-    const size_t lds = (size_t)2 * ni_a * 1024 + 3 * 8192;
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 128, 1>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 128, 1>), grid, dim3(256), lds, st, a);
-  } else {
-    const size_t lds = (size_t)2 * ni_a * 1024 + 3 * 12288;
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 64, 3>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 64, 3>), grid, dim3(256), lds, st, a);
-  }
+  dim3 grid((unsigned)(npatch * nblocks), (unsigned)a.g.ncls, 1);
+  if (a.g.ntaps == 9) launch_fwd3_nt<9, 1, 3>(a, pw, grid, st);
+  else launch_fwd3_nt<4, 1, 2>(a, pw, grid, st);
   SEG_CHECK_LAUNCH("seg_igemm_fwd (halo tiles)");
   return SEG_OK;
 }

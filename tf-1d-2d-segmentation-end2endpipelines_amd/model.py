@@ -287,13 +287,24 @@ def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
 
 def fwd_halo_patch(g: Geom) -> int:
     """Mirror of seg_fwd_halo_patch() (csrc/igemm.hip): patch width of the halo-tile forward / data-gradient kernel
-    (variant 3; 32 = 8x32-pixel patches, 16 = 16x16), 0 when the geometry is not a stride-1 'same' convolution with the
-    nine tap offsets {-1,0,1}^2 (in any order) on an image those patches tile."""
-    if g.ncls != 1 or g.ntaps != 9 or (g.isy, g.isx, g.osy, g.osx) != (1, 1, 1, 1):
+    (variant 3; 32 = 8x32-pixel patches, 16 = 16x16), 0 when the geometry is neither a stride-1 'same' convolution with
+    the nine tap offsets {-1,0,1}^2 (in any order) nor a 4x4 / stride-2 transposed convolution (four sub-pixel classes
+    of 2x2 taps), or the image is not tiled by those patches."""
+    if (g.isy, g.isx) != (1, 1) or (g.Hl, g.Wl) != (g.Hin, g.Win):
         return 0
-    if (g.Hl, g.Wl, g.Hout, g.Wout) != (g.Hin, g.Win, g.Hin, g.Win) or g.oy[0] != 0 or g.ox[0] != 0:
-        return 0
-    if {(g.tap_dy[t], g.tap_dx[t]) for t in range(9)} != {(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)}:
+    if g.ncls == 1 and g.ntaps == 9:
+        if (g.osy, g.osx, g.Hout, g.Wout, g.oy[0], g.ox[0]) != (1, 1, g.Hin, g.Win, 0, 0):
+            return 0
+        if {(g.tap_dy[t], g.tap_dx[t]) for t in range(9)} != {(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)}:
+            return 0
+    elif g.ncls == 4 and g.ntaps == 4:
+        if (g.osy, g.osx, g.Hout, g.Wout) != (2, 2, 2 * g.Hin, 2 * g.Win):
+            return 0
+        if any(not (0 <= g.oy[c] <= 1 and 0 <= g.ox[c] <= 1) for c in range(4)):
+            return 0
+        if any(abs(g.tap_dy[e]) > 1 or abs(g.tap_dx[e]) > 1 for e in range(16)):
+            return 0
+    else:
         return 0
     if g.Win % 32 == 0 and g.Hin % 8 == 0:
         return 32
@@ -310,7 +321,7 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     """(tile_m, tile_n, variant) of a forward / data-gradient launch."""
     if f16 and FWD_HALO and fwd_halo_patch(g):
         tn = 64 if n_rows <= 64 else 128
-        if (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
+        if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
             return 256, tn, 3
     tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
     return tm, tn, 0
