@@ -62,6 +62,25 @@ def make_batch(model, N, H, W, Cin, loss, rank):
     return x.cuda(), [t.cuda() for t in targets]
 
 
+def pmc_traffic(entry_point):
+    """HBM bytes per launch of a C-ABI GEMM entry point from the committed PMC summary of this workload
+    (profiles/*_c3_hbm_traffic.json, written by tools/profile_run.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled on gfx950): launch-weighted mean over the device kernels behind the entry point."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_hbm_traffic.json")))      # newest round / revision last by name
+    if not files:
+        return None, None
+    prefix = {"seg_igemm_fwd": ("igemm_fwd",), "seg_igemm_wgrad": ("igemm_wgrad",)}[entry_point]
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    n = tot = 0
+    for k, v in d.items():
+        if any(pf in k for pf in prefix):
+            n += v["launches"]
+            tot += v["launches"] * (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"])
+    return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(workload, sample_batch=1, steps=1):
     """The oracle (torch-CPU fp32 restatement of the reference graph, kind 'port') timed on the host cores:
     forward + backward + Keras Adam on a bounded sample (smaller batch, same model and resolution)."""
@@ -178,8 +197,10 @@ def main():
         d_ = gemm[dom]
         ach = d_["flops"] / d_["seconds"] / 1e12
         tot_s = sum(v["seconds"] for v in summ.values())
+        traffic, traffic_src = pmc_traffic(dom) if args.workload == "C3" else (None, None)
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_TFLOPS_F16, "traffic": None, "launches": d_["launches"],
+                    "frac": ach / PEAK_TFLOPS_F16, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                    "traffic_source": traffic_src, "launches": d_["launches"],
                     "avg_launch_us": d_["seconds"] / d_["launches"] * 1e6,
                     "algorithmic_flops_per_launch": d_["flops"] / d_["launches"],
                     "step_share": d_["seconds"] / tot_s,
