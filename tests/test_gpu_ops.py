@@ -328,12 +328,31 @@ def test_wgrad_halo_kernel_matches_autograd(case):
     assert rel(torch.from_numpy(got), kern.grad) < 1e-4
 
 
+@pytest.mark.parametrize("case", [
+    dict(shape=(2, 8, 32), cins=[128], cout=64, sk=2),
+    dict(shape=(2, 16, 16), cins=[72], cout=24, sk=1),
+    dict(shape=(1, 4, 64), cins=[64, 64], cout=136, sk=3),
+], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
+def test_wgrad_halo_kernel_transposed_conv(case):
+    """variant 2 on Conv2DTranspose(4x4, stride 2): per sub-pixel class four of the nine halo shifts against the stride-2 dz pixels."""
+    N, H, W = case["shape"]
+    xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]
+    cin = sum(case["cins"])
+    kshape = (4, 4, case["cout"], cin)
+    kern = torch.zeros(kshape, requires_grad=True)
+    y = K.conv2d_transpose_same(torch.cat(xs, -1), kern, None, (2, 2))
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    got = U.igemm_wgrad(xs, dz, kshape, "convT", (2, 2), 2, case["sk"], None)
+    assert rel(torch.from_numpy(got), kern.grad) < 1e-4
+
+
 def test_wgrad_halo_kernel_refuses_other_geometries():
     xs = [h16(torch.randn(2, 8, 8, 64))]
     with pytest.raises(U.ffi.SegHipError, match="variant 2"):
         U.igemm_wgrad(xs, h16(torch.randn(2, 8, 8, 64)), (3, 3, 64, 64), "conv", (1, 1), 2, 1, None)       # W = 8
     with pytest.raises(U.ffi.SegHipError, match="variant 2"):
-        U.igemm_wgrad([h16(torch.randn(2, 8, 32, 64))], h16(torch.randn(2, 16, 64, 32)), (4, 4, 32, 64), "convT", (2, 2), 2, 1, None)
+        U.igemm_wgrad([h16(torch.randn(2, 8, 32, 64))], h16(torch.randn(2, 16, 64, 32)), (2, 2, 32, 64), "convT", (2, 2), 2, 1, None)   # 2x2 kernel
 
 
 # ------------------------------------------------------------------------------------------------ BatchNormalization

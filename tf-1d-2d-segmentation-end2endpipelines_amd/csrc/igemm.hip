@@ -1294,7 +1294,7 @@ template __global__ void igemm_wgrad_mt_kernel<128, 3>(const seg_igemm_wgrad_arg
 // 32-lane group reads on 64 distinct banks for every tap shift; with the shift a compile-time constant the swizzled
 // lane offset is one of four precomputed registers and the rest of the address is the instruction's immediate.
 // ---------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool TC>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igemm_wgrad_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int R = 64 / C, HC = C + 2, HROWS = (R + 2) * HC;
@@ -1332,6 +1332,25 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   const int per = (npatch + p.splitk - 1) / p.splitk;
   const int q0 = bz * per, q1 = min(npatch, q0 + per);
   if (q0 >= q1) return;
+  // taps: a 3x3 conv uses all nine halo shifts t = 3 (dy + 1) + dx + 1 in geometry order; a sub-pixel class of the
+  // 4x4 / stride-2 transposed conv (TC) uses four of them against the stride-2 pixels (oy, ox) of dz
+  const int cls = TC ? (int)blockIdx.y : 0;
+  unsigned tmask = TC ? 0u : 0x1ffu;
+  int wmap[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wmap[t] = TC ? 0 : g.tap_w[t];
+  if constexpr (TC) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = cls * 4 + i;
+      const int t = (g.tap_dy[e] + 1) * 3 + g.tap_dx[e] + 1;
+      tmask |= 1u << t;
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+        if (u == t) wmap[u] = g.tap_w[e];
+    }
+  }
+  const int Ho = g.Hout, Wo = g.Wout, osy = g.osy, osx = g.osx;
 
   // wave-uniform descriptors (readfirstlane returns int: keep the halves unsigned, or a low word with bit 31 set
   // sign-extends into the high word of the base address)
@@ -1341,7 +1360,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
     return (void*)(((unsigned long long)hi << 32) | lo);
   };
   const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.seg_ptr[seg]), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * cs2), 0x00020000);
-  const auto rsrc_dz = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.dz), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * dzcs2), 0x00020000);
+  const auto rsrc_dz = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.dz), 0, __builtin_amdgcn_readfirstlane(g.N * Ho * Wo * dzcs2), 0x00020000);
 
   // ---- LDS-DMA lane constants.  A wave instruction fills 8 LDS rows (lane >> 3) x 8 chunks (lane & 7); the chunk a
   // lane fetches from memory is its LDS chunk XOR the row's swizzle
@@ -1352,7 +1371,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
     const int row = (wave * 2 + i) * 8 + lrow;
     const int gch = lch ^ (((row >> 1) & 1) << 2);
     const int yy = row / C, xx = row % C;
-    z_voff[i] = (r0 + gch * 8 < p.n_rows) ? (unsigned)((yy * W + xx) * dzcs2 + (p.dz_coff + r0 + gch * 8) * 2) : OOB_OFF;
+    z_voff[i] = (r0 + gch * 8 < p.n_rows) ? (unsigned)((yy * osy * Wo + xx * osx) * dzcs2 + (p.dz_coff + r0 + gch * 8) * 2) : OOB_OFF;
   }
   int in_dy[NI_W], in_dx[NI_W], in_cb[NI_W];      // halo pixel relative to the patch origin, channel byte offset (-1: no load)
 #pragma unroll
@@ -1371,7 +1390,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
     const int py = rem / PW;
     const int y0 = py * R, x0 = (rem - py * PW) * C;
     unsigned char* sb = smem + stage * STAGE;
-    const int zs = ((n * H + y0) * W + x0) * dzcs2;
+    const int zs = ((n * Ho + y0 * osy + g.oy[cls]) * Wo + x0 * osx + g.ox[cls]) * dzcs2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dz, (lds_ptr_t)(sb + (wave * 2 + i) * 1024), 16, z_voff[i], zs, 0, 0);
@@ -1419,6 +1438,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
       const h8 af = trfrag(Zs + kb * 16 * 128 + offA);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
+        if (TC && !((tmask >> t) & 1u)) continue;                   // wave-uniform
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
         const h8 bf = trfrag(Is + hb * 128 + offB[hb & 3]);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
@@ -1445,7 +1465,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   if (kcol < sc) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int widx = g.tap_w[t];
+      if (TC && !((tmask >> t) & 1u)) continue;
+      const int widx = wmap[t];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
@@ -1455,8 +1476,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   }
 #endif
 }
-template __global__ void igemm_wgrad_halo_kernel<32>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_kernel<16>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<32, false>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<16, false>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<32, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<16, true>(const seg_igemm_wgrad_args);
 
 bool check_geom(const seg_geom& g, const char* who) {
   if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Hl <= 0 || g.Wl <= 0 || g.Hout <= 0 || g.Wout <= 0) {
@@ -1683,10 +1706,27 @@ extern "C" int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int v
 // patch width (32 or 16 pixels; the patch is 64 / width rows high) of the halo-tile weight-gradient kernel for this
 // geometry, 0 when the geometry is not a 3x3 / stride-1 / 'same' convolution it can tile
 extern "C" int seg_wgrad_halo_patch(const seg_geom* g) {
-  if (g == nullptr || g->ncls != 1 || g->ntaps != 9 || g->isy != 1 || g->isx != 1 || g->osy != 1 || g->osx != 1) return 0;
-  if (g->Hl != g->Hin || g->Wl != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->oy[0] != 0 || g->ox[0] != 0) return 0;
-  for (int t = 0; t < 9; ++t)
-    if (g->tap_dy[t] != t / 3 - 1 || g->tap_dx[t] != t % 3 - 1) return 0;
+  if (g == nullptr || g->isy != 1 || g->isx != 1 || g->Hl != g->Hin || g->Wl != g->Win) return 0;
+  if (g->ncls == 1 && g->ntaps == 9) {
+    if (g->osy != 1 || g->osx != 1 || g->Hout != g->Hin || g->Wout != g->Win || g->oy[0] != 0 || g->ox[0] != 0) return 0;
+    for (int t = 0; t < 9; ++t)
+      if (g->tap_dy[t] != t / 3 - 1 || g->tap_dx[t] != t % 3 - 1) return 0;
+  } else if (g->ncls == 4 && g->ntaps == 4) {          // 4x4 / stride-2 transposed conv: 4 distinct halo shifts per sub-pixel class
+    if (g->osy != 2 || g->osx != 2 || g->Hout != 2 * g->Hin || g->Wout != 2 * g->Win) return 0;
+    for (int c = 0; c < 4; ++c) {
+      if (g->oy[c] < 0 || g->oy[c] > 1 || g->ox[c] < 0 || g->ox[c] > 1) return 0;
+      unsigned seen = 0;
+      for (int t = 0; t < 4; ++t) {
+        const int dy = g->tap_dy[c * 4 + t], dx = g->tap_dx[c * 4 + t];
+        if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return 0;
+        const unsigned bit = 1u << ((dy + 1) * 3 + dx + 1);
+        if (seen & bit) return 0;
+        seen |= bit;
+      }
+    }
+  } else {
+    return 0;
+  }
   if (g->Win % 32 == 0 && g->Hin % 2 == 0) return 32;
   if (g->Win % 16 == 0 && g->Hin % 4 == 0) return 16;
   return 0;
@@ -1708,19 +1748,25 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   if (a->variant == 2) {
     SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_wgrad: variant 2 (LDS-DMA halo tiles) is fp16 only");
     const int pc = seg_wgrad_halo_patch(&a->g);
-    SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' geometry with W %% 16 == 0 and H %% 4 == 0 (or W %% 32 == 0, H %% 2 == 0)");
+    SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 16 == 0 and H %% 4 == 0 (or W %% 32 == 0, H %% 2 == 0)");
     const long pix = (long)a->g.N * a->g.Hin * a->g.Win;
-    SEG_CHECK_ARG(pix * a->dz_cs * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
+    SEG_CHECK_ARG((long)a->g.N * a->g.Hout * a->g.Wout * a->dz_cs * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
     int planes = 0;
     for (int s = 0; s < a->nseg; ++s) {
       SEG_CHECK_ARG(pix * a->seg_cs[s] * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
       planes += (a->seg_c[s] + 63) / 64;
     }
     if constexpr (sizeof(T) == 2) {
-      dim3 gridh((unsigned)(((a->n_rows + 63) / 64) * planes), 1, (unsigned)a->splitk);
+      dim3 gridh((unsigned)(((a->n_rows + 63) / 64) * planes), (unsigned)a->g.ncls, (unsigned)a->splitk);
       hipStream_t sth = (hipStream_t)stream;
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32>), gridh, dim3(256), (size_t)2 * (8192 + 17 * 1024), sth, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16>), gridh, dim3(256), (size_t)2 * (8192 + 14 * 1024), sth, *a);
+      const size_t lds32 = (size_t)2 * (8192 + 17 * 1024), lds16 = (size_t)2 * (8192 + 14 * 1024);
+      if (a->g.ncls == 1) {
+        if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32, false>), gridh, dim3(256), lds32, sth, *a);
+        else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16, false>), gridh, dim3(256), lds16, sth, *a);
+      } else {
+        if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32, true>), gridh, dim3(256), lds32, sth, *a);
+        else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16, true>), gridh, dim3(256), lds16, sth, *a);
+      }
     }
     SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
     return SEG_OK;

@@ -329,12 +329,25 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
 
 def wgrad_halo_patch(g: Geom) -> int:
     """Mirror of seg_wgrad_halo_patch() (csrc/igemm.hip): patch width of the LDS-DMA halo-tile weight-gradient kernel
-    (variant 2) for this geometry, 0 when it is not a 3x3 / stride-1 / 'same' convolution the kernel can tile."""
-    if g.ncls != 1 or g.ntaps != 9 or (g.isy, g.isx, g.osy, g.osx) != (1, 1, 1, 1):
+    (variant 2) for this geometry, 0 when it is neither a 3x3 / stride-1 / 'same' convolution nor a 4x4 / stride-2
+    transposed convolution the kernel can tile."""
+    if (g.isy, g.isx) != (1, 1) or (g.Hl, g.Wl) != (g.Hin, g.Win):
         return 0
-    if (g.Hl, g.Wl, g.Hout, g.Wout) != (g.Hin, g.Win, g.Hin, g.Win) or g.oy[0] != 0 or g.ox[0] != 0:
-        return 0
-    if any(g.tap_dy[t] != t // 3 - 1 or g.tap_dx[t] != t % 3 - 1 for t in range(9)):
+    if g.ncls == 1 and g.ntaps == 9:
+        if (g.osy, g.osx, g.Hout, g.Wout, g.oy[0], g.ox[0]) != (1, 1, g.Hin, g.Win, 0, 0):
+            return 0
+        if any(g.tap_dy[t] != t // 3 - 1 or g.tap_dx[t] != t % 3 - 1 for t in range(9)):
+            return 0
+    elif g.ncls == 4 and g.ntaps == 4:
+        if (g.osy, g.osx, g.Hout, g.Wout) != (2, 2, 2 * g.Hin, 2 * g.Win):
+            return 0
+        for c in range(4):
+            if not (0 <= g.oy[c] <= 1 and 0 <= g.ox[c] <= 1):
+                return 0
+            sh = [(g.tap_dy[c * 4 + t], g.tap_dx[c * 4 + t]) for t in range(4)]
+            if any(abs(dy) > 1 or abs(dx) > 1 for dy, dx in sh) or len(set(sh)) != 4:
+                return 0
+    else:
         return 0
     if g.Win % 32 == 0 and g.Hin % 2 == 0:
         return 32
@@ -346,10 +359,10 @@ def wgrad_halo_patch(g: Geom) -> int:
 HALO_BLOCKS = 512          # resident blocks of the variant-2 kernel: 2 per CU x 256 CUs
 
 
-def pick_split_halo(M, n_rows, seg_cs: Sequence[int]):
+def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1):
     """Patch-range split of the variant-2 kernel: fill whole rounds of HALO_BLOCKS co-resident blocks, keep at least 8
     patches (512 pixels) per block."""
-    tiles = _cdiv(n_rows, 64) * sum(_cdiv(c, 64) for c in seg_cs)
+    tiles = ncls * _cdiv(n_rows, 64) * sum(_cdiv(c, 64) for c in seg_cs)
     npatch = M // 64
     best, best_eff = 1, 0.0
     for sk in range(1, max(1, min(npatch // 8, _cdiv(2 * HALO_BLOCKS, tiles))) + 1):
@@ -362,7 +375,7 @@ def pick_split_halo(M, n_rows, seg_cs: Sequence[int]):
 
 def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0):
     if variant == 2:
-        return 64, 64, pick_split_halo(M, n_rows, seg_cs)
+        return 64, 64, pick_split_halo(M, n_rows, seg_cs, ncls)
     tm = 128 if n_rows > 64 else 64
     tn = 128 if max(seg_cs) > 64 else 64
     ntb = wgrad_taps_per_block(tm, tn, ntaps, variant)
