@@ -89,6 +89,14 @@ typedef struct seg_igemm_fwd_args {
   int32_t out_cs_o[SEG_MAX_SEG];
   int32_t out_acc[SEG_MAX_SEG];
   void* out_ptr[SEG_MAX_SEG];
+  /* fused activation backward of the layer that produced span o (split-output mode): when out_y[o] != NULL the value
+   * stored to (or accumulated into) out_ptr[o] is first multiplied by act'(y), y = out_y[o][pixel][channel] being that
+   * layer's OUTPUT (same layout as out_ptr[o]), act = out_dact[o] (RELU / LEAKY / SIGMOID), slope out_dalpha[o].
+   * Replaces a separate seg_act_bwd pass when the span's tensor has no other consumer (Conv2DTranspose + LeakyReLU,
+   * unet_variants.py:17-24).                                                                                     */
+  const void* out_y[SEG_MAX_SEG];
+  int32_t out_dact[SEG_MAX_SEG];
+  float out_dalpha[SEG_MAX_SEG];
   int32_t variant;               /* 0: per-tap kernels (any geometry); 3: halo-tile kernel - fp16, 3x3 taps with
                                     offsets in {-1,0,1}^2, stride 1, 'same'; a block owns a 256-pixel patch, so
                                     tile_m must be 256 (tile_n 64 | 128) and seg_fwd_halo_patch(&g) != 0          */
@@ -233,6 +241,21 @@ int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64
 /* fp32 [rows][T][K] -> fp16 [K][T][rows_pad] (the data-gradient operand of the same layer)                     */
 int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                     seg_stream_t stream);
+/* the same transpose for a DEVICE-resident table of jobs in one launch.  Job d reads the K columns k0 .. k0+kcount of
+ * w [rows][T][K] and writes wt[k - k0][t][dst_coff + r] (row length dst_ld; r < rows_pad, zero for r >= rows):
+ * k0 = 0, kcount = K, dst_ld = rows_pad, dst_coff = 0 is seg_transpose_w; a column slice + column offset builds the
+ * operand of a gathered data gradient (one tensor, several consuming convs side by side along K).  tile0 = number of
+ * blocks of the jobs before d (a job has T * ceil(kcount/32) * ceil(rows_pad/32) blocks); total_tiles = their sum.  */
+typedef struct seg_transpose_desc {
+  const float* w;
+  void* wt;
+  int32_t rows, T, K;
+  int32_t k0, kcount;
+  int32_t rows_pad, dst_ld, dst_coff;
+  int32_t tile0;
+  int32_t reserved;
+} seg_transpose_desc;
+int seg_transpose_w_multi(const seg_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, seg_stream_t stream);
 /* fp32 -> fp16 cast of n elements                                                                              */
 int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream);
 /* fp32 NHWC [npix][C] -> fp16 [npix][cs] zero padded (model input)                                             */
@@ -295,6 +318,7 @@ int seg_copy_channels_f32(const void* src, int32_t src_cs, int32_t src_coff, voi
                           int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream);
 int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                         seg_stream_t stream);
+int seg_transpose_w_multi_f32(const seg_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, seg_stream_t stream);
 int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
 int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
 

@@ -44,7 +44,8 @@ def test_struct_layout_matches_header():
     ffi = importlib.import_module(PKG + "._ffi")
     assert ctypes.sizeof(ffi.Geom) == 4 * (14 + 2 * 4 + 3 * 16)
     hdr = open(os.path.join(ROOT, "include", "seg_hip.h")).read()
-    for struct, cls in (("seg_igemm_fwd_args", ffi.IgemmFwdArgs), ("seg_igemm_wgrad_args", ffi.IgemmWgradArgs), ("seg_geom", ffi.Geom)):
+    for struct, cls in (("seg_igemm_fwd_args", ffi.IgemmFwdArgs), ("seg_igemm_wgrad_args", ffi.IgemmWgradArgs), ("seg_geom", ffi.Geom),
+                        ("seg_transpose_desc", ffi.TransposeDesc)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

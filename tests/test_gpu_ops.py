@@ -218,6 +218,44 @@ def test_dgrad_matches_autograd(kind, k, s, shape, cin, cout):
     assert rel(from_dev(dx, cin), x.grad) < 2e-3
 
 
+@pytest.mark.parametrize("variant,tile,shape", [(0, (128, 128), (2, 16, 16)), (0, (64, 64), (2, 12, 10)), (3, (256, 128), (2, 16, 32)), (3, (256, 64), (1, 16, 16))])
+@pytest.mark.parametrize("act,alpha", [("leaky_relu", 0.3), ("relu", 0.0), ("sigmoid", 0.0)])
+def test_split_output_with_fused_activation_backward(variant, tile, shape, act, alpha):
+    """split-output epilogue: span 0 is multiplied by act'(y0) of the layer that produced that tensor and accumulated,
+    span 1 is stored plain (the data gradient of a conv over cat[up, skip] with the LeakyReLU backward of `up` folded in)."""
+    N, H, W = shape
+    cin, c0, c1 = 40, 32, 64                                   # GEMM N = 96 columns = spans of 32 and 64
+    if tile[1] == 64:
+        c1 = 32
+    x = h16(torch.randn(N, H, W, cin))
+    kern = h16(torch.from_numpy(rng.standard_normal((3, 3, cin, c0 + c1)).astype(np.float32) * 0.1))
+    ref = K.conv2d_same(x, kern, None, (1, 1))
+    y0 = h16(torch.rand(N, H, W, c0) * 2 - 1) if act != "sigmoid" else h16(torch.rand(N, H, W, c0))
+    old0 = h16(torch.randn(N, H, W, c0))
+    d = {"leaky_relu": torch.where(y0 > 0, torch.ones_like(y0), torch.full_like(y0, alpha)), "relu": (y0 > 0).float(), "sigmoid": y0 * (1 - y0)}[act]
+    want0, want1 = old0 + ref[..., :c0] * d, ref[..., c0:]
+    M = U.M
+    n_rows, Kpad = c0 + c1, U.r32(cin)
+    E = M.pack_gemm_weight(kern.numpy(), [cin], [0], n_rows, Kpad, False)
+    w16 = torch.from_numpy(E).to("cuda", torch.float16).contiguous()
+    xd, y0d, o0, o1 = to_dev_nhwc(x), to_dev_nhwc(y0), to_dev_nhwc(old0), torch.zeros((N, H, W, c1), dtype=torch.float16, device="cuda")
+    a = ffi.IgemmFwdArgs()
+    a.g, a.nseg = M.geom_conv(N, H, W, 3, 3, 1, 1), 1
+    a.seg_c[0], a.seg_cs[0], a.seg_woff[0], a.seg_ptr[0] = xd.shape[3], xd.shape[3], 0, xd.data_ptr()
+    a.w, a.Kpad, a.n_rows, a.n_valid = w16.data_ptr(), Kpad, n_rows, n_rows
+    a.nout = 2
+    a.out_span[0], a.out_cs_o[0], a.out_acc[0], a.out_ptr[0] = c0, c0, 1, o0.data_ptr()
+    a.out_span[1], a.out_cs_o[1], a.out_acc[1], a.out_ptr[1] = c1, c1, 0, o1.data_ptr()
+    a.out_y[0], a.out_dact[0], a.out_dalpha[0] = y0d.data_ptr(), ffi.ACT[act], alpha
+    a.tile_m, a.tile_n, a.variant = tile[0], tile[1], variant
+    ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(o0, c0), want0) < 2e-3 and rel(from_dev(o1, c1), want1) < 2e-3
+    a.out_dact[0] = 0
+    with pytest.raises(ffi.SegHipError, match="fused activation backward"):
+        ffi.call("seg_igemm_fwd", C.byref(a), stream())
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", [
     dict(shape=(2, 16, 16), cins=[32], cout=64, k=(3, 3), kind="conv", s=(1, 1), sk=4, tile=(64, 64)),

@@ -30,7 +30,8 @@ class IgemmFwdArgs(C.Structure):
                 ("out_cs", C.c_int32), ("out_coff", C.c_int32), ("bias", C.c_void_p), ("act", C.c_int32),
                 ("alpha", C.c_float), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("tile_m", C.c_int32),
                 ("tile_n", C.c_int32), ("nout", C.c_int32), ("out_span", C.c_int32 * MAX_SEG), ("out_cs_o", C.c_int32 * MAX_SEG),
-                ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG), ("variant", C.c_int32)]
+                ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG), ("out_y", C.c_void_p * MAX_SEG),
+                ("out_dact", C.c_int32 * MAX_SEG), ("out_dalpha", C.c_float * MAX_SEG), ("variant", C.c_int32)]
 
 
 class IgemmWgradArgs(C.Structure):
@@ -39,6 +40,12 @@ class IgemmWgradArgs(C.Structure):
                 ("dz_cs", C.c_int32), ("dz_coff", C.c_int32), ("dw", C.c_void_p), ("Kpad", C.c_int32),
                 ("n_rows", C.c_int32), ("splitk", C.c_int32), ("scale", C.c_float), ("scale_ptr", C.c_void_p),
                 ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("variant", C.c_int32)]
+
+
+class TransposeDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("rows", C.c_int32), ("T", C.c_int32), ("K", C.c_int32),
+                ("k0", C.c_int32), ("kcount", C.c_int32), ("rows_pad", C.c_int32), ("dst_ld", C.c_int32),
+                ("dst_coff", C.c_int32), ("tile0", C.c_int32), ("reserved", C.c_int32)]
 
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -75,6 +82,7 @@ _PROTOS = {
     "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),
     "seg_adam_step": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp], C.c_int),
     "seg_transpose_w": ([vp, vp, i32, i32, i32, i32, vp], C.c_int),
+    "seg_transpose_w_multi": ([vp, i32, i32, vp], C.c_int),
     "seg_cast_f32_f16": ([vp, vp, i64, vp], C.c_int),
     "seg_pack_input": ([vp, vp, i64, i32, i32, vp], C.c_int),
     "seg_unpack_f32": ([vp, vp, i64, i32, i32, i32, vp], C.c_int),
@@ -84,7 +92,7 @@ _PROTOS = {
 DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
         "seg_add_act_bwd", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
-        "seg_head_fwd", "seg_head_bwd", "seg_transpose_w", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")
+        "seg_head_fwd", "seg_head_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")
 for _n in DUAL:
     _PROTOS[_n + "_f32"] = _PROTOS[_n]
 

@@ -1175,6 +1175,37 @@ __global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, T* wt,
   }
 }
 
+// the same transpose for a table of (weight, K-column slice, destination column offset) jobs in ONE launch: the
+// data-gradient operands of every layer, and the side-by-side slices of a gathered data gradient, are refreshed
+// after each optimiser step; ~50 launches of a few microseconds each otherwise
+template <typename T>
+__global__ __launch_bounds__(TPB) void transpose_w_multi_kernel(const seg_transpose_desc* descs, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;                    // last descriptor with tile0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const seg_transpose_desc d = descs[lo];
+  const int local = blockIdx.x - d.tile0;
+  const int ktn = (d.kcount + 31) / 32, rtn = (d.rows_pad + 31) / 32;
+  const int t = local / (ktn * rtn), rem = local - t * (ktn * rtn);
+  const int kt = rem % ktn, rt = rem / ktn;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = rt * 32 + ty + 8 * j, k = kt * 32 + tx;
+    tile[ty + 8 * j][tx] = (r < d.rows && k < d.kcount && d.k0 + k < d.K) ? d.w[((int64_t)r * d.T + t) * d.K + d.k0 + k] : 0.f;
+  }
+  __syncthreads();
+  T* wt = (T*)d.wt;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = kt * 32 + ty + 8 * j, r = rt * 32 + tx;
+    if (k < d.kcount && r < d.rows_pad) wt[((int64_t)k * d.T + t) * d.dst_ld + d.dst_coff + r] = (T)tile[tx][ty + 8 * j];
+  }
+}
+
 __global__ __launch_bounds__(TPB) void cast_kernel(const float* x, half_t* y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) y[i] = (half_t)x[i];
 }
@@ -1567,6 +1598,16 @@ static int seg_transpose_w_impl(const float* w, void* wt, int32_t rows, int32_t 
 }
 extern "C" int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<half_t>(w, wt, rows, Tn, K, rows_pad, stream); }
 extern "C" int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<float>(w, wt, rows, Tn, K, rows_pad, stream); }
+
+template <typename T>
+static int seg_transpose_w_multi_impl(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) {
+  SEG_CHECK_ARG(descs && n > 0 && total_tiles > 0, "seg_transpose_w_multi: bad arguments");
+  hipLaunchKernelGGL((transpose_w_multi_kernel<T>), dim3(total_tiles), dim3(TPB), 0, ST(stream), descs, n);
+  SEG_CHECK_LAUNCH("seg_transpose_w_multi");
+  return SEG_OK;
+}
+extern "C" int seg_transpose_w_multi(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) { return seg_transpose_w_multi_impl<half_t>(descs, n, total_tiles, stream); }
+extern "C" int seg_transpose_w_multi_f32(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) { return seg_transpose_w_multi_impl<float>(descs, n, total_tiles, stream); }
 
 extern "C" int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && n > 0, "seg_cast_f32_f16: bad arguments");

@@ -162,12 +162,17 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   const int st_row = lane >> 2, st_ch = lane & 3;
   // destination of each 32-column tile: the single output, or one span of the split output (wave-uniform)
   T* obase[TN];
-  int ocs[TN], ocol[TN], olim[TN], oacc[TN];
-  bool any_acc = false;
+  const T* ybase[TN];            // output of the layer whose activation derivative multiplies this span (or null)
+  int ocs[TN], ocol[TN], olim[TN], oacc[TN], dact[TN];
+  float dalpha[TN];
+  bool any_acc = false, any_y = false;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int nbase = n0 + col0 + b * 32;
     obase[b] = out;
+    ybase[b] = nullptr;
+    dact[b] = SEG_ACT_NONE;
+    dalpha[b] = 0.f;
     ocs[b] = p.out_cs; ocol[b] = p.out_coff + nbase; olim[b] = p.n_rows - nbase; oacc[b] = p.accumulate;
     if (p.nout > 0) {
       int start = 0;
@@ -180,11 +185,15 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
           ocol[b] = nbase - start;
           olim[b] = p.out_cs_o[o] - ocol[b];
           oacc[b] = p.out_acc[o];
+          ybase[b] = (const T*)p.out_y[o];
+          dact[b] = p.out_dact[o];
+          dalpha[b] = p.out_dalpha[o];
         }
         start += p.out_span[o];
       }
     }
     any_acc |= oacc[b] != 0;
+    any_y |= ybase[b] != nullptr;
   }
   long opix[TM][2];
 #pragma unroll
@@ -212,10 +221,10 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   // the read-modify-write costs one memory latency per block instead of one per 32x32 tile and row pass
   // (in groups of two 32-row tiles: 16 registers per tile row)
   constexpr int AG = TM > 2 ? 2 : TM;
-  typename Raw8<T>::type oldv[AG][TN][2];
+  typename Raw8<T>::type oldv[AG][TN][2], yv[AG][TN][2];
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
-    if (any_acc && a % AG == 0) {
+    if ((any_acc || any_y) && a % AG == 0) {
 #pragma unroll
       for (int a2 = 0; a2 < AG; ++a2)
 #pragma unroll
@@ -223,8 +232,12 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
 #pragma unroll
           for (int ps = 0; ps < 2; ++ps) {
             Raw8<T>::zero(oldv[a2][b][ps]);
-            if (oacc[b] && opix[a + a2][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b])
-              Raw8<T>::load(obase[b] + (size_t)opix[a + a2][ps] * ocs[b] + ocol[b] + st_ch * 8, oldv[a2][b][ps]);
+            Raw8<T>::zero(yv[a2][b][ps]);
+            if (opix[a + a2][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b]) {
+              const size_t eo = (size_t)opix[a + a2][ps] * ocs[b] + ocol[b] + st_ch * 8;
+              if (oacc[b]) Raw8<T>::load(obase[b] + eo, oldv[a2][b][ps]);
+              if (ybase[b] != nullptr) Raw8<T>::load(ybase[b] + eo, yv[a2][b][ps]);
+            }
           }
     }
 #pragma unroll
@@ -254,6 +267,14 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
         if (opix[a][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b]) {
           T* dst = obase[b] + (size_t)opix[a][ps] * ocs[b] + ocol[b] + st_ch * 8;
           float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if (any_y && ybase[b] != nullptr) {
+            float yf[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) yf[t] = 0.f;
+            Raw8<T>::add(yv[a % AG][b][ps], yf);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) f[t] *= seg_act_grad_from_out(yf[t], dact[b], dalpha[b]);
+          }
           if (any_acc) Raw8<T>::add(oldv[a % AG][b][ps], f);
           store8(dst, f);
         }
@@ -1660,6 +1681,9 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
       tot += a->out_span[o];
     }
     SEG_CHECK_ARG(tot >= a->n_rows, "seg_igemm_fwd: output spans cover %d of %d columns", tot, a->n_rows);
+    for (int o = 0; o < a->nout; ++o)
+      SEG_CHECK_ARG(a->out_y[o] == nullptr || (a->out_ptr[o] != nullptr && a->out_dact[o] >= SEG_ACT_RELU && a->out_dact[o] <= SEG_ACT_SIGMOID),
+                    "seg_igemm_fwd: span %d: fused activation backward needs an output tensor and act in RELU..SIGMOID (got %d)", o, a->out_dact[o]);
   }
   SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_fwd: Kpad=%d not a multiple of 32", a->Kpad);
   SEG_CHECK_ARG(a->variant == 0 || a->variant == 3, "seg_igemm_fwd: variant=%d", a->variant);

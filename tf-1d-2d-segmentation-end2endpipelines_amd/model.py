@@ -35,7 +35,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from ._ffi import ACT, LOSS, Geom, IgemmFwdArgs, IgemmWgradArgs
+from ._ffi import TransposeDesc, ACT, LOSS, Geom, IgemmFwdArgs, IgemmWgradArgs
 from .graph import Graph, Node
 
 BN_PARTS_BWD = 512
@@ -269,7 +269,7 @@ def pick_tile_fwd(M, n_rows, ncls, ktot=1 << 30):
         return (128, 64) if blocks(128, 64) >= 256 else (64, 64)
     if blocks(128, 128) >= 384:
         return 128, 128
-    if blocks(128, 64) >= 256:
+    if blocks(128, 64) >= 128:          # even at half a block per CU the LDS-DMA kernel beats the 64-row register-staged one 2x (8x8 level)
         return 128, 64
     return (64, 128) if blocks(64, 128) >= 256 else (64, 64)
 
@@ -313,6 +313,8 @@ def fwd_halo_patch(g: Geom) -> int:
     return 0
 
 
+FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
+GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
@@ -397,6 +399,7 @@ class DevTensor:
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = True
         self.gw = False          # "gradient written" flag used while the static backward schedule is built
+        self.claimers: List[Optional[tuple]] = []      # who writes this gradient: (dgrad args, span) for conv data gradients, else None
         if DevTensor.registry is not None:
             DevTensor.registry[name] = self
 
@@ -409,10 +412,11 @@ class DevTensor:
             self.grad = torch.zeros_like(self.buf)
         return self.grad
 
-    def claim(self) -> int:
+    def claim(self, owner: Optional[tuple] = None) -> int:
         """Returns the accumulate flag for the next producer of this tensor's gradient."""
         acc = 1 if self.gw else 0
         self.gw = True
+        self.claimers.append(owner)
         self.ensure_grad()
         return acc
 
@@ -578,6 +582,9 @@ class ConvOp(Op):
         self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
         self.wt = torch.zeros(Kpad * self.T * self.rows_pad, dtype=DevTensor.dtype, device=dev) if any(self.need_dgrad) else None
         self.fwd_args = None
+        self.gathered: Dict[int, "GatherDgrad"] = {}      # segment index -> gathered data gradient that covers it
+        self.gather_launch: List["GatherDgrad"] = []      # gathered data gradients launched at the end of this op's backward
+        self.dz_ptr = None
 
     # -- argument blocks (built after the parameter store has been allocated)
     def finalize(self):
@@ -617,10 +624,12 @@ class ConvOp(Op):
         wg.variant = variant
         self.wg_args = wg
 
-    def post_step(self):
-        if self.wt is not None:
-            call("seg_transpose_w", self.m.store.ptr(self.wname, "P"), _p(self.wt), self.n_rows, self.T, self.Kpad,
-                 self.rows_pad, _stream())
+    def transpose_jobs(self):
+        """(w fp32 [rows][T][K], dst, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff) of the derived operands."""
+        if self.wt is None:
+            return []
+        return [(self.m.store.ptr(self.wname, "P").value, self.wt.data_ptr(), self.n_rows, self.T, self.Kpad, 0, self.Kpad,
+                 self.rows_pad, self.rows_pad, 0)]
 
     def forward(self, training):
         st, s = self.m.store, _stream()
@@ -657,38 +666,57 @@ class ConvOp(Op):
         if self.pooled is not None and self.pooled.gw:
             self.pool_acc = self.out.claim()
         self.live = self.out.gw
+        self.fused_act_bwd = False
         if not self.live:
             return
+        # activation backward folded into the epilogue of the only consumer's data gradient (the transposed convs:
+        # LeakyReLU, no BN, consumed by one conv): saves a read-modify-write pass over the gradient
+        if (FUSE_ACT_BWD and not self.has_bn and self.kind != "convlstm" and ACT[self.act] in (1, 2, 3) and self.pool_acc is None
+                and len(self.out.claimers) == 1 and self.out.claimers[0] is not None):
+            ca, span = self.out.claimers[0]
+            ca.out_y[span], ca.out_dact[span], ca.out_dalpha[span] = self.out.buf.data_ptr(), ACT[self.act], float(self.alpha)
+            self.fused_act_bwd = True
         if self.kind == "convlstm":
             self.z.ensure_grad()
         # one data-gradient launch for the whole (virtual) concat: GEMM N = the K axis of the forward weight,
-        # split back onto the segment tensors by the epilogue
+        # split back onto the segment tensors by the epilogue.  Segments whose tensor is handled by a gathered data
+        # gradient (GatherDgrad: one launch per tensor over all its consuming convs) or needs no gradient are left
+        # out: each run of consecutive remaining segments is one launch on that row range of the transposed weight
         self.dg_args = []
-        if any(t.needs_grad for t, _c in self.segs):
+        own = [t.needs_grad and s_i not in self.gathered for s_i, (t, _c) in enumerate(self.segs)]
+        s_i = 0
+        while s_i < len(self.segs):
+            if not own[s_i]:
+                s_i += 1
+                continue
+            e_i = s_i
+            while e_i < len(self.segs) and own[e_i]:
+                e_i += 1
             a = IgemmFwdArgs()
             a.g = self.g_dgrad
             a.nseg = 1
             a.seg_c[0], a.seg_cs[0], a.seg_woff[0] = self.n_rows, self.z.cs, 0
             a.seg_ptr[0] = None     # dz pointer filled in backward()
-            a.w = self.wt.data_ptr()
-            a.Kpad, a.n_rows, a.n_valid = self.rows_pad, self.Kpad, self.Kpad
+            width = sum(_r32(t.cs) for t, _c in self.segs[s_i:e_i])
+            a.w = self.wt.data_ptr() + self.woff[s_i] * self.T * self.rows_pad * self.wt.element_size()
+            a.Kpad, a.n_rows, a.n_valid = self.rows_pad, width, width
             a.out, a.out_cs, a.out_coff, a.accumulate = None, 0, 0, 0
             a.bias, a.act, a.alpha, a.stats = None, 0, 0.0, None
-            a.nout = len(self.segs)
+            a.nout = e_i - s_i
             zero_first, fl = [], 0.0
-            for s_i, (t, _c) in enumerate(self.segs):
-                a.out_span[s_i], a.out_cs_o[s_i] = _r32(t.cs), t.cs
-                if t.needs_grad:
-                    acc = t.claim()
-                    a.out_ptr[s_i], a.out_acc[s_i] = t.grad.data_ptr(), acc
-                    fl += self.flops_seg[s_i]
-                    if self.strided and not acc:
-                        zero_first.append(t)
-                else:
-                    a.out_ptr[s_i], a.out_acc[s_i] = None, 0
+            for o_i, (t, _c) in enumerate(self.segs[s_i:e_i]):
+                a.out_span[o_i], a.out_cs_o[o_i] = _r32(t.cs), t.cs
+                acc = t.claim((a, o_i))
+                a.out_ptr[o_i], a.out_acc[o_i] = t.grad.data_ptr(), acc
+                fl += self.flops_seg[s_i + o_i]
+                if self.strided and not acc:
+                    zero_first.append(t)
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
-            a.tile_m, a.tile_n, a.variant = pick_fwd(Md, self.Kpad, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
+            a.tile_m, a.tile_n, a.variant = pick_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
             self.dg_args.append((a, zero_first, fl))
+            s_i = e_i
+        for grp in self.gather_launch:       # gathered data gradients this op launches (it is their last-running consumer)
+            grp.plan()
 
     def backward(self):
         st, s = self.m.store, _stream()
@@ -716,7 +744,7 @@ class ConvOp(Op):
             self._bias_grad(dz, s, gs_inv)
         else:
             dz = self.out.grad
-            if ACT[self.act] != 0:
+            if ACT[self.act] != 0 and not self.fused_act_bwd:
                 call("seg_act_bwd", _p(dz), _p(self.out.buf), _p(dz), self.out.npix, self.out.cs, self.cout, ACT[self.act],
                      float(self.alpha), None, 1.0, None, s)
             self._bias_grad(dz, s, gs_inv)
@@ -725,6 +753,9 @@ class ConvOp(Op):
                 t.grad.zero_()
             a.seg_ptr[0] = dz.data_ptr()
             call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad:" + self.node.name)
+        self.dz_ptr = dz.data_ptr()
+        for grp in self.gather_launch:
+            grp.launch(s)
         self.wg_args.dz = dz.data_ptr()
         side = self.m.side_stream
         if side is None:
@@ -735,6 +766,73 @@ class ConvOp(Op):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 call("seg_igemm_wgrad", C.byref(self.wg_args), _stream(), flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+
+
+class GatherDgrad:
+    """Data gradient of ONE tensor consumed by several 3x3 / stride-1 convs (the dense skips of UNet++ / UNet 3+: X00
+    feeds X01 .. X05) as one launch: dT = sum_j dz_j (*) W_j[:, T's K columns]^T is a conv over the virtual concat of the
+    dz_j with the row slices of the transposed weights side by side along K.  Against one split-output launch per
+    consumer this writes T's gradient once instead of read-modify-writing it per consumer and runs N = T's channels
+    at the full K depth (level 0 of C3: 530 -> 900 TFLOP/s)."""
+
+    def __init__(self, m, t: DevTensor, members):
+        self.m, self.t, self.members = m, t, members          # members: [(ConvOp, segment index)] in forward order
+        self.coloff, k = [], 0
+        for op, _si in members:
+            self.coloff.append(k)
+            k += op.rows_pad
+        self.Kg = k
+        self.T = members[0][0].T
+        self.w = torch.zeros(t.cs * self.T * self.Kg, dtype=DevTensor.dtype, device=_dev())
+        self.args = None
+        for op, si in members:
+            op.gathered[si] = self
+        members[0][0].gather_launch.append(self)               # first in forward order = last in the backward sweep
+
+    def transpose_jobs(self):
+        return [(self.m.store.ptr(op.wname, "P").value, self.w.data_ptr(), op.n_rows, op.T, op.Kpad, op.woff[si], self.t.cs,
+                 op.rows_pad, self.Kg, self.coloff[j]) for j, (op, si) in enumerate(self.members)]
+
+    def plan(self):
+        op0 = self.members[0][0]
+        a = IgemmFwdArgs()
+        a.g = op0.g_dgrad
+        a.nseg = len(self.members)
+        for j, (op, _si) in enumerate(self.members):
+            a.seg_c[j], a.seg_cs[j], a.seg_woff[j], a.seg_ptr[j] = op.n_rows, op.z.cs, self.coloff[j], None
+        a.w = self.w.data_ptr()
+        a.Kpad, a.n_rows, a.n_valid = self.Kg, self.t.cs, self.t.cs
+        acc = self.t.claim()
+        a.out, a.out_cs, a.out_coff, a.accumulate = self.t.grad.data_ptr(), self.t.cs, 0, acc
+        a.bias, a.act, a.alpha, a.stats, a.nout = None, 0, 0.0, None, 0
+        Md = op0.N * op0.g_dgrad.Hl * op0.g_dgrad.Wl
+        a.tile_m, a.tile_n, a.variant = pick_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, True)
+        self.args = a
+        self.flops = sum(op.flops_seg[si] for op, si in self.members)
+
+    def launch(self, s):
+        a = self.args
+        for j, (op, _si) in enumerate(self.members):
+            a.seg_ptr[j] = op.dz_ptr
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops, tag="dgrad:gather:" + self.t.name)
+
+
+def plan_gathers(m, ops) -> List[GatherDgrad]:
+    """Tensors with >= 2 consuming 3x3 stride-1 convs whose data-gradient geometry the halo-tile kernel takes."""
+    if m.dtype != "f16" or not GATHER_DGRAD:
+        return []
+    users: Dict[int, list] = {}
+    tens: Dict[int, DevTensor] = {}
+    for op in ops:
+        if not isinstance(op, ConvOp) or op.kind != "conv" or op.wt is None:
+            continue
+        if tuple(op.node.attrs["kernel"]) != (3, 3) or tuple(op.node.attrs.get("strides", (1, 1))) != (1, 1) or not fwd_halo_patch(op.g_dgrad):
+            continue
+        for si, (t, _c) in enumerate(op.segs):
+            if t.needs_grad:
+                users.setdefault(id(t), []).append((op, si))
+                tens[id(t)] = t
+    return [GatherDgrad(m, tens[k], mem) for k, mem in users.items() if 2 <= len(mem) <= _ffi.MAX_SEG]
 
 
 def _pad_to(n):
@@ -1167,6 +1265,8 @@ class SegModel:
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.finalize()
+        self.gathers = [] if _DryRun.on else plan_gathers(self, self.ops)
+        self._build_transpose_table()
         self.set_weights({p.name: init_param(p, self.seed) for p in g.param_specs()})
         # ---- static backward schedule (accumulate flags)
         for op in reversed(self.ops):
@@ -1177,6 +1277,29 @@ class SegModel:
             self.side_stream = torch.cuda.Stream()
         self.built = True
         return self
+
+    def _build_transpose_table(self):
+        """Device table of every derived (transposed) weight operand: refreshed by ONE launch after each optimiser step."""
+        jobs = []
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                jobs += op.transpose_jobs()
+        for grp in self.gathers:
+            jobs += grp.transpose_jobs()
+        self.tr_n, self.tr_tiles, self.tr_table = len(jobs), 0, None
+        if not jobs or _DryRun.on:
+            return
+        arr = (TransposeDesc * len(jobs))()
+        for d, (w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff) in zip(arr, jobs):
+            d.w, d.wt, d.rows, d.T, d.K, d.k0, d.kcount, d.rows_pad, d.dst_ld, d.dst_coff = w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff
+            d.tile0 = self.tr_tiles
+            self.tr_tiles += T * _cdiv(kcount, 32) * _cdiv(rows_pad, 32)
+        self.tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(_dev())
+
+    def refresh_derived(self):
+        """Re-derive the data-gradient operands from the master weights (after an optimiser step / weight import)."""
+        if self.tr_table is not None:
+            call("seg_transpose_w_multi", _p(self.tr_table), self.tr_n, self.tr_tiles, _stream())
 
     def _materialise(self, val, i) -> DevTensor:
         v = val[i]
@@ -1241,6 +1364,7 @@ class SegModel:
             call("seg_cast_f32_f16", _p(st.P), _p(st.P16), st.P.numel(), _stream())
         for op in self.ops:
             op.post_step()
+        self.refresh_derived()
 
     # ---------------------------------------------------------------- execution
     def _check_x(self, x):
@@ -1338,6 +1462,7 @@ class SegModel:
              self.epsilon, 1.0 / self.world_size, _stream())
         for op in self.ops:
             op.post_step()
+        self.refresh_derived()
 
     def train_step(self, x, targets, loss: Optional[str] = None) -> torch.Tensor:
         """One optimiser step = Keras' default train_step (Train.py:394-415): forward (training BN) -> loss -> backward
