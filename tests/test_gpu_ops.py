@@ -704,12 +704,17 @@ def test_head_fwd_bwd(Cin, Cout, act, stride):
     dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
     dyd = dy.cuda().contiguous()
     ffi.call("seg_head_bwd", P(dyd), P(yd), P(xd), cs, Cin, N, H, W, stride, stride, P(wd), cs, Cout, ACT[act], P(dx), 0,
-             P(gsv), P(dw), P(db), stream())
+             P(gsv), P(dw), P(db), None, 0, stream())                              # no workspace: atomics
+    work = torch.full((7 * Cout * (cs + 1) + 3,), 1e30, device="cuda")             # room for 7 blocks of partial rows
+    dw2, db2 = torch.zeros_like(wd), torch.zeros_like(bd)
+    ffi.call("seg_head_bwd", P(dyd), P(yd), P(xd), cs, Cin, N, H, W, stride, stride, P(wd), cs, Cout, ACT[act], None, 0,
+             P(gsv), P(dw2), P(db2), P(work), work.numel(), stream())
     torch.cuda.synchronize()
     assert float((yd.cpu() - y.detach()).abs().max()) < 2e-5
     assert rel(from_dev(dx, Cin) / 16.0, x.grad) < 1e-3
-    assert rel(dw[:, :Cin].cpu(), kern.grad.reshape(Cin, Cout).T) < 1e-4
-    assert rel(db.cpu(), b.grad) < 1e-4
+    for dw_, db_ in ((dw, db), (dw2, db2)):
+        assert rel(dw_[:, :Cin].cpu(), kern.grad.reshape(Cin, Cout).T) < 1e-4
+        assert rel(db_.cpu(), b.grad) < 1e-4
 
 
 @pytest.mark.parametrize("kind,Cc", [("mse", 1), ("mse", 3), ("bce", 1), ("cce", 4), ("cce", 2)])

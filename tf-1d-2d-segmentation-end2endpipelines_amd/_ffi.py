@@ -76,7 +76,7 @@ _PROTOS = {
     "seg_convlstm_gate_fwd": ([vp, i32, vp, i32, i64, i32, vp], C.c_int),
     "seg_convlstm_gate_bwd": ([vp, i32, vp, i32, vp, i64, i32, vp], C.c_int),
     "seg_head_fwd": ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp], C.c_int),
-    "seg_head_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp], C.c_int),
+    "seg_head_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i64, vp], C.c_int),
     "seg_loss_fwd_bwd": ([i32, vp, vp, i64, i32, vp, vp, vp], C.c_int),
     "seg_absmax": ([vp, i64, vp, vp], C.c_int),
     "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),

@@ -173,6 +173,12 @@ __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* stats, in
 // (grid stride a multiple of the chunks per pixel - always true for power-of-two channel counts).
 constexpr int UNR = 4;
 
+// pixel index of flat item idx = pix * CH + chunk.  A 64-bit division costs tens of VALU instructions per item -
+// more than the memory system gives these kernels time for - so power-of-two chunk counts (every 8.. 2048-channel
+// tensor of the hot path) take a shift.
+__device__ __forceinline__ int ch_shift(int CH) { return (CH & (CH - 1)) == 0 ? __ffs(CH) - 1 : -1; }
+__device__ __forceinline__ int64_t div_ch(int64_t idx, int CH, int shift) { return shift >= 0 ? (idx >> shift) : idx / CH; }
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs, int x_coff, T* y, int y_cs, int y_coff,
                                                            int64_t npix, int C, int c_valid, const float* scale, const float* shift,
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs,
   const int64_t items = npix * CH, stride = (int64_t)gridDim.x * TPB;
   const int64_t it0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const bool fixed = (stride % CH) == 0;
+  const int chs = ch_shift(CH);
   const int chf = (int)(it0 % CH);
   float sc[8], sh[8];
 #pragma unroll
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs,
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int64_t idx = it + u * stride;
-      pix[u] = idx / CH;
+      pix[u] = div_ch(idx, CH, chs);
       ch[u] = fixed ? chf : (int)(idx - pix[u] * CH);
       if (idx < items) load8(x + pix[u] * x_cs + x_coff + ch[u] * 8, f[u]);
     }
@@ -319,59 +326,58 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
                                                                int x_coff, T* dx, int dx_cs, int dx_coff, int64_t npix, int C,
                                                                const float* scale, const float* shift, const float* mean,
                                                                const float* invstd, const float* c1, const float* c2, int act,
-                                                               float alpha, int accumulate) {
-  const int CH = C / 8;
-  const int64_t items = npix * CH, stride = (int64_t)gridDim.x * TPB;
-  const int64_t it0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  const bool fixed = (stride % CH) == 0;
-  const int chf = (int)(it0 % CH);
+                                                               float alpha, int accumulate, ColLayout L) {
+  // thread = (pixel row rowi, channel chunk col); blocks walk the tensor in interleaved chunks of RP * UNR pixels (as
+  // act_bwd_kernel: concurrently running blocks stream neighbouring addresses - 2.9 -> 4.5 TB/s against a plain
+  // grid-stride loop whose four loads per thread are megabytes apart); the channel chunk of a thread is fixed, so
+  // the per-channel coefficients live in registers
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
   const bool train = c1 != nullptr;
-  // dx = sc * (g - c1 - (x - mu) * is * c2) = g * sc + x * ka + kb   with ka = -sc*is*c2, kb = sc*(mu*is*c2 - c1)
-  float sc[8], sh[8], ka[8], kb[8];
-  auto coef = [&](int c, float& s_, float& h_, float& a_, float& b_) {
-    s_ = scale[c];
-    h_ = shift[c];
-    if (train) {
-      const float k = invstd[c] * c2[c];
-      a_ = -s_ * k;
-      b_ = s_ * (mean[c] * k - c1[c]);
-    } else {
-      a_ = 0.f;
-      b_ = 0.f;
-    }
-  };
+  const int64_t chunk = (int64_t)L.RP * UNR;
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    if (ch >= L.CH) continue;
+    // dx = sc * (g - c1 - (x - mu) * is * c2) = g * sc + x * ka + kb   with ka = -sc*is*c2, kb = sc*(mu*is*c2 - c1)
+    float sc[8], sh[8], ka[8], kb[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) coef(chf * 8 + t, sc[t], sh[t], ka[t], kb[t]);
-  for (int64_t it = it0; it < items; it += stride * UNR) {
-    float g[UNR][8], xv[UNR][8], old[UNR][8];
-    int64_t pix[UNR];
-    int ch[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int64_t idx = it + u * stride;
-      pix[u] = idx / CH;
-      ch[u] = fixed ? chf : (int)(idx - pix[u] * CH);
-      if (idx < items) {
-        load8(dy + pix[u] * dy_cs + dy_coff + ch[u] * 8, g[u]);
-        load8(x + pix[u] * x_cs + x_coff + ch[u] * 8, xv[u]);
-        if (accumulate) load8(dx + pix[u] * dx_cs + dx_coff + ch[u] * 8, old[u]);
+    for (int t = 0; t < 8; ++t) {
+      const int c = ch * 8 + t;
+      sc[t] = scale[c];
+      sh[t] = shift[c];
+      if (train) {
+        const float k = invstd[c] * c2[c];
+        ka[t] = -sc[t] * k;
+        kb[t] = sc[t] * (mean[c] * k - c1[c]);
+      } else {
+        ka[t] = 0.f;
+        kb[t] = 0.f;
       }
     }
+    for (int64_t pb = blockIdx.x * chunk + rowi; pb < npix; pb += chunk * gridDim.x) {
+      float g[UNR][8], xv[UNR][8], old[UNR][8];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (it + u * stride >= items) continue;
-      float o[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float s_, h_, a_, b_;
-        if (fixed) { s_ = sc[t]; h_ = sh[t]; a_ = ka[t]; b_ = kb[t]; }
-        else coef(ch[u] * 8 + t, s_, h_, a_, b_);
-        const float yv = seg_act(xv[u][t] * s_ + h_, act, alpha);
-        const float gg = g[u][t] * seg_act_grad_from_out(yv, act, alpha);
-        o[t] = train ? gg * s_ + xv[u][t] * a_ + b_ : gg * s_;
-        if (accumulate) o[t] += old[u][t];
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = pb + (int64_t)u * L.RP;
+        if (pix < npix) {
+          load8(dy + pix * dy_cs + dy_coff + ch * 8, g[u]);
+          load8(x + pix * x_cs + x_coff + ch * 8, xv[u]);
+          if (accumulate) load8(dx + pix * dx_cs + dx_coff + ch * 8, old[u]);
+        }
       }
-      store8(dx + pix[u] * dx_cs + dx_coff + ch[u] * 8, o);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = pb + (int64_t)u * L.RP;
+        if (pix >= npix) continue;
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float yv = seg_act(xv[u][t] * sc[t] + sh[t], act, alpha);
+          const float gg = g[u][t] * seg_act_grad_from_out(yv, act, alpha);
+          o[t] = train ? gg * sc[t] + xv[u][t] * ka[t] + kb[t] : gg * sc[t];
+          if (accumulate) o[t] += old[u][t];
+        }
+        store8(dx + pix * dx_cs + dx_coff + ch * 8, o);
+      }
     }
   }
 }
@@ -788,8 +794,10 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* x, int cs, int C
   for (int k = 0; k < CO; ++k)
 #pragma unroll
     for (int t = 0; t < 8; ++t) wr[k][t] = (one && k < Cout && sub * 8 + t < Cin) ? w[k * w_ld + sub * 8 + t] : 0.f;
-  const int64_t pstride = (int64_t)gridDim.x * gpb;
-  for (int64_t pb = (int64_t)blockIdx.x * gpb; pb < npix; pb += pstride * UNR) {
+  // a block owns chunks of gpb * UNR consecutive pixels, interleaved over the grid (neighbouring blocks stream
+  // neighbouring addresses); pixel u of a trip is gpb further on
+  const int64_t pstride = gpb;
+  for (int64_t pb = (int64_t)blockIdx.x * gpb * UNR; pb < npix; pb += (int64_t)gridDim.x * gpb * UNR) {
     float acc[UNR][CO];
     float f[UNR][8];
     bool ok[UNR];
@@ -895,8 +903,10 @@ __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const
   for (int k = 0; k < CO; ++k)
 #pragma unroll
     for (int t = 0; t < 8; ++t) wr[k][t] = (one && k < Cout && sub * 8 + t < Cin) ? w[k * w_ld + sub * 8 + t] * gs : 0.f;
-  const int64_t pstride = (int64_t)gridDim.x * gpb;
-  for (int64_t pb = (int64_t)blockIdx.x * gpb; pb < npix; pb += pstride * UNR) {
+  // a block owns chunks of gpb * UNR consecutive pixels, interleaved over the grid (neighbouring blocks stream
+  // neighbouring addresses); pixel u of a trip is gpb further on
+  const int64_t pstride = gpb;
+  for (int64_t pb = (int64_t)blockIdx.x * gpb * UNR; pb < npix; pb += (int64_t)gridDim.x * gpb * UNR) {
     float d[UNR][CO], old[UNR][8];
     T* dp[UNR];
     bool ok[UNR];
@@ -965,13 +975,12 @@ __global__ __launch_bounds__(TPB) void head_bwd_dx_kernel(const float* dy, const
 template <typename T, int CO>
 __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const float* y, const T* x, int cs, int Cin, int N, int H,
                                                           int W, int sy, int sx, int w_ld, int Cout, int act, float* dw, float* db,
-                                                          ColLayout L) {
+                                                          float* work, ColLayout L) {
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
   const int HO = (H + sy - 1) / sy, WO = (W + sx - 1) / sx;
   const int64_t npix = (int64_t)N * HO * WO;
-  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  const int64_t p1 = npix;
   for (int grp = 0; grp < L.ngrp; ++grp) {
     const int ch = grp * L.CHP + col;
     float acc[CO][8];
@@ -985,7 +994,7 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
     if (ch < L.CH) {
       // UNR pixels per trip, every load issued before the first use (a block walks thousands of pixels: one load
       // in flight per thread leaves the kernel latency-bound)
-      for (int64_t pb = p0 + rowi; pb < p1; pb += (int64_t)L.RP * UNR) {
+      for (int64_t pb = (int64_t)blockIdx.x * L.RP * UNR + rowi; pb < p1; pb += (int64_t)gridDim.x * L.RP * UNR) {
         float dyv[UNR][CO], yv[UNR][CO], f[UNR][8];
         bool ok[UNR];
 #pragma unroll
@@ -1020,12 +1029,17 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
     }
     block_col_reduce<CO>(acc, sm, rowi, col, L.CHP, L.RP);
     if (rowi == 0 && ch < L.CH) {
+      // with a workspace every block stores its partial row (summed by head_bwd_dw_finalize_kernel); without one the
+      // Cout x Cin sums of all blocks meet in the same few cache lines as atomics (~4 ns each, serialised)
 #pragma unroll
       for (int k = 0; k < CO; ++k)
         if (k < Cout) {
 #pragma unroll
           for (int t = 0; t < 8; ++t)
-            if (ch * 8 + t < Cin) atomicAdd(dw + k * w_ld + ch * 8 + t, acc[k][t]);
+            if (ch * 8 + t < Cin) {
+              if (work != nullptr) work[((size_t)blockIdx.x * Cout + k) * w_ld + ch * 8 + t] = acc[k][t];
+              else atomicAdd(dw + k * w_ld + ch * 8 + t, acc[k][t]);
+            }
         }
     }
     if (grp == 0 && db != nullptr) {   // bias: column 0 threads of every row-group
@@ -1038,9 +1052,36 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_kernel(const float* dy, const
       if (threadIdx.x < Cout) {
         float s = 0.f;
         for (int r = 0; r < L.RP; ++r) s += sm[r * CO + threadIdx.x];
-        atomicAdd(db + threadIdx.x, s);
+        if (work != nullptr) work[(size_t)gridDim.x * Cout * w_ld + (size_t)blockIdx.x * Cout + threadIdx.x] = s;
+        else atomicAdd(db + threadIdx.x, s);
       }
     }
+  }
+}
+
+// dw[k][c] += sum_b work[b][k][c],  db[k] += sum_b workb[b][k]: 16 outputs x 16 partial lanes per block, the lanes of
+// an output stride through the blocks' rows and meet in LDS
+__global__ __launch_bounds__(TPB) void head_bwd_dw_finalize_kernel(const float* work, int nblk, int Cin, int w_ld, int Cout, float* dw,
+                                                                   float* db) {
+  __shared__ float sm[16][17];
+  const int o = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  const int nw = Cout * w_ld;
+  float s = 0.f;
+  if (o < nw) {
+    for (int b = pl; b < nblk; b += 16) s += work[(size_t)b * nw + o];
+  } else if (o < nw + Cout) {
+    for (int b = pl; b < nblk; b += 16) s += work[(size_t)nblk * nw + (size_t)b * Cout + (o - nw)];
+  }
+  sm[pl][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (pl != 0) return;
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t += sm[j][threadIdx.x];
+  if (o < nw) {
+    if (o % w_ld < Cin) dw[o] += t;
+  } else if (o < nw + Cout && db != nullptr) {
+    db[o - nw] += t;
   }
 }
 
@@ -1338,9 +1379,12 @@ static int seg_bn_act_bwd_apply_impl(const void* dy, int32_t dy_cs, int32_t dy_c
   SEG_CHECK_ARG(dy && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
                     dx_coff + C <= dx_cs && (c1 == nullptr || (c2 && mean && invstd)),
                 "seg_bn_act_bwd_apply: bad arguments");
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(grid_for((npix * (C / 8) + UNR - 1) / UNR)), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
+  const ColLayout L = col_layout(C);
+  int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
                      (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
-                     accumulate);
+                     accumulate, L);
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply");
   return SEG_OK;
 }
@@ -1526,7 +1570,7 @@ extern "C" int seg_head_fwd_f32(const void* x, int32_t cs, int32_t Cin, int32_t 
 template <typename T>
 static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W,
                             int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate,
-                            const float* gs_ptr, float* dw, float* db, seg_stream_t stream) {
+                            const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && y && x && w && Cin > 0 && Cin <= cs && (cs & 7) == 0 && Cout >= 1 && Cout <= HEAD_MAXC && w_ld >= Cin,
                 "seg_head_bwd: bad arguments");
   const int64_t npix = (int64_t)N * ((H + sy - 1) / sy) * ((W + sx - 1) / sx);
@@ -1540,17 +1584,29 @@ static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int
                 accumulate, gs_ptr, LPP);
   }
   if (dw != nullptr) {
-    int blocks = (int)((npix + 1023) / 1024);      // every block ends with Cout*Cin same-address atomics: keep the count low
-    if (blocks > 256) blocks = 256;
+    // with a workspace: up to work_elems / (Cout * (w_ld + 1)) blocks (1024 fill the chip), partial rows + a finalize
+    // launch; without: every block ends with Cout*Cin same-address atomics, so the count is kept low
+    int blocks = (int)((npix + 1023) / 1024);
+    int cap = 256;
+    if (work != nullptr) {
+      cap = (int)(work_elems / ((int64_t)Cout * (w_ld + 1)));
+      if (cap > 1024) cap = 1024;
+      SEG_CHECK_ARG(cap >= 1, "seg_head_bwd: workspace of %ld floats is too small", (long)work_elems);
+      blocks = (int)((npix + 255) / 256);
+    }
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     SEG_HEAD_CO(head_bwd_dw_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), dy, y, (const T*)x, cs, Cin, N, H, W, sy, sx, w_ld, Cout, act, dw,
-                db, col_layout(((Cin + 7) / 8) * 8));
+                db, work, col_layout(((Cin + 7) / 8) * 8));
+    if (work != nullptr)
+      hipLaunchKernelGGL(head_bwd_dw_finalize_kernel, dim3((Cout * w_ld + Cout + 15) / 16), dim3(TPB), 0, ST(stream), work, blocks, Cin,
+                         w_ld, Cout, dw, db);
   }
   SEG_CHECK_LAUNCH("seg_head_bwd");
   return SEG_OK;
 }
-extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream) { return seg_head_bwd_impl<half_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, stream); }
-extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, seg_stream_t stream) { return seg_head_bwd_impl<float>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, stream); }
+extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<half_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
+extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<float>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
 
 extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float* loss_out, float* dpred,
                                 seg_stream_t stream) {

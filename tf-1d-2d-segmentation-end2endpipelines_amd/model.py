@@ -854,6 +854,7 @@ class HeadOp(Op):
         Ho, Wo = node.shape[0], node.shape[1]
         self.y = torch.zeros((x.N, Ho, Wo, self.cout), dtype=torch.float32, device=_dev())
         self.dy = torch.zeros_like(self.y)
+        self.work = torch.zeros(1024 * self.cout * (self.w_ld + 1), dtype=torch.float32, device=_dev())     # weight-gradient partial rows
         cin, cout, w_ld = self.cin, self.cout, self.w_ld
         kspec, bspec = node.params[0], node.params[1]
 
@@ -880,7 +881,7 @@ class HeadOp(Op):
         call("seg_head_bwd", _p(self.dy), _p(self.y), _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W,
              self.sy, self.sx, st.ptr(self.wname), self.w_ld, self.cout, self.act,
              _p(self.x.grad) if self.acc is not None else None, self.acc or 0, _p(self.m.gs), st.ptr(self.wname, "G"),
-             st.ptr(self.bname, "G"), _stream())
+             st.ptr(self.bname, "G"), _p(self.work), self.work.numel(), _stream())
 
 
 class BNOp(Op):

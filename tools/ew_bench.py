@@ -50,8 +50,9 @@ b = torch.zeros(1, device="cuda")
 yo = torch.zeros((N, H, W, 1), device="cuda")
 dyo = torch.rand((N, H, W, 1), device="cuda")
 dw, dbb = torch.zeros(1, Cc, device="cuda"), torch.zeros(1, device="cuda")
+hwork = torch.zeros(1024 * (Cc + 1), device="cuda")
 timeit("head_fwd (64->1 sigmoid)", lambda: ffi.call("seg_head_fwd", P(x), Cc, Cc, N, H, W, 1, 1, P(w), Cc, P(b), 1, 3, P(yo), stream()), T + npix * 4)
-timeit("head_bwd (dx acc + dw)", lambda: ffi.call("seg_head_bwd", P(dyo), P(yo), P(x), Cc, Cc, N, H, W, 1, 1, P(w), Cc, 1, 3, P(dx), 1, P(gs), P(dw), P(dbb), stream()), 3 * T + 2 * npix * 4)
+timeit("head_bwd (dx acc + dw)", lambda: ffi.call("seg_head_bwd", P(dyo), P(yo), P(x), Cc, Cc, N, H, W, 1, 1, P(w), Cc, 1, 3, P(dx), 1, P(gs), P(dw), P(dbb), P(hwork), hwork.numel(), stream()), 3 * T + 2 * npix * 4)
 pf = torch.rand(199_000_000, device="cuda")
 g_, m_, v_ = torch.rand_like(pf), torch.zeros_like(pf), torch.zeros_like(pf)
 p16 = torch.zeros(pf.numel(), dtype=torch.float16, device="cuda")
