@@ -1334,9 +1334,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   const int H = g.Hin, W = g.Win;
 
   // ---- which (64-row tile, 64-channel plane, patch range) is this block
+  // logical order: patch range (z) slowest, then sub-pixel class (y), then (row tile, plane): every block that reads
+  // the same pixels - other planes / row tiles re-read dz, the four classes of a transposed conv re-read the input
+  // halo - is handed to the same XCD and meets the data in its L2
   const int rtiles = (p.n_rows + 63) / 64;
-  const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
-  const int bz = lin / gridDim.x, bx = lin - bz * gridDim.x;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int bz = lin / (gridDim.x * gridDim.y);
+  const int lrem = lin - bz * (gridDim.x * gridDim.y);
+  const int bcls = lrem / gridDim.x, bx = lrem - bcls * gridDim.x;
   const int rt = bx % rtiles;
   int pl = bx / rtiles;
   int seg = 0;
@@ -1355,7 +1360,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   if (q0 >= q1) return;
   // taps: a 3x3 conv uses all nine halo shifts t = 3 (dy + 1) + dx + 1 in geometry order; a sub-pixel class of the
   // 4x4 / stride-2 transposed conv (TC) uses four of them against the stride-2 pixels (oy, ox) of dz
-  const int cls = TC ? (int)blockIdx.y : 0;
+  const int cls = TC ? bcls : 0;
   unsigned tmask = TC ? 0u : 0x1ffu;
   int wmap[9];
 #pragma unroll
