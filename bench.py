@@ -81,7 +81,7 @@ def pmc_traffic(entry_point):
     return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(workload, sample_batch=1, steps=1):
+def cpu_baseline(workload, sample_batch=1, steps=4):
     """The oracle (torch-CPU fp32 restatement of the reference graph, kind 'port') timed on the host cores:
     forward + backward + Keras Adam on a bounded sample (smaller batch, same model and resolution)."""
     from oracle.keras_ref import Layers

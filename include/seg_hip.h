@@ -129,6 +129,8 @@ typedef struct seg_igemm_wgrad_args {
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
 /* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */
 int seg_wgrad_halo_patch(const seg_geom* g);
+/* blocks along the class axis of the variant-2 kernel (1: conv; 2: transposed conv on the class-pair kernel; 4)     */
+int seg_wgrad_halo_class_groups(const seg_geom* g);
 /* taps one block of seg_igemm_wgrad handles for this tile (layers with <= 64 output channels use a multi-tap
  * kernel that reads the dz tile once for 3 / 4 / 9 taps); the host sizes `splitk` with it.                       */
 int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int variant);

@@ -1508,6 +1508,186 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   }
 #endif
 }
+// ---------------------------------------------------------------------------------------------------------
+// the same for Conv2DTranspose(4x4, stride 2), two sub-pixel classes per block: class (py, 0) and (py, 1) read
+// horizontally adjacent dz pixels and 2 x 2 of the same six halo shifts (dy in {0,-1} for py = 0, {1,0} for py = 1;
+// dx in {0,-1} for px = 0, {1,0} for px = 1 - the tap table of model.geom_convT, checked by the launcher).  One input
+// halo tile + two dz tiles per 64-pixel patch, 8 accumulator tiles per wave, 32 MFMAs per barrier instead of 16:
+// the per-class form is bound by its fixed cost per patch (LDS-DMA pieces, barrier), not by MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_igemm_wgrad_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int R = 64 / C, HC = C + 2, HROWS = (R + 2) * HC;
+  constexpr int NI_IN = (HROWS + 7) / 8, NI_W = (NI_IN + 3) / 4;
+  constexpr int Z_BYTES = 64 * 128, IN_BYTES = NI_IN * 1024, STAGE = 2 * Z_BYTES + IN_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+  typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const seg_geom& g = p.g;
+  const int H = g.Hin, W = g.Win, Ho = g.Hout, Wo = g.Wout;
+
+  const int rtiles = (p.n_rows + 63) / 64;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int bz = lin / (gridDim.x * gridDim.y);
+  const int lrem = lin - bz * (gridDim.x * gridDim.y);
+  const int py = lrem / gridDim.x, bx = lrem - py * gridDim.x;       // class row
+  const int rt = bx % rtiles;
+  int pl = bx / rtiles;
+  int seg = 0;
+  for (; seg < p.nseg; ++seg) {
+    const int t = (p.seg_c[seg] + 63) / 64;
+    if (pl < t) break;
+    pl -= t;
+  }
+  if (seg >= p.nseg) return;
+  const int r0 = rt * 64, c0 = pl * 64;
+  const int sc = p.seg_c[seg], cs2 = p.seg_cs[seg] * 2, dzcs2 = p.dz_cs * 2;
+  const int PW = W / C, PH = H / R;
+  const int npatch = g.N * PH * PW;
+  const int per = (npatch + p.splitk - 1) / p.splitk;
+  const int q0 = bz * per, q1 = min(npatch, q0 + per);
+  if (q0 >= q1) return;
+
+  auto uniform_ptr = [](const void* q) -> void* {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+  };
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.seg_ptr[seg]), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * cs2), 0x00020000);
+  const auto rsrc_dz = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.dz), 0, __builtin_amdgcn_readfirstlane(g.N * Ho * Wo * dzcs2), 0x00020000);
+
+  const int lrow = lane >> 3, lch = lane & 7;
+  unsigned z_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + lrow;
+    const int gch = lch ^ (((row >> 1) & 1) << 2);
+    const int yy = row / C, xx = row % C;
+    z_voff[i] = (r0 + gch * 8 < p.n_rows) ? (unsigned)((yy * 2 * Wo + xx * 2) * dzcs2 + (p.dz_coff + r0 + gch * 8) * 2) : OOB_OFF;
+  }
+  int in_dy[NI_W], in_dx[NI_W], in_cb[NI_W];
+#pragma unroll
+  for (int k = 0; k < NI_W; ++k) {
+    const int i = wave + 4 * k;
+    const int row = i * 8 + lrow;
+    const int gch = lch ^ (((row >> 1) & 1) << 2);
+    const int yy = row / HC, xx = row - yy * HC;
+    in_dy[k] = yy - 1;
+    in_dx[k] = xx - 1;
+    in_cb[k] = (i < NI_IN && row < HROWS && c0 + gch * 8 < sc) ? (c0 + gch * 8) * 2 : -1;
+  }
+  int pn_ = q0 / (PH * PW);
+  int py_ = (q0 - pn_ * (PH * PW)) / PW;
+  int px_ = q0 - pn_ * (PH * PW) - py_ * PW;
+  auto issue = [&](int stage) {
+    const int n = pn_, y0 = py_ * R, x0 = px_ * C;
+    if (++px_ == PW) {
+      px_ = 0;
+      if (++py_ == PH) { py_ = 0; ++pn_; }
+    }
+    unsigned char* sb = smem + stage * STAGE;
+    const int zs = ((n * Ho + y0 * 2 + py) * Wo + x0 * 2) * dzcs2;          // class (py, 0); (py, 1) is the next pixel
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dz, (lds_ptr_t)(sb + c2 * Z_BYTES + (wave * 2 + i) * 1024), 16, z_voff[i], zs + c2 * dzcs2, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NI_W; ++k) {
+      if (wave + 4 * k < NI_IN) {
+        const int y = y0 + in_dy[k], x = x0 + in_dx[k];
+        const bool ok = in_cb[k] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)(((n * H + y) * W + x) * cs2 + in_cb[k]) : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(sb + 2 * Z_BYTES + (wave + 4 * k) * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  const int tg = lane >> 4, tt = lane & 15, tq = tt >> 2, tp = tt & 3;
+  const int j = 8 * (tg >> 1) + tq;
+  const int cbA = (wm * 32 + 16 * (tg & 1) + 4 * tp) * 2, cbB = (wn * 32 + 16 * (tg & 1) + 4 * tp) * 2;
+  const int offA = j * 128 + (cbA ^ (((j >> 1) & 1) << 6));
+  int offB[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) offB[r] = j * 128 + (cbB ^ ((((r + j) >> 1) & 1) << 6));
+  auto trfrag = [&](const unsigned char* ad) -> h8 {
+    s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
+    s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * 128));
+    h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
+    return h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
+  };
+
+  f16v acc[8];        // [class px][iy][ix]
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  auto compute = [&](auto pyc, int stage) {
+    constexpr int PY = decltype(pyc)::value;
+    const unsigned char* Zs = smem + stage * STAGE;
+    const unsigned char* Is = Zs + 2 * Z_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      constexpr int KPR = C / 16;
+      const int yy = kb / KPR, xx0 = (kb % KPR) * 16;
+      const h8 af0 = trfrag(Zs + kb * 16 * 128 + offA), af1 = trfrag(Zs + Z_BYTES + kb * 16 * 128 + offA);
+#pragma unroll
+      for (int iy = 0; iy < 2; ++iy) {
+        const int dy = PY == 0 ? (iy == 0 ? 0 : -1) : (iy == 0 ? 1 : 0);
+        const int hb0 = (yy + 1 + dy) * HC + xx0 + 1;               // halo row of pixel 0 of this K block at dx = 0
+        const h8 bm = trfrag(Is + (hb0 - 1) * 128 + offB[(hb0 - 1) & 3]);
+        const h8 bz_ = trfrag(Is + hb0 * 128 + offB[hb0 & 3]);
+        const h8 bp = trfrag(Is + (hb0 + 1) * 128 + offB[(hb0 + 1) & 3]);
+        acc[iy * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bz_, acc[iy * 2 + 0], 0, 0, 0);       // px = 0: dx = 0, -1
+        acc[iy * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bm, acc[iy * 2 + 1], 0, 0, 0);
+        acc[4 + iy * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bp, acc[4 + iy * 2 + 0], 0, 0, 0);  // px = 1: dx = 1, 0
+        acc[4 + iy * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bz_, acc[4 + iy * 2 + 1], 0, 0, 0);
+      }
+    }
+  };
+  auto run = [&](auto pyc) {
+    int stage = 0;
+    issue(0);
+    for (int q = q0; q < q1; ++q) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (q + 1 < q1) issue(stage ^ 1);
+      compute(pyc, stage);
+      stage ^= 1;
+    }
+  };
+  if (py == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+
+  float sc_mul = p.scale;
+  if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
+  float* dw = p.dw;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int kcol = c0 + wn * 32 + fr;
+  if (kcol < sc) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int widx = g.tap_w[(py * 2 + (t >> 2)) * 4 + (t & 3)];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+        if (row < p.n_rows) atomicAdd(dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol, acc[t][q] * sc_mul);
+      }
+    }
+  }
+#endif
+}
+template __global__ void igemm_wgrad_halo_tc2_kernel<32>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_tc2_kernel<16>(const seg_igemm_wgrad_args);
+
 template __global__ void igemm_wgrad_halo_kernel<32, false>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<16, false>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<32, true>(const seg_igemm_wgrad_args);
@@ -1767,6 +1947,23 @@ extern "C" int seg_wgrad_halo_patch(const seg_geom* g) {
   return 0;
 }
 
+// blocks along the class axis of the variant-2 kernel: 1 for a conv, 2 when the four classes of a transposed conv
+// follow the tap table of the class-pair kernel (classes py*2+px; taps iy*2+ix with dy = {0,-1} / {1,0} for py = 0 / 1
+// and dx likewise for px), 4 otherwise.  The host sizes splitk with it.
+extern "C" int seg_wgrad_halo_class_groups(const seg_geom* g) {
+  if (g == nullptr || g->ncls != 4 || g->ntaps != 4) return g != nullptr && g->ncls == 1 ? 1 : (g != nullptr ? g->ncls : 0);
+  for (int c = 0; c < 4; ++c) {
+    const int py = c >> 1, px = c & 1;
+    if (g->oy[c] != py || g->ox[c] != px) return 4;
+    for (int t = 0; t < 4; ++t) {
+      const int iy = t >> 1, ix = t & 1;
+      const int dy = py == 0 ? (iy == 0 ? 0 : -1) : (iy == 0 ? 1 : 0), dx = px == 0 ? (ix == 0 ? 0 : -1) : (ix == 0 ? 1 : 0);
+      if (g->tap_dy[c * 4 + t] != dy || g->tap_dx[c * 4 + t] != dx) return 4;
+    }
+  }
+  return 2;
+}
+
 template <typename T>
 static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
   SEG_CHECK_ARG(a != nullptr, "seg_igemm_wgrad: null args");
@@ -1798,6 +1995,10 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
       if (a->g.ncls == 1) {
         if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32, false>), gridh, dim3(256), lds32, sth, *a);
         else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16, false>), gridh, dim3(256), lds16, sth, *a);
+      } else if (seg_wgrad_halo_class_groups(&a->g) == 2) {
+        dim3 grid2(gridh.x, 2, gridh.z);
+        if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_tc2_kernel<32>), grid2, dim3(256), (size_t)2 * (2 * 8192 + 17 * 1024), sth, *a);
+        else hipLaunchKernelGGL((igemm_wgrad_halo_tc2_kernel<16>), grid2, dim3(256), (size_t)2 * (2 * 8192 + 14 * 1024), sth, *a);
       } else {
         if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32, true>), gridh, dim3(256), lds32, sth, *a);
         else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16, true>), gridh, dim3(256), lds16, sth, *a);

@@ -358,6 +358,23 @@ def wgrad_halo_patch(g: Geom) -> int:
     return 0
 
 
+def wgrad_halo_class_groups(g: Geom) -> int:
+    """Mirror of seg_wgrad_halo_class_groups(): 1 (conv), 2 (transposed conv whose taps follow the class-pair table), else ncls."""
+    if g.ncls != 4 or g.ntaps != 4:
+        return g.ncls
+    for c in range(4):
+        py, px = c >> 1, c & 1
+        if (g.oy[c], g.ox[c]) != (py, px):
+            return 4
+        for t in range(4):
+            iy, ix = t >> 1, t & 1
+            dy = (0, -1)[iy] if py == 0 else (1, 0)[iy]
+            dx = (0, -1)[ix] if px == 0 else (1, 0)[ix]
+            if (g.tap_dy[c * 4 + t], g.tap_dx[c * 4 + t]) != (dy, dx):
+                return 4
+    return 2
+
+
 HALO_BLOCKS = 512          # resident blocks of the variant-2 kernel: 2 per CU x 256 CUs
 
 
@@ -618,7 +635,8 @@ class ConvOp(Op):
         variant = WGRAD_VARIANT
         if variant == 0 and self.m.dtype == "f16" and WGRAD_HALO and wgrad_halo_patch(self.g_fwd):
             variant = 2         # 3x3 stride-1 layers: LDS-DMA halo-tile kernel
-        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs], self.g_fwd.ncls, self.g_fwd.ntaps, variant)
+        tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs],
+                                     wgrad_halo_class_groups(self.g_fwd) if variant == 2 else self.g_fwd.ncls, self.g_fwd.ntaps, variant)
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = variant
