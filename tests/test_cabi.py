@@ -88,6 +88,7 @@ def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
     geoms += [M.geom_conv(2, h, w, 3, 3, 1, 1) for (h, w) in ((8, 32), (16, 16), (24, 64), (32, 48), (12, 32))]
     geoms += [M.geom_conv_dgrad(2, h, w, 3, 3, 1, 1) for (h, w) in ((8, 32), (16, 16), (4, 32))]
     geoms += [M.geom_convT(2, h, w, k, k, 2, 2) for (h, w) in ((8, 32), (16, 16), (4, 32)) for k in (4, 2)]
+    geoms += [M.geom_convT_dgrad(2, h, w, k, k, 2, 2) for (h, w) in ((8, 32), (16, 16), (4, 32)) for k in (4, 2)]
     assert {L.seg_wgrad_halo_class_groups(ctypes.byref(g)) for g in geoms} == {1, 2, 4}
     assert all(L.seg_wgrad_halo_class_groups(ctypes.byref(g)) == M.wgrad_halo_class_groups(g) for g in geoms)
     seen = set()

@@ -218,6 +218,40 @@ def test_dgrad_matches_autograd(kind, k, s, shape, cin, cout):
     assert rel(from_dev(dx, cin), x.grad) < 2e-3
 
 
+@pytest.mark.parametrize("shape,cin,cout,tile", [((2, 8, 32), 64, 32, (256, 64)), ((1, 16, 16), 128, 72, (256, 128)), ((2, 16, 64), 40, 136, (256, 64)),
+                                                 ((1, 8, 32), 200, 16, (256, 128))])
+def test_conv_transpose_dgrad_halo_kernel(shape, cin, cout, tile):
+    """variant 3 on the data gradient of Conv2DTranspose(4x4, stride 2): dY read as four parity planes, 2x2 taps each."""
+    N, H, W = shape
+    x = h16(torch.randn(N, H, W, cin)).requires_grad_(True)
+    kshape = (4, 4, cout, cin)
+    kern = h16(torch.from_numpy(rng.standard_normal(kshape).astype(np.float32) * 0.1))
+    y = K.conv2d_transpose_same(x, kern, None, (2, 2))
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    M = U.M
+    n_rows, T, Kpad = U.r8(cout), 16, U.r32(U.r8(cin))
+    E = M.pack_gemm_weight(kern.numpy(), [cin], [0], n_rows, Kpad, True)
+    rows_pad = U.r32(n_rows)
+    wt = torch.zeros(Kpad * T * rows_pad, dtype=torch.float16, device="cuda")
+    Ed = dev_f32(E.reshape(-1))
+    ffi.call("seg_transpose_w", P(Ed), P(wt), n_rows, T, Kpad, rows_pad, stream())
+    g = M.geom_convT_dgrad(N, H, W, 4, 4, 2, 2)
+    assert M.fwd_halo_patch(g) in (16, 32)
+    dzd = to_dev_nhwc(dz)
+    cs_in = U.r8(cin)
+    dx = torch.full((N, H, W, cs_in), 3.0, dtype=torch.float16, device="cuda")
+    a = ffi.IgemmFwdArgs()
+    a.g, a.nseg = g, 1
+    a.seg_c[0], a.seg_cs[0], a.seg_woff[0], a.seg_ptr[0] = n_rows, dzd.shape[3], 0, dzd.data_ptr()
+    a.w, a.Kpad, a.n_rows, a.n_valid = wt.data_ptr(), rows_pad, cs_in, cs_in
+    a.out, a.out_cs, a.out_coff = dx.data_ptr(), cs_in, 0
+    a.tile_m, a.tile_n, a.variant = tile[0], tile[1], 3
+    ffi.call("seg_igemm_fwd", C.byref(a), stream())
+    torch.cuda.synchronize()
+    assert rel(from_dev(dx, cin), x.grad) < 2e-3
+
+
 @pytest.mark.parametrize("variant,tile,shape", [(0, (128, 128), (2, 16, 16)), (0, (64, 64), (2, 12, 10)), (3, (256, 128), (2, 16, 32)), (3, (256, 64), (1, 16, 16))])
 @pytest.mark.parametrize("act,alpha", [("leaky_relu", 0.3), ("relu", 0.0), ("sigmoid", 0.0)])
 def test_split_output_with_fused_activation_backward(variant, tile, shape, act, alpha):

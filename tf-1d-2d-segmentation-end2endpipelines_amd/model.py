@@ -290,6 +290,12 @@ def fwd_halo_patch(g: Geom) -> int:
     (variant 3; 32 = 8x32-pixel patches, 16 = 16x16), 0 when the geometry is neither a stride-1 'same' convolution with
     the nine tap offsets {-1,0,1}^2 (in any order) nor a 4x4 / stride-2 transposed convolution (four sub-pixel classes
     of 2x2 taps), or the image is not tiled by those patches."""
+    if g.isy == 2:         # data gradient of the 4x4 / stride-2 transposed conv: four parity planes of the stride-2 input
+        if (g.ncls, g.ntaps, g.isx, g.osy, g.osx) != (1, 16, 2, 1, 1) or (g.Hin, g.Win, g.Hout, g.Wout) != (2 * g.Hl, 2 * g.Wl, g.Hl, g.Wl):
+            return 0
+        if g.oy[0] != 0 or g.ox[0] != 0 or any(g.tap_dy[t] != (t >> 2) - 1 or g.tap_dx[t] != (t & 3) - 1 for t in range(16)):
+            return 0
+        return 32 if g.Wl % 32 == 0 and g.Hl % 8 == 0 else 16 if g.Wl % 16 == 0 and g.Hl % 16 == 0 else 0
     if (g.isy, g.isx) != (1, 1) or (g.Hl, g.Wl) != (g.Hin, g.Win):
         return 0
     if g.ncls == 1 and g.ntaps == 9:
