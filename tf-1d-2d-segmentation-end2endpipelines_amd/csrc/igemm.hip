@@ -668,6 +668,9 @@ template __global__ void igemm_fwd2_kernel<128, 64, 9, 32, 3>(const seg_igemm_fw
 template __global__ void igemm_fwd2_kernel<128, 64, 9, 64, 2>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd2_kernel<128, 64, 16, 32, 3>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd2_kernel<128, 64, 16, 64, 2>(const seg_igemm_fwd_args);
+// small grids (about one block per CU: the 8x8 / 16x16 levels with 1024-2048 channels): 64-deep K steps AND a 3-stage ring
+template __global__ void igemm_fwd2_kernel<128, 64, 9, 64, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd2_kernel<128, 64, 16, 64, 3>(const seg_igemm_fwd_args);
 
 // ---------------------------------------------------------------------------------------------------------
 // forward / data gradient of the 3x3 / stride-1 / 'same' convolutions, v3 (fp16): halo tiles.  A block owns a
@@ -1889,6 +1892,21 @@ static int fwd2_bk(const seg_igemm_fwd_args& a, long nblocks) {
 
 static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hipStream_t st) {
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a.g.ncls, 1);
+  // deep-and-small layers: with ~1 block per CU nothing else hides a block's barriers and load latency, so take both
+  // the 64-deep K step (8 instead of 4 MFMAs per wave and barrier) and two steps of loads in flight (72 KB of LDS)
+  static const bool no_deep = std::getenv("SEG_NO_DEEP_RING") != nullptr;
+  if (!no_deep && std::getenv("SEG_V2_BK") == nullptr && a.tile_m == 128 && a.tile_n == 64 && (long)mblocks * nblocks * a.g.ncls <= 384 &&
+      (a.g.ntaps == 9 || a.g.ntaps == 16) && (a.Kpad & 63) == 0) {
+    bool ok = true;
+    for (int s = 0; s < a.nseg; ++s) ok = ok && a.seg_c[s] >= 64 && (a.seg_c[s] & 63) == 0;
+    if (ok) {
+      const size_t lds = (size_t)3 * (128 + 64) * 128;
+      if (a.g.ntaps == 9) hipLaunchKernelGGL((igemm_fwd2_kernel<128, 64, 9, 64, 3>), grid, dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((igemm_fwd2_kernel<128, 64, 16, 64, 3>), grid, dim3(256), lds, st, a);
+      SEG_CHECK_LAUNCH("seg_igemm_fwd (LDS-DMA, deep ring)");
+      return SEG_OK;
+    }
+  }
   if (fwd2_bk(a, (long)mblocks * nblocks * a.g.ncls) == 64) {
     const size_t lds = (size_t)2 * (a.tile_m + a.tile_n) * 128;     // >= epilogue staging (20.5 KB)
     if (a.tile_m == 128 && a.tile_n == 128) launch_fwd2_nt<128, 128, 64, 2>(a, grid, lds, st);
