@@ -84,7 +84,7 @@ def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
         got = L.seg_wgrad_halo_patch(ctypes.byref(g))
         assert got == M.wgrad_halo_patch(g)
         seen.add(got)
-    assert seen == {0, 16, 32}
+    assert seen == {0, 8, 16, 32}
     geoms += [M.geom_conv(2, h, w, 3, 3, 1, 1) for (h, w) in ((8, 32), (16, 16), (24, 64), (32, 48), (12, 32))]
     geoms += [M.geom_conv_dgrad(2, h, w, 3, 3, 1, 1) for (h, w) in ((8, 32), (16, 16), (4, 32))]
     geoms += [M.geom_convT(2, h, w, k, k, 2, 2) for (h, w) in ((8, 32), (16, 16), (4, 32)) for k in (4, 2)]

@@ -385,6 +385,8 @@ def test_conv_fwd_halo_kernel_refuses_other_geometries():
     dict(shape=(1, 4, 96), cins=[24], cout=136, sk=2),                    # three row tiles, the last ragged
     dict(shape=(2, 12, 48), cins=[192], cout=128, sk=7),                  # W = 48 -> 16-wide patches
     dict(shape=(1, 2, 32), cins=[8], cout=8, sk=1),                       # a single patch: every tap but the centre row is border
+    dict(shape=(3, 8, 8), cins=[128, 40], cout=72, sk=2),                 # 8x8 patches: a 16-pixel K block spans two image rows
+    dict(shape=(2, 16, 24), cins=[64], cout=64, sk=3),                    # W = 24 -> 8-wide patches, several per row
 ], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
 def test_wgrad_halo_kernel_matches_autograd(case):
     """variant 2: LDS-DMA halo tiles + transposed LDS reads, 3x3 stride-1 'same' convs."""
@@ -404,6 +406,7 @@ def test_wgrad_halo_kernel_matches_autograd(case):
     dict(shape=(2, 8, 32), cins=[128], cout=64, sk=2),
     dict(shape=(2, 16, 16), cins=[72], cout=24, sk=1),
     dict(shape=(1, 4, 64), cins=[64, 64], cout=136, sk=3),
+    dict(shape=(2, 8, 8), cins=[192], cout=96, sk=1),                     # 8x8 patches
 ], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
 def test_wgrad_halo_kernel_transposed_conv(case):
     """variant 2 on Conv2DTranspose(4x4, stride 2): per sub-pixel class four of the nine halo shifts against the stride-2 dz pixels."""
@@ -422,7 +425,7 @@ def test_wgrad_halo_kernel_transposed_conv(case):
 def test_wgrad_halo_kernel_refuses_other_geometries():
     xs = [h16(torch.randn(2, 8, 8, 64))]
     with pytest.raises(U.ffi.SegHipError, match="variant 2"):
-        U.igemm_wgrad(xs, h16(torch.randn(2, 8, 8, 64)), (3, 3, 64, 64), "conv", (1, 1), 2, 1, None)       # W = 8
+        U.igemm_wgrad([h16(torch.randn(2, 8, 12, 64))], h16(torch.randn(2, 8, 12, 64)), (3, 3, 64, 64), "conv", (1, 1), 2, 1, None)       # W = 12
     with pytest.raises(U.ffi.SegHipError, match="variant 2"):
         U.igemm_wgrad([h16(torch.randn(2, 8, 32, 64))], h16(torch.randn(2, 16, 64, 32)), (2, 2, 32, 64), "convT", (2, 2), 2, 1, None)   # 2x2 kernel
 

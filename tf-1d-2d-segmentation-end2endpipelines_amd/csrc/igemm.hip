@@ -1480,9 +1480,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   const int j = 8 * (tg >> 1) + tq;
   const int cbA = (wm * 32 + 16 * (tg & 1) + 4 * tp) * 2, cbB = (wn * 32 + 16 * (tg & 1) + 4 * tp) * 2;
   const int offA = j * 128 + (cbA ^ (((j >> 1) & 1) << 6));
+  // 8-pixel-wide patches (the 8x8 level): a 16-pixel K block is two image rows, pixels 8..15 sit one halo row further
+  const int jr = C >= 16 ? j : j + (j >> 3) * (HC - 8);
   int offB[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) offB[r] = j * 128 + (cbB ^ ((((r + j) >> 1) & 1) << 6));
+  for (int r = 0; r < 4; ++r) offB[r] = jr * 128 + (cbB ^ ((((r + jr) >> 1) & 1) << 6));
   auto trfrag = [&](const unsigned char* ad) -> h8 {
     s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
     s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * 128));
@@ -1501,8 +1503,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
     const unsigned char* Is = Zs + Z_BYTES;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      constexpr int KPR = C / 16;                                  // K blocks per patch row
-      const int yy = kb / KPR, xx0 = (kb % KPR) * 16;
+      constexpr int KPR = C >= 16 ? C / 16 : 1;                    // K blocks per patch row (C = 8: one K block = two rows)
+      const int yy = C >= 16 ? kb / KPR : 2 * kb, xx0 = C >= 16 ? (kb % KPR) * 16 : 0;
       const h8 af = trfrag(Zs + kb * 16 * 128 + offA);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -1538,7 +1540,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-        if (row < p.n_rows) atomicAdd(dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol, acc[t][q] * sc_mul);
+        if (row < p.n_rows) {
+          float* d = dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol;
+          if (p.splitk == 1) *d += acc[t][q] * sc_mul;       // this block is the only writer of its tile: no atomic needed
+          else atomicAdd(d, acc[t][q] * sc_mul);
+        }
       }
     }
   }
@@ -1649,9 +1655,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
   const int j = 8 * (tg >> 1) + tq;
   const int cbA = (wm * 32 + 16 * (tg & 1) + 4 * tp) * 2, cbB = (wn * 32 + 16 * (tg & 1) + 4 * tp) * 2;
   const int offA = j * 128 + (cbA ^ (((j >> 1) & 1) << 6));
+  // 8-pixel-wide patches (the 8x8 level): a 16-pixel K block is two image rows, pixels 8..15 sit one halo row further
+  const int jr = C >= 16 ? j : j + (j >> 3) * (HC - 8);
   int offB[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) offB[r] = j * 128 + (cbB ^ ((((r + j) >> 1) & 1) << 6));
+  for (int r = 0; r < 4; ++r) offB[r] = jr * 128 + (cbB ^ ((((r + jr) >> 1) & 1) << 6));
   auto trfrag = [&](const unsigned char* ad) -> h8 {
     s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
     s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * 128));
@@ -1671,8 +1679,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
     const unsigned char* Is = Zs + 2 * Z_BYTES;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      constexpr int KPR = C / 16;
-      const int yy = kb / KPR, xx0 = (kb % KPR) * 16;
+      constexpr int KPR = C >= 16 ? C / 16 : 1;
+      const int yy = C >= 16 ? kb / KPR : 2 * kb, xx0 = C >= 16 ? (kb % KPR) * 16 : 0;
       const h8 af0 = trfrag(Zs + kb * 16 * 128 + offA), af1 = trfrag(Zs + Z_BYTES + kb * 16 * 128 + offA);
 #pragma unroll
       for (int iy = 0; iy < 2; ++iy) {
@@ -1715,7 +1723,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-        if (row < p.n_rows) atomicAdd(dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol, acc[t][q] * sc_mul);
+        if (row < p.n_rows) {
+          float* d = dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol;
+          if (p.splitk == 1) *d += acc[t][q] * sc_mul;       // this block is the only writer of its tile: no atomic needed
+          else atomicAdd(d, acc[t][q] * sc_mul);
+        }
       }
     }
   }
@@ -1723,11 +1735,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
 }
 template __global__ void igemm_wgrad_halo_tc2_kernel<32>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_tc2_kernel<16>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_tc2_kernel<8>(const seg_igemm_wgrad_args);
 
 template __global__ void igemm_wgrad_halo_kernel<32, false>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<16, false>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<32, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<16, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<8, false>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_kernel<8, true>(const seg_igemm_wgrad_args);
 
 bool check_geom(const seg_geom& g, const char* who) {
   if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Hl <= 0 || g.Wl <= 0 || g.Hout <= 0 || g.Wout <= 0) {
@@ -2011,6 +2026,7 @@ extern "C" int seg_wgrad_halo_patch(const seg_geom* g) {
   }
   if (g->Win % 32 == 0 && g->Hin % 2 == 0) return 32;
   if (g->Win % 16 == 0 && g->Hin % 4 == 0) return 16;
+  if (g->Win % 8 == 0 && g->Hin % 8 == 0) return 8;
   return 0;
 }
 
@@ -2047,7 +2063,7 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   if (a->variant == 2) {
     SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_wgrad: variant 2 (LDS-DMA halo tiles) is fp16 only");
     const int pc = seg_wgrad_halo_patch(&a->g);
-    SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 16 == 0 and H %% 4 == 0 (or W %% 32 == 0, H %% 2 == 0)");
+    SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 32 == 0 and H %% 2 == 0, W %% 16 == 0 and H %% 4 == 0, or W and H %% 8 == 0");
     const long pix = (long)a->g.N * a->g.Hin * a->g.Win;
     SEG_CHECK_ARG((long)a->g.N * a->g.Hout * a->g.Wout * a->dz_cs * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
     int planes = 0;
@@ -2058,18 +2074,23 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
     if constexpr (sizeof(T) == 2) {
       dim3 gridh((unsigned)(((a->n_rows + 63) / 64) * planes), (unsigned)a->g.ncls, (unsigned)a->splitk);
       hipStream_t sth = (hipStream_t)stream;
-      const size_t lds32 = (size_t)2 * (8192 + 17 * 1024), lds16 = (size_t)2 * (8192 + 14 * 1024);
+      const int ni = pc == 32 ? 17 : pc == 16 ? 14 : 13;              // LDS-DMA pieces of the halo tile
+      const size_t lds1 = (size_t)2 * (8192 + ni * 1024), lds2 = (size_t)2 * (2 * 8192 + ni * 1024);
+#define SEG_HALO_PC(KERNEL, GRID, LDS, ...)                                                                     \
+  do {                                                                                                          \
+    if (pc == 32) hipLaunchKernelGGL((KERNEL<32 __VA_ARGS__>), GRID, dim3(256), LDS, sth, *a);                   \
+    else if (pc == 16) hipLaunchKernelGGL((KERNEL<16 __VA_ARGS__>), GRID, dim3(256), LDS, sth, *a);              \
+    else hipLaunchKernelGGL((KERNEL<8 __VA_ARGS__>), GRID, dim3(256), LDS, sth, *a);                             \
+  } while (0)
       if (a->g.ncls == 1) {
-        if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32, false>), gridh, dim3(256), lds32, sth, *a);
-        else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16, false>), gridh, dim3(256), lds16, sth, *a);
+        SEG_HALO_PC(igemm_wgrad_halo_kernel, gridh, lds1, , false);
       } else if (seg_wgrad_halo_class_groups(&a->g) == 2) {
         dim3 grid2(gridh.x, 2, gridh.z);
-        if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_tc2_kernel<32>), grid2, dim3(256), (size_t)2 * (2 * 8192 + 17 * 1024), sth, *a);
-        else hipLaunchKernelGGL((igemm_wgrad_halo_tc2_kernel<16>), grid2, dim3(256), (size_t)2 * (2 * 8192 + 14 * 1024), sth, *a);
+        SEG_HALO_PC(igemm_wgrad_halo_tc2_kernel, grid2, lds2);
       } else {
-        if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<32, true>), gridh, dim3(256), lds32, sth, *a);
-        else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<16, true>), gridh, dim3(256), lds16, sth, *a);
+        SEG_HALO_PC(igemm_wgrad_halo_kernel, gridh, lds1, , true);
       }
+#undef SEG_HALO_PC
     }
     SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
     return SEG_OK;

@@ -361,6 +361,8 @@ def wgrad_halo_patch(g: Geom) -> int:
         return 32
     if g.Win % 16 == 0 and g.Hin % 4 == 0:
         return 16
+    if g.Win % 8 == 0 and g.Hin % 8 == 0:
+        return 8
     return 0
 
 
