@@ -259,7 +259,7 @@ typedef struct seg_transpose_desc {
   int32_t k0, kcount;
   int32_t rows_pad, dst_ld, dst_coff;
   int32_t tile0;
-  int32_t reserved;
+  int32_t src16;                 /* != 0: w points at an fp16 copy of the weight (same layout) instead of the fp32 master */
 } seg_transpose_desc;
 int seg_transpose_w_multi(const seg_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, seg_stream_t stream);
 /* fp32 -> fp16 cast of n elements                                                                              */

@@ -1236,7 +1236,12 @@ __global__ __launch_bounds__(TPB) void transpose_w_multi_kernel(const seg_transp
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = rt * 32 + ty + 8 * j, k = kt * 32 + tx;
-    tile[ty + 8 * j][tx] = (r < d.rows && k < d.kcount && d.k0 + k < d.K) ? d.w[((int64_t)r * d.T + t) * d.K + d.k0 + k] : 0.f;
+    float v = 0.f;
+    if (r < d.rows && k < d.kcount && d.k0 + k < d.K) {
+      const int64_t i = ((int64_t)r * d.T + t) * d.K + d.k0 + k;
+      v = d.src16 ? (float)reinterpret_cast<const half_t*>(d.w)[i] : d.w[i];      // fp16 operand copy: half the read traffic
+    }
+    tile[ty + 8 * j][tx] = v;
   }
   __syncthreads();
   T* wt = (T*)d.wt;

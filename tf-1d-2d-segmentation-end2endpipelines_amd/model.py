@@ -654,7 +654,7 @@ class ConvOp(Op):
         """(w fp32 [rows][T][K], dst, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff) of the derived operands."""
         if self.wt is None:
             return []
-        return [(self.m.store.ptr(self.wname, "P").value, self.wt.data_ptr(), self.n_rows, self.T, self.Kpad, 0, self.Kpad,
+        return [(self.m.store.ptr(self.wname, self.m.src_buf).value, self.wt.data_ptr(), self.n_rows, self.T, self.Kpad, 0, self.Kpad,
                  self.rows_pad, self.rows_pad, 0)]
 
     def forward(self, training):
@@ -816,7 +816,7 @@ class GatherDgrad:
         members[0][0].gather_launch.append(self)               # first in forward order = last in the backward sweep
 
     def transpose_jobs(self):
-        return [(self.m.store.ptr(op.wname, "P").value, self.w.data_ptr(), op.n_rows, op.T, op.Kpad, op.woff[si], self.t.cs,
+        return [(self.m.store.ptr(op.wname, self.m.src_buf).value, self.w.data_ptr(), op.n_rows, op.T, op.Kpad, op.woff[si], self.t.cs,
                  op.rows_pad, self.Kg, self.coloff[j]) for j, (op, si) in enumerate(self.members)]
 
     def plan(self):
@@ -1292,6 +1292,7 @@ class SegModel:
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.finalize()
+        self.src_buf = "P16" if self.dtype == "f16" else "P"      # the derived operands are transposed from the fp16 copy Adam refreshes
         self.gathers = [] if _DryRun.on else plan_gathers(self, self.ops)
         self._build_transpose_table()
         self.set_weights({p.name: init_param(p, self.seed) for p in g.param_specs()})
@@ -1314,12 +1315,13 @@ class SegModel:
         for grp in self.gathers:
             jobs += grp.transpose_jobs()
         self.tr_n, self.tr_tiles, self.tr_table = len(jobs), 0, None
+        src16 = 1 if self.src_buf == "P16" else 0
         if not jobs or _DryRun.on:
             return
         arr = (TransposeDesc * len(jobs))()
         for d, (w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff) in zip(arr, jobs):
             d.w, d.wt, d.rows, d.T, d.K, d.k0, d.kcount, d.rows_pad, d.dst_ld, d.dst_coff = w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff
-            d.tile0 = self.tr_tiles
+            d.tile0, d.src16 = self.tr_tiles, src16
             self.tr_tiles += T * _cdiv(kcount, 32) * _cdiv(rows_pad, 32)
         self.tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(_dev())
 
