@@ -66,8 +66,11 @@ def _worker(rank, world, port, q):
         real_zero = m2.store.G.zero_
         m2.store.G.zero_ = lambda: m2.store.G.fill_(float(rank + 1))
         m2.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m2.out_heads])
-        ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen == [(lo, hi) for lo, hi, _ in reversed(bk)] \
-            and bool((m2.store.G[:m2.store.n_train] == 3.0).all()) and not d2.pending
+        M._DryRun.log.clear()
+        m2.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m2.out_heads])
+        n_adam = sum(1 for c in M._DryRun.log if c == "seg_adam_step")        # one optimiser launch per exchanged slice (+ padding tail)
+        ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen[:len(bk)] == [(lo, hi) for lo, hi, _ in reversed(bk)] \
+            and bool((m2.store.G[:m2.store.n_train] == 3.0).all()) and not d2.pending and len(bk) <= n_adam <= len(bk) + 1
         q.put((rank, ok1, ok2, ok3 and ok4, None))
         dist.destroy_process_group()
     except Exception as e:      # pragma: no cover

@@ -64,7 +64,8 @@ class DataParallel:
     overlap=True (default): the backward sweep hands over each slice of the flat gradient buffer as soon as the
     ops that own it are done (model.grad_buckets(): slices follow op boundaries; the backward order is reverse
     creation order, so the decoder's slices become final first) and the all-reduce of that slice is launched
-    asynchronously on RCCL's stream while the remaining backward kernels keep running; Adam waits for all of them."""
+    asynchronously on RCCL's stream while the remaining backward kernels keep running; Adam runs per slice as soon as
+    that slice's exchange has finished."""
 
     def __init__(self, model, bucket_elems: int = 32 << 20, group=None, overlap: bool = True):
         self.model, self.group, self.bucket_elems = model, group, bucket_elems
@@ -75,7 +76,7 @@ class DataParallel:
         model.bucket_elems = bucket_elems
         if overlap and self.world_size > 1:
             model.bucket_hook = self._bucket_ready
-            model.allreduce = self._wait_all
+            model.bucket_waits = self._take_pending
         else:
             model.allreduce = self._allreduce
         if self.world_size > 1:
@@ -88,12 +89,13 @@ class DataParallel:
         allreduce_flat(flat_grads, self.bucket_elems, self.group)
 
     def _bucket_ready(self, lo: int, hi: int):
-        self.pending.append(dist.all_reduce(self.model.store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.pending.append((lo, hi, dist.all_reduce(self.model.store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
-    def _wait_all(self, flat_grads: torch.Tensor):
-        for w in self.pending:
-            w.wait()
-        self.pending.clear()
+    def _take_pending(self):
+        """[(lo, hi, work)] in issue order; the optimiser waits for each and updates that slice (Adam per bucket: the
+        update of the slices that arrived first runs under the exchange of the last ones)."""
+        out, self.pending = self.pending, []
+        return out
 
     def train_step(self, x_local, targets_local, loss=None):
         return self.model.train_step(x_local, targets_local, loss)

@@ -1099,6 +1099,7 @@ class SegModel:
         self.world_size = 1
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
+        self.bucket_waits = None       # ... and fn() -> [(lo, hi, work)] handing the pending all-reduces to the optimiser
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
@@ -1483,12 +1484,33 @@ class SegModel:
     def optimizer_step(self):
         st = self.store
         self._enter()
-        if self.allreduce is not None:
-            self.allreduce(st.G)
         self.adam_t += 1
         a_t = self.lr * math.sqrt(1.0 - self.beta_2 ** self.adam_t) / (1.0 - self.beta_1 ** self.adam_t)
-        call("seg_adam_step", _p(st.P), _p(st.G), _p(st.M), _p(st.V), _p(st.P16) if self.dtype == "f16" else None, st.P.numel(), a_t, self.beta_1, self.beta_2,
-             self.epsilon, 1.0 / self.world_size, _stream())
+
+        def adam(lo, hi):
+            off = lambda t: C.c_void_p(t.data_ptr() + lo * t.element_size())
+            call("seg_adam_step", off(st.P), off(st.G), off(st.M), off(st.V), off(st.P16) if self.dtype == "f16" else None, hi - lo, a_t,
+                 self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _stream())
+
+        n = st.P.numel()
+        if self.bucket_waits is not None:
+            # overlapped data parallel: update each slice of the flat buffers as soon as ITS all-reduce has finished (the
+            # waits are stream-side), so the optimiser of the decoder's slices runs under the exchange of the encoder's
+            done = []
+            for lo, hi, work in self.bucket_waits():
+                work.wait()
+                adam(lo, hi)
+                done.append((lo, hi))
+            done.sort()
+            pos = 0
+            for lo, hi in done + [(n, n)]:            # whatever no bucket covered (alignment padding behind the last parameter)
+                if lo > pos:
+                    adam(pos, lo)
+                pos = max(pos, hi)
+        else:
+            if self.allreduce is not None:
+                self.allreduce(st.G)
+            adam(0, n)
         for op in self.ops:
             op.post_step()
         self.refresh_derived()
