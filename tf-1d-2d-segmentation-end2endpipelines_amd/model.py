@@ -1463,8 +1463,13 @@ class SegModel:
             self.ops[oi].backward()
             for lo, hi in ready.get(oi, ()):
                 if self.side_stream is not None:
-                    torch.cuda.current_stream().wait_stream(self.side_stream)     # the slice includes weight gradients
-                self.bucket_hook(lo, hi)
+                    # the slice holds weight gradients (side stream) and BN / bias gradients (this stream): issue the
+                    # exchange from the side stream after it has caught up with this one - this stream never stalls
+                    self.side_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self.side_stream):
+                        self.bucket_hook(lo, hi)
+                else:
+                    self.bucket_hook(lo, hi)
         if self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
 
