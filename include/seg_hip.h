@@ -125,6 +125,11 @@ typedef struct seg_igemm_wgrad_args {
                                     2: LDS-DMA halo tiles (3x3 stride-1 'same' only, fp16; tile_m/tile_n ignored:
                                        64 rows x 64-channel planes x 9 taps per block, splitk splits the
                                        64-pixel patches; requires seg_wgrad_halo_patch(&g) != 0)              */
+  float* bias_part;              /* optional, variant 2 on a transposed conv with seg_wgrad_halo_class_groups(&g) == 2:
+                                    per-block partial column sums of dz (the bias gradient before the 1/S scale),
+                                    fp32 [2 * splitk][2][n_rows] - row (py * splitk + z), plane 0 = sum, plane 1 = 0,
+                                    the layout seg_bn_bwd_finalize reduces (dgamma = NULL, dbeta = the bias gradient).
+                                    Must be NULL otherwise.                                                   */
 } seg_igemm_wgrad_args;
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
 /* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */

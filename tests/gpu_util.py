@@ -98,7 +98,7 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
     return res, (stats.sum(0).cpu() if stats is not None else None), pad
 
 
-def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None, f32=False):
+def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None, f32=False, bias_parts=False):
     """Returns dW in Keras layout (numpy)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kshape[:2]
@@ -130,9 +130,17 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
         tm, tn = tile
     a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)
     a.scale, a.scale_ptr, a.variant = 1.0, None, variant
+    bp = None
+    if bias_parts:
+        bp = torch.full((2 * a.splitk, 2, n_rows), 1e30, dtype=torch.float32, device="cuda")
+        a.bias_part = bp.data_ptr()
     ffi.call("seg_igemm_wgrad_f32" if f32 else "seg_igemm_wgrad", C.byref(a), stream())
     torch.cuda.synchronize()
-    return M.unpack_gemm_weight(dw.cpu().numpy(), kshape, cin_l, woff, n_rows, Kpad, transposed)
+    w = M.unpack_gemm_weight(dw.cpu().numpy(), kshape, cin_l, woff, n_rows, Kpad, transposed)
+    if bias_parts:
+        assert float(bp[:, 1].abs().max()) == 0.0
+        return w, bp[:, 0].sum(0).cpu()
+    return w
 
 
 def ref_conv(xs, kern, bias, kind, strides):

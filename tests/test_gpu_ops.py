@@ -420,6 +420,10 @@ def test_wgrad_halo_kernel_transposed_conv(case):
     (y * dz).sum().backward()
     got = U.igemm_wgrad(xs, dz, kshape, "convT", (2, 2), 2, case["sk"], None)
     assert rel(torch.from_numpy(got), kern.grad) < 1e-4
+    # the bias gradient (column sums of dz) as per-block partial rows out of the same launch
+    got2, bias = U.igemm_wgrad(xs, dz, kshape, "convT", (2, 2), 2, case["sk"], None, bias_parts=True)
+    assert rel(torch.from_numpy(got2), kern.grad) < 1e-4
+    assert rel(bias[:case["cout"]], dz.sum((0, 1, 2))) < 1e-4
 
 
 def test_wgrad_halo_kernel_refuses_other_geometries():

@@ -1594,7 +1594,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
   const int npatch = g.N * PH * PW;
   const int per = (npatch + p.splitk - 1) / p.splitk;
   const int q0 = bz * per, q1 = min(npatch, q0 + per);
-  if (q0 >= q1) return;
+  if (q0 >= q1) {                      // an empty patch range still owns its row of the bias partials
+    if (p.bias_part != nullptr && seg == 0 && c0 == 0 && tid < 64 && r0 + tid < p.n_rows) {
+      float* rowp = p.bias_part + ((size_t)(py * p.splitk + bz) * 2) * p.n_rows;
+      rowp[r0 + tid] = 0.f;
+      rowp[p.n_rows + r0 + tid] = 0.f;
+    }
+    return;
+  }
 
   auto uniform_ptr = [](const void* q) -> void* {
     const unsigned long long v = (unsigned long long)q;
@@ -1672,6 +1679,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  // bias gradient = column sums of dz: the blocks of the first input plane contract their dz tiles with a ones operand
+  // (one more MFMA per class and K block) instead of a separate pass over the 134 MB gradient tensor
+  const bool do_bias = p.bias_part != nullptr && seg == 0 && c0 == 0 && wn == 0;
+  f16v accb;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) accb[q] = 0.f;
+  const h8 ones = h8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 
   auto compute = [&](auto pyc, int stage) {
     constexpr int PY = decltype(pyc)::value;
@@ -1682,6 +1696,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
       constexpr int KPR = C >= 16 ? C / 16 : 1;
       const int yy = C >= 16 ? kb / KPR : 2 * kb, xx0 = C >= 16 ? (kb % KPR) * 16 : 0;
       const h8 af0 = trfrag(Zs + kb * 16 * 128 + offA), af1 = trfrag(Zs + Z_BYTES + kb * 16 * 128 + offA);
+      if (do_bias) {                                                 // wave-uniform
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, ones, accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, ones, accb, 0, 0, 0);
+      }
 #pragma unroll
       for (int iy = 0; iy < 2; ++iy) {
         const int dy = PY == 0 ? (iy == 0 ? 0 : -1) : (iy == 0 ? 1 : 0);
@@ -1715,6 +1733,17 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
   float* dw = p.dw;
   const int fr = lane & 31, fh = lane >> 5;
+  if (do_bias && fr == 0) {          // every column of accb holds the same sums: lanes of column 0 write the partial row
+    float* rowp = p.bias_part + ((size_t)(py * p.splitk + bz) * 2) * p.n_rows;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+      if (row < p.n_rows) {
+        rowp[row] = accb[q];
+        rowp[p.n_rows + row] = 0.f;
+      }
+    }
+  }
   const int kcol = c0 + wn * 32 + fr;
   if (kcol < sc) {
 #pragma unroll
@@ -2060,6 +2089,8 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
                 "seg_igemm_wgrad: tile %dx%d", a->tile_m, a->tile_n);
   SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "seg_igemm_wgrad: splitk=%d", a->splitk);
   SEG_CHECK_ARG(a->variant >= 0 && a->variant <= 2, "seg_igemm_wgrad: variant=%d", a->variant);
+  SEG_CHECK_ARG(a->bias_part == nullptr || (a->variant == 2 && seg_wgrad_halo_class_groups(&a->g) == 2),
+                "seg_igemm_wgrad: bias_part needs variant 2 on a transposed conv of the class-pair kernel");
   if (a->variant == 2) {
     SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_wgrad: variant 2 (LDS-DMA halo tiles) is fp16 only");
     const int pc = seg_wgrad_halo_patch(&a->g);

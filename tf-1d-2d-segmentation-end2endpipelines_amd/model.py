@@ -321,6 +321,7 @@ def fwd_halo_patch(g: Geom) -> int:
 
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
+BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
@@ -648,6 +649,14 @@ class ConvOp(Op):
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = variant
+        # transposed convs on the class-pair kernel: the bias gradient (column sums of dz) comes out of the weight-gradient
+        # launch as per-block partial rows instead of a separate pass over dz
+        self.bias_from_wgrad = (BIAS_FROM_WGRAD and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
+                                and wgrad_halo_class_groups(self.g_fwd) == 2)
+        if self.bias_from_wgrad:
+            self.wg_bias_parts = 2 * sk
+            self.wg_bpart = torch.zeros(self.wg_bias_parts * 2 * self.n_rows, dtype=torch.float32, device=_dev())
+            wg.bias_part = self.wg_bpart.data_ptr()
         self.wg_args = wg
 
     def transpose_jobs(self):
@@ -680,7 +689,7 @@ class ConvOp(Op):
     def _bias_grad(self, dz, s, gs_inv):
         """dbias += (1/S) * column sums of dz: deterministic per-block partials + one finalize launch (thousands of
         same-address float atomics serialise at one memory channel - measured 170 us per 134 MB tensor)."""
-        if self.bname is None:
+        if self.bname is None or self.bias_from_wgrad:
             return
         st = self.m.store
         call("seg_bn_stats", _p(dz), self.z.npix, self.z.cs, 0, self.n_rows, _p(self.bpart), BN_PARTS_BWD, self.n_rows, 0, s)
@@ -783,15 +792,21 @@ class ConvOp(Op):
         for grp in self.gather_launch:
             grp.launch(s)
         self.wg_args.dz = dz.data_ptr()
+        def wgrad(stream):
+            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+            if self.bias_from_wgrad:
+                call("seg_bn_bwd_finalize", _p(self.wg_bpart), self.wg_bias_parts, self.n_rows, self.z.npix, None, st.ptr(self.bname, "G"),
+                     1.0, gs_inv, _p(self.c1), _p(self.c2), stream)
+
         side = self.m.side_stream
         if side is None:
-            call("seg_igemm_wgrad", C.byref(self.wg_args), s, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+            wgrad(s)
         else:
             # the weight gradient is only needed by the optimiser: run it on a second stream so that this MFMA-bound
             # kernel overlaps the HBM-bound BN / activation backward kernels of the layers that follow
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call("seg_igemm_wgrad", C.byref(self.wg_args), _stream(), flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+                wgrad(_stream())
 
 
 class GatherDgrad:
