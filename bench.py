@@ -223,6 +223,7 @@ def main():
                 "data": "synthetic", "config": {"workload": f"{args.workload}: {desc}", "global_batch": world * bs,
                                                "per_gpu_batch": bs, "parallelism": f"dp{world}", "loss": loss,
                                                "optimizer": "adam", "gflop_per_image_fwd_bwd": flop_img / 1e9,
+                                               "hbm_resident_gb": torch.cuda.max_memory_allocated() / 1e9,
                                                "final_loss": loss_val},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
