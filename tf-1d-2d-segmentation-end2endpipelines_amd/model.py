@@ -1460,6 +1460,8 @@ class SegModel:
     def backward(self, grads: Optional[Sequence[torch.Tensor]] = None):
         """Backward pass.  grads[i] = dLoss/d output_i (fp32, same shape as the output); None: use the gradients the
         loss kernels left in the heads' dy buffers."""
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)      # derived operands rebuilt after the last optimiser step
         s = _stream()
         self._enter()
         if grads is not None:
@@ -1533,7 +1535,14 @@ class SegModel:
             adam(0, n)
         for op in self.ops:
             op.post_step()
-        self.refresh_derived()
+        if self.side_stream is None:
+            self.refresh_derived()
+        else:
+            # the transposed operands are first needed by the next backward pass: rebuild them on the side stream, under
+            # the next forward pass (backward() joins the side stream before its first kernel)
+            self.side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side_stream):
+                self.refresh_derived()
 
     def train_step(self, x, targets, loss: Optional[str] = None) -> torch.Tensor:
         """One optimiser step = Keras' default train_step (Train.py:394-415): forward (training BN) -> loss -> backward
