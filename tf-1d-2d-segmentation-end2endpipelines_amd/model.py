@@ -1115,6 +1115,7 @@ class SegModel:
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
         self.bucket_waits = None       # ... and fn() -> [(lo, hi, work)] handing the pending all-reduces to the optimiser
+        self._g_clean = False          # the flat gradient buffer is already zero (cleared on the side stream after Adam)
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
@@ -1396,7 +1397,8 @@ class SegModel:
         self.set_weights(load_weights_npz(path))
 
     def get_grads(self) -> Dict[str, np.ndarray]:
-        """Gradients of the last backward pass, Keras layout (already divided by the internal gradient scale)."""
+        """Gradients of the last backward pass, Keras layout (already divided by the internal gradient scale).  Valid
+        between backward() and optimizer_step(): the optimiser step clears the buffer for the next backward pass."""
         st = self.store
         host = st.G.cpu().numpy()
         return {name: np.asarray(s.from_engine(host[s.off:s.off + s.numel]), np.float32).reshape(s.spec.shape)
@@ -1471,7 +1473,9 @@ class SegModel:
         for h in self.out_heads:
             call("seg_absmax", _p(h.dy), h.dy.numel(), _p(self.amax), s)
         call("seg_grad_scale", _p(self.amax), GRAD_TARGET, _p(self.gs), s)
-        self.store.G.zero_()
+        if not self._g_clean:
+            self.store.G.zero_()          # (after an optimiser step the side stream has already cleared it)
+        self._g_clean = False
         ready = {}
         if self.bucket_hook is not None:
             for lo, hi, oi in self.grad_buckets():
@@ -1542,6 +1546,8 @@ class SegModel:
             # the next forward pass (backward() joins the side stream before its first kernel)
             self.side_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side_stream):
+                self.store.G.zero_()      # likewise the gradient accumulators of the next backward pass
+                self._g_clean = True
                 self.refresh_derived()
 
     def train_step(self, x, targets, loss: Optional[str] = None) -> torch.Tensor:
