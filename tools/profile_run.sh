@@ -10,16 +10,22 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- $B > $O/stats.log 2>&1
+# the same with every kernel alone on one stream (no weight-gradient side stream): the per-kernel durations bench.py's
+# roofline object is computed from (its profiled step also runs single-stream)
+export SEG_WGRAD_STREAM=0
+rocprofv3 --kernel-trace --stats -d $O/stats1 -o run --output-format csv -- $B > $O/stats1.log 2>&1
+unset SEG_WGRAD_STREAM
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o run --output-format csv -- $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o run --output-format csv -- $B > $O/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/sq1 -o run --output-format csv -- $B > $O/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/sq2 -o run --output-format csv -- $B > $O/sq2.log 2>&1
 cd $R
 python3 tools/profile_summary.py stats $O/stats profiles/${TAG}_c3_kernel_stats.csv
+python3 tools/profile_summary.py stats $O/stats1 profiles/${TAG}_c3_kernel_stats_single_stream.csv
 python3 tools/profile_summary.py hbm $O/fetch $O/write profiles/${TAG}_c3_hbm_traffic.json
 python3 tools/profile_summary.py pmc $O/sq1 $O/pmc_sq1.csv
 python3 tools/profile_summary.py pmc $O/sq2 $O/pmc_sq2.csv
-cp profiles/${TAG}_c3_kernel_stats.csv profiles/${TAG}_c3_hbm_traffic.json $O/
+cp profiles/${TAG}_c3_kernel_stats.csv profiles/${TAG}_c3_kernel_stats_single_stream.csv profiles/${TAG}_c3_hbm_traffic.json $O/
 # keep only the summaries (the raw traces are tens of MB)
-rm -rf $O/stats $O/fetch $O/write $O/sq1 $O/sq2
+rm -rf $O/stats $O/stats1 $O/fetch $O/write $O/sq1 $O/sq2
 ls -la $O
