@@ -77,8 +77,8 @@ class DataParallel:
         if overlap and self.world_size > 1:
             model.bucket_hook = self._bucket_ready
             model.bucket_waits = self._take_pending
-        else:
-            model.allreduce = self._allreduce
+        elif self.world_size > 1:
+            model.allreduce = self._allreduce       # (a single rank keeps the model's own single-GPU optimiser path)
         if self.world_size > 1:
             st = model.store
             broadcast_flat(st.P, 0, group)

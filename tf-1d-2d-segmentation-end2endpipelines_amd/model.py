@@ -322,6 +322,8 @@ def fwd_halo_patch(g: Geom) -> int:
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
+ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
+ADAM_SLICE_ELEMS = 4 << 20
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
@@ -1116,6 +1118,8 @@ class SegModel:
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
         self.bucket_waits = None       # ... and fn() -> [(lo, hi, work)] handing the pending all-reduces to the optimiser
         self._g_clean = False          # the flat gradient buffer is already zero (cleared on the side stream after Adam)
+        self._param_events: list = []  # (first op index, event) of optimiser slices still running on the side stream
+        self._adam_slices = None
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
@@ -1361,6 +1365,8 @@ class SegModel:
     def set_weights(self, weights: Dict[str, np.ndarray]):
         """weights: structural name -> numpy array in Keras layout (see graph.py)."""
         st = self.store
+        if self.built:
+            self._join_side()
         host_p = st.P.cpu().numpy()
         host_s = st.S.cpu().numpy()
         for name, arr in weights.items():
@@ -1377,8 +1383,14 @@ class SegModel:
         st.S.copy_(torch.from_numpy(host_s))
         self._refresh_copies()
 
+    def _join_side(self):
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+        self._param_events = []
+
     def get_weights(self) -> Dict[str, np.ndarray]:
         st = self.store
+        self._join_side()
         host_p, host_s = st.P.cpu().numpy(), st.S.cpu().numpy()
         out = {}
         for name, s in st.slots.items():
@@ -1430,8 +1442,15 @@ class SegModel:
         training = self.training if training is None else training
         self._x = self._check_x(x)
         self._enter()
-        for op in self.ops:
+        ev, k = self._param_events, 0          # optimiser slices still being updated on the side stream (forward order)
+        for i, op in enumerate(self.ops):
+            while k < len(ev) and ev[k][0] <= i:
+                torch.cuda.current_stream().wait_event(ev[k][1])
+                k += 1
             op.forward(training)
+        for _first, e in ev[k:]:
+            torch.cuda.current_stream().wait_event(e)
+        self._param_events = []
         outs = [h.y for h in self.out_heads]
         return [o.squeeze(1) for o in outs] if self.graph.ndim == 1 else outs
 
@@ -1442,6 +1461,26 @@ class SegModel:
         x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x
         outs = [o.cpu().numpy() for o in self.forward(x, training=False)]
         return outs if len(outs) > 1 else outs[0]
+
+    def adam_slices(self) -> List[Tuple[int, int, int]]:
+        """[(lo, hi, first_op)]: op-aligned slices of the flat parameter buffers in forward order that tile [0, numel);
+        an op's parameters are final once the slices with first_op <= its index have been updated."""
+        if self._adam_slices is None:
+            owners = sorted(self._op_grad_range.items())
+            out, lo, first = [], None, None
+            for oi, (a, b) in owners:
+                if lo is None:
+                    lo, first = a, oi
+                if b - lo >= ADAM_SLICE_ELEMS:
+                    out.append([lo, b, first])
+                    lo = None
+            if lo is not None:
+                out.append([lo, owners[-1][1][1], first])
+            if not out:
+                out = [[0, self.store.P.numel(), 0]]
+            out[0][0], out[-1][1] = 0, self.store.P.numel()
+            self._adam_slices = [tuple(o) for o in out]
+        return self._adam_slices
 
     def grad_buckets(self) -> List[Tuple[int, int, int]]:
         """[(lo, hi, op_index)]: contiguous slices of the flat gradient buffer, each complete once the backward sweep
@@ -1533,6 +1572,20 @@ class SegModel:
                 if lo > pos:
                     adam(pos, lo)
                 pos = max(pos, hi)
+        elif self.allreduce is None and self.side_stream is not None and ADAM_ASYNC:
+            # single GPU: the update itself moves under the next forward pass - slices in forward order on the side stream,
+            # an event per slice; forward() makes each op wait only for the slice holding its own parameters (Adam
+            # streams 30 B per parameter from HBM while the forward GEMMs leave the HBM mostly idle)
+            side = self.side_stream
+            side.wait_stream(torch.cuda.current_stream())
+            events = []
+            with torch.cuda.stream(side):
+                for lo, hi, first_op in self.adam_slices():
+                    adam(lo, hi)
+                    e = torch.cuda.Event()
+                    e.record(side)
+                    events.append((first_op, e))
+            self._param_events = events
         else:
             if self.allreduce is not None:
                 self.allreduce(st.G)
