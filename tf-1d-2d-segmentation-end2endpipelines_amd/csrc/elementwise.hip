@@ -128,11 +128,24 @@ __device__ __forceinline__ void reduce_parts16(const float* stats, int nparts, i
                                                float (*sm)[16][16]) {
   s = 0.f;
   q = 0.f;
-  if (c < C)
-    for (int p = pl; p < nparts; p += 16) {
-      s += stats[((size_t)p * 2 + 0) * C + c];
-      q += stats[((size_t)p * 2 + 1) * C + c];
+  if (c < C) {
+    // four rows per trip, all eight loads issued before the adds (a dependent chain of nparts / 16 L2 round trips is
+    // what these tiny launches consist of); the summation order stays fixed
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pl; p < nparts; p += 64) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + 16 * u;
+        a[u] = pp < nparts ? stats[((size_t)pp * 2 + 0) * C + c] : 0.f;
+        b[u] = pp < nparts ? stats[((size_t)pp * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s4[u] += a[u]; q4[u] += b[u]; }
     }
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+  }
   sm[0][pl][threadIdx.x & 15] = s;
   sm[1][pl][threadIdx.x & 15] = q;
   __syncthreads();

@@ -34,16 +34,17 @@ def timeit(name, fn, nbytes, iters=10):
 x, y, dy, dx = h(), h(), h(), h()
 T = x.numel() * 2
 scale, shift, mean, invstd, c1, c2 = (f32(Cc) for _ in range(6))
-part = torch.zeros(512 * 2 * Cc, device="cuda")
+NPARTS = int(os.environ.get("EW_PARTS", "512"))
+part = torch.zeros(NPARTS * 2 * Cc, device="cuda")
 pooled = torch.zeros((N, H // 2, W // 2, Cc), dtype=torch.float16, device="cuda")
 gs = torch.tensor([8.0, 0.125], device="cuda")
 db = torch.zeros(Cc, device="cuda")
 timeit("bn_act_apply", lambda: ffi.call("seg_bn_act_apply", P(x), Cc, 0, P(y), Cc, 0, N, H, W, Cc, Cc, P(scale), P(shift), 1, 0.0, None, 1, 1, stream()), 2 * T)
 timeit("bn_act_apply+pool", lambda: ffi.call("seg_bn_act_apply", P(x), Cc, 0, P(y), Cc, 0, N, H, W, Cc, Cc, P(scale), P(shift), 1, 0.0, P(pooled), 2, 2, stream()), 2.25 * T)
-timeit("bn_act_bwd_reduce", lambda: ffi.call("seg_bn_act_bwd_reduce", P(dy), Cc, 0, P(x), Cc, 0, npix, Cc, P(scale), P(shift), P(mean), P(invstd), 1, 0.0, P(part), 512, stream()), 2 * T)
+timeit("bn_act_bwd_reduce", lambda: ffi.call("seg_bn_act_bwd_reduce", P(dy), Cc, 0, P(x), Cc, 0, npix, Cc, P(scale), P(shift), P(mean), P(invstd), 1, 0.0, P(part), NPARTS, stream()), 2 * T)
 timeit("bn_act_bwd_apply", lambda: ffi.call("seg_bn_act_bwd_apply", P(dy), Cc, 0, P(x), Cc, 0, P(dx), Cc, 0, npix, Cc, P(scale), P(shift), P(mean), P(invstd), P(c1), P(c2), 1, 0.0, 0, stream()), 3 * T)
 timeit("act_bwd(+dbias)", lambda: ffi.call("seg_act_bwd", P(dy), P(y), P(dx), npix, Cc, Cc, 2, 0.3, P(db), 1.0, C.c_void_p(gs.data_ptr() + 4), stream()), 3 * T)
-timeit("bn_stats", lambda: ffi.call("seg_bn_stats", P(x), npix, Cc, 0, Cc, P(part), 512, Cc, 0, stream()), T)
+timeit("bn_stats", lambda: ffi.call("seg_bn_stats", P(x), npix, Cc, 0, Cc, P(part), NPARTS, Cc, 0, stream()), T)
 timeit("maxpool_bwd", lambda: ffi.call("seg_maxpool_bwd", P(pooled), P(x), P(pooled), P(dx), N, H, W, Cc, 2, 2, 1, stream()), 3.5 * T)
 w = torch.rand(1, Cc, device="cuda")
 b = torch.zeros(1, device="cuda")
