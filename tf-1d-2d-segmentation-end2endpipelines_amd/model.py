@@ -386,7 +386,7 @@ def wgrad_halo_class_groups(g: Geom) -> int:
     return 2
 
 
-HALO_BLOCKS = 512          # resident blocks of the variant-2 kernel: 2 per CU x 256 CUs
+HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "512"))          # resident blocks of the variant-2 kernel: 2 per CU x 256 CUs
 
 
 def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1):
