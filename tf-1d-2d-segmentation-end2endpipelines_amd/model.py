@@ -360,10 +360,10 @@ def wgrad_halo_patch(g: Geom) -> int:
                 return 0
     else:
         return 0
+    if g.Win % 16 == 0 and g.Hin % 4 == 0:         # 4 x 16 patches first (smallest halo overhead that still tiles most images)
+        return 16
     if g.Win % 32 == 0 and g.Hin % 2 == 0:
         return 32
-    if g.Win % 16 == 0 and g.Hin % 4 == 0:
-        return 16
     if g.Win % 8 == 0 and g.Hin % 8 == 0:
         return 8
     return 0
