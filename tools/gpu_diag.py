@@ -1,5 +1,10 @@
-"""GPU bring-up diagnostics: runs every parity check, never stops at the first failure, prints error magnitudes.
-Usage on the GPU box:  python tools/gpu_diag.py [section ...]   (sections: igemm wgrad model)"""
+"""GPU bring-up diagnostics: runs every check, never stops at the first failure, prints error magnitudes.
+Usage on the GPU box:  python tools/gpu_diag.py [section ...]   (sections: igemm wgrad model)
+
+The `model` section compares the fp16 throughput mode element-wise with the fp32 oracle at the exact-mode thresholds:
+it is a magnitude report, NOT a pass/fail gate - ReLU / max-pool masks flip on values that differ by one fp16 ulp, so
+max-abs gradient errors there say nothing about correctness.  The gates are tests/test_gpu_ops.py (kernels on identical
+fp16 inputs), tests/test_gpu_models.py (calibrated fp16 metrics) and tests/test_gpu_fp32.py (north-star tolerance)."""
 import os
 import sys
 import time
@@ -156,5 +161,5 @@ if __name__ == "__main__":
     for s in secs:
         print(f"===== {s} =====", flush=True)
         globals()["sec_" + s]()
-    print("FAILED:", FAILS if FAILS else "none")
+    print("over threshold (informational for the model section, see the module docstring):", FAILS if FAILS else "none")
     sys.exit(1 if FAILS else 0)
