@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step (single GPU; for launch-bound small models)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-launches", default="", help="write the per-launch event timings of the profiled step to this JSON file")
     args = ap.parse_args()
@@ -157,12 +158,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = model.train_step
+    if args.graph and world == 1:
+        step = model.graphed_train_step(x, targets)
     for _ in range(args.warmup):
-        model.train_step(x, targets)
+        step(x, targets)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.train_step(x, targets)
+        step(x, targets)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -249,6 +249,10 @@ int seg_grad_scale(const float* amax, float target, float* gs, seg_stream_t stre
  * parallel).  Also refreshes the fp16 operand copy p16 (same indexing).  Non-finite gradients are skipped.     */
 int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1,
                   float b2, float eps, float gmul, seg_stream_t stream);
+/* the same with alpha_t read from device memory at run time: the form a captured hipGraph of the training step replays
+ * (the host refreshes *alpha_ptr before each replay)                                                             */
+int seg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const float* alpha_ptr,
+                      float b1, float b2, float eps, float gmul, seg_stream_t stream);
 /* fp32 [rows][T][K] -> fp16 [K][T][rows_pad] (the data-gradient operand of the same layer)                     */
 int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                     seg_stream_t stream);

@@ -103,3 +103,27 @@ def test_bucketed_optimizer_path_matches_flat_adam():
     # weight gradients are split-K sums through float atomics: their order, hence the last bits, differ from run to run
     dp_, dm_ = float((p0 - p1).abs().max()), float((m0 - m1).abs().max())
     assert dp_ <= 1e-5 * float(p0.abs().max()) and dm_ <= 1e-4 * float(m0.abs().max()), (dp_, dm_)
+
+
+def test_graphed_train_step_matches_eager():
+    """One hipGraph replay per optimiser step (both streams captured) must train exactly like the eager step."""
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.rand((4, 32, 32, 3), generator=g).cuda() for _ in range(4)]
+
+    def run(graphed):
+        m = build("f16")
+        tgs = [[(x[..., :1] > 0.5).float() for _ in m.out_heads] for x in xs]
+        losses = []
+        step = m.graphed_train_step(xs[0], tgs[0]) if graphed else None
+        for x, tg in zip(xs[1:] if graphed else xs, tgs[1:] if graphed else tgs):
+            lv = step(x, tg) if graphed else m.train_step(x, tg)
+            losses.append(float(lv.cpu()))
+        torch.cuda.synchronize()
+        return m.get_weights(), losses, m.adam_t
+
+    w0, l0, t0 = run(False)
+    w1, l1, t1 = run(True)          # the capture warm-up is the step on xs[0]
+    assert t0 == t1 == 4
+    assert np.allclose(l0[1:], l1, rtol=2e-3, atol=1e-4), (l0, l1)
+    worst = max(float(np.abs(w0[k] - w1[k]).max()) for k in w0)
+    assert worst < 5e-3, worst       # Adam moves a weight by ~lr = 2e-3 per step; atomics reorder the last bits of the gradients

@@ -82,6 +82,7 @@ _PROTOS = {
     "seg_absmax": ([vp, i64, vp, vp], C.c_int),
     "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),
     "seg_adam_step": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp], C.c_int),
+    "seg_adam_step_dev": ([vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp], C.c_int),
     "seg_transpose_w": ([vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "seg_transpose_w_multi": ([vp, i32, i32, vp], C.c_int),
     "seg_cast_f32_f16": ([vp, vp, i64, vp], C.c_int),

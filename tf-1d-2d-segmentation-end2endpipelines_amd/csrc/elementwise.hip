@@ -1193,7 +1193,8 @@ __global__ void grad_scale_kernel(const float* amax, float target, float* gs) {
 
 // ------------------------------------------------------------------------------------------------ optimiser / packing
 __global__ __launch_bounds__(TPB) void adam_kernel(float* p, const float* g, float* m, float* v, half_t* p16, int64_t n, float alpha_t,
-                                                   float b1, float b2, float eps, float gmul) {
+                                                   float b1, float b2, float eps, float gmul, const float* alpha_ptr) {
+  if (alpha_ptr != nullptr) alpha_t *= *alpha_ptr;      // step size from device memory: a captured hipGraph replays with a fresh value
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const float gi = g[i] * gmul;
     float pi = p[i];
@@ -1660,8 +1661,16 @@ extern "C" int seg_grad_scale(const float* amax, float target, float* gs, seg_st
 extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1, float b2, float eps,
                              float gmul, seg_stream_t stream) {
   SEG_CHECK_ARG(p && g && m && v && n > 0, "seg_adam_step: bad arguments");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), p, g, m, v, (half_t*)p16, n, alpha_t, b1, b2, eps, gmul);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), p, g, m, v, (half_t*)p16, n, alpha_t, b1, b2, eps, gmul,
+                     (const float*)nullptr);
   SEG_CHECK_LAUNCH("seg_adam_step");
+  return SEG_OK;
+}
+extern "C" int seg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const float* alpha_ptr, float b1, float b2,
+                                 float eps, float gmul, seg_stream_t stream) {
+  SEG_CHECK_ARG(p && g && m && v && alpha_ptr && n > 0, "seg_adam_step_dev: bad arguments");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), p, g, m, v, (half_t*)p16, n, 1.0f, b1, b2, eps, gmul, alpha_ptr);
+  SEG_CHECK_LAUNCH("seg_adam_step_dev");
   return SEG_OK;
 }
 
