@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step (single GPU; for launch-bound small models)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic: run the data-parallel exchange path (RCCL all-reduce per gradient slice, Adam per slice) even with one rank")
     ap.add_argument("--dump-launches", default="", help="write the per-launch event timings of the profiled step to this JSON file")
     args = ap.parse_args()
 
@@ -140,7 +142,7 @@ def main():
     pkg = importlib.import_module(PKG)
     modelmod = importlib.import_module(PKG + ".model")
     dp = importlib.import_module(PKG + ".dp")
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dp.init_process_group_from_env("nccl")
     import torch.distributed as dist
 
@@ -150,7 +152,7 @@ def main():
     model = pkg.unet_model_builder(length=H, width=W, num_channels=Cin, train_mode="from_scratch", **kw).ResNet50()
     model.build(bs)
     model.compile(loss=loss, lr=2e-4)
-    dpm = dp.DataParallel(model)
+    dpm = dp.DataParallel(model, force_exchange=args.force_exchange)
     x, targets = make_batch(model, bs, H, W, Cin, loss, rank)
 
     def barrier():
@@ -225,13 +227,13 @@ def main():
                 "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
                 "data": "synthetic", "config": {"workload": f"{args.workload}: {desc}", "global_batch": world * bs,
-                                               "per_gpu_batch": bs, "parallelism": f"dp{world}", "loss": loss,
+                                               "per_gpu_batch": bs, "parallelism": f"dp{world}" + ("+forced-exchange" if args.force_exchange else ""), "loss": loss,
                                                "optimizer": "adam", "gflop_per_image_fwd_bwd": flop_img / 1e9,
                                                "hbm_resident_gb": torch.cuda.max_memory_allocated() / 1e9,
                                                "final_loss": loss_val},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

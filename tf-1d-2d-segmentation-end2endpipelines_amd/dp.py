@@ -43,9 +43,9 @@ def bucket_bounds(numel: int, bucket_elems: int):
     return out
 
 
-def allreduce_flat(buf: torch.Tensor, bucket_elems: int = 64 << 20, group=None):
+def allreduce_flat(buf: torch.Tensor, bucket_elems: int = 64 << 20, group=None, force: bool = False):
     """In-place sum all-reduce of a flat tensor in large contiguous buckets (async launches, one wait)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     works = [dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
              for lo, hi in bucket_bounds(buf.numel(), bucket_elems)]
@@ -67,17 +67,21 @@ class DataParallel:
     asynchronously on RCCL's stream while the remaining backward kernels keep running; Adam runs per slice as soon as
     that slice's exchange has finished."""
 
-    def __init__(self, model, bucket_elems: int = 32 << 20, group=None, overlap: bool = True):
+    def __init__(self, model, bucket_elems: int = 32 << 20, group=None, overlap: bool = True, force_exchange: bool = False):
+        """force_exchange: take the exchange path even in a group of one rank (tests: the RCCL launches, their stream
+        ordering against the side stream and the per-slice optimiser can then be exercised on a single GPU)."""
         self.model, self.group, self.bucket_elems = model, group, bucket_elems
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.pending = []
+        self.force_exchange = force_exchange
         model.world_size = self.world_size
         model.bucket_elems = bucket_elems
-        if overlap and self.world_size > 1:
+        exchange = self.world_size > 1 or (force_exchange and dist.is_initialized())
+        if overlap and exchange:
             model.bucket_hook = self._bucket_ready
             model.bucket_waits = self._take_pending
-        elif self.world_size > 1:
+        elif exchange:
             model.allreduce = self._allreduce       # (a single rank keeps the model's own single-GPU optimiser path)
         if self.world_size > 1:
             st = model.store
@@ -86,7 +90,7 @@ class DataParallel:
             model._refresh_copies()
 
     def _allreduce(self, flat_grads: torch.Tensor):
-        allreduce_flat(flat_grads, self.bucket_elems, self.group)
+        allreduce_flat(flat_grads, self.bucket_elems, self.group, force=self.force_exchange)
 
     def _bucket_ready(self, lo: int, hi: int):
         self.pending.append((lo, hi, dist.all_reduce(self.model.store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
