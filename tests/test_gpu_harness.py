@@ -176,3 +176,33 @@ def test_rccl_exchange_path_single_rank(overlap):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_predict_any_sample_count_and_folder_loop(tmp_path):
+    """predict() pads the last chunk to the engine's batch (inference-mode BN keeps samples independent): 1, 4 and 6
+    samples give the rows of the full batches; the folder loop (loader -> fit -> predict_directory) runs end to end."""
+    from PIL import Image
+    from segamd import data as D
+    m = build()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((8, 32, 32, 3), generator=g)
+    full = [np.concatenate([a, b], 0) for a, b in zip(m.predict(x[:4]), m.predict(x[4:]))]
+    for n in (1, 3, 4, 6, 8):
+        got = m.predict(x[:n])
+        assert all(np.array_equal(gk, fk[:n]) for gk, fk in zip(got, full)), n
+    rng = np.random.default_rng(0)
+    idir, mdir = tmp_path / "img", tmp_path / "msk"
+    idir.mkdir()
+    mdir.mkdir()
+    for k in range(6):
+        im = rng.integers(0, 256, (32, 32, 3)).astype(np.uint8)
+        Image.fromarray(im, "RGB").save(idir / f"{k}.png")
+        Image.fromarray(((im[..., 0] > 127) * 255).astype(np.uint8), "L").save(mdir / f"{k}.png")
+    gen = D.CustomDataGenerator(str(idir), str(mdir), img_size=(32, 32), batch_size=4, is_train=True, drop_remainder=True,
+                                deep_supervision=True, model_depth=3, ds_type="UNetPP", rng=rng)
+    hist = H.fit(m, gen, 8)
+    assert hist["loss"][-1] < hist["loss"][0]
+    r = H.predict_directory(m, str(idir), str(mdir), str(tmp_path / "pred"), threshold=0.5)
+    assert r["cm"].sum() == 6 * 32 * 32 and len(r["dice"]) == 6
+    assert sorted(p.name for p in (tmp_path / "pred").iterdir()) == sorted(r["names"])
+    assert set(np.unique(np.asarray(Image.open(tmp_path / "pred" / "0.png")))) <= {0, 255}

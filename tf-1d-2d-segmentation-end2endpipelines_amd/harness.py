@@ -12,6 +12,7 @@ f3  weight files keyed by structural parameter names (.npz).
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -105,30 +106,56 @@ class FitState:
         self.stop_training = False
 
 
+def _as_batch(model, x, targets):
+    """Loader output -> what the engine takes: numpy arrays become torch tensors, a Keras-style {output name: array}
+    dictionary (data.prepare_train_dict) becomes a list in the order of the model's outputs, a single target a list."""
+    import torch
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, np.float32))
+    if isinstance(targets, dict):
+        from .data import targets_for
+        targets = targets_for(model, targets)
+    elif not isinstance(targets, (list, tuple)):
+        targets = [targets]
+    targets = [torch.from_numpy(np.ascontiguousarray(t, np.float32)) if isinstance(t, np.ndarray) else t for t in targets]
+    return x, targets
+
+
+def _batches(src):
+    """A loader is a callable returning an iterable, or an iterable itself (e.g. data.CustomDataGenerator)."""
+    return src() if callable(src) else src
+
+
 def evaluate(model, batches: Iterable, loss: Optional[str] = None) -> float:
     """Mean over batches of the summed per-output loss, inference-mode BN (Keras `evaluate`)."""
     tot, n = 0.0, 0
-    for x, targets in batches:
+    for x, targets in _batches(batches):
+        x, targets = _as_batch(model, x, targets)
         model.forward(x, training=False)
-        tot += float(model.compute_loss(targets if isinstance(targets, (list, tuple)) else [targets], loss).cpu())
+        tot += float(model.compute_loss(targets, loss).cpu())
         n += 1
     return tot / max(n, 1)
 
 
-def fit(model, train_batches: Callable[[], Iterable], epochs: int, val_batches: Optional[Callable[[], Iterable]] = None,
+def fit(model, train_batches, epochs: int, val_batches=None,
         callbacks: Sequence = (), verbose: bool = False) -> Dict[str, List[float]]:
-    """model.fit(...) of Train.py:394-415: per epoch one pass over train_batches() (optimiser step per batch), then
-    validation, then the callbacks in order.  Returns `history.history`."""
+    """model.fit(...) of Train.py:394-415: per epoch one pass over the training loader (optimiser step per batch), then
+    validation, then the callbacks in order.  A loader is a callable returning an iterable of (x, targets), or such an
+    iterable itself (data.CustomDataGenerator: its on_epoch_end() reshuffles after every epoch, as Keras calls it).
+    Returns `history.history`."""
     hist: Dict[str, List[float]] = {}
     state = FitState(model)
     for epoch in range(int(epochs)):
         tot, n = 0.0, 0
-        for x, targets in train_batches():
+        for x, targets in _batches(train_batches):
+            x, targets = _as_batch(model, x, targets)
             tot += float(model.train_step(x, targets).cpu())
             n += 1
+        if hasattr(train_batches, "on_epoch_end"):
+            train_batches.on_epoch_end()
         logs = {"loss": tot / max(n, 1)}
         if val_batches is not None:
-            logs["val_loss"] = evaluate(model, val_batches())
+            logs["val_loss"] = evaluate(model, val_batches)
         for cb in callbacks:
             cb.on_epoch_end(epoch, logs, state)
         for k, v in logs.items():
@@ -141,14 +168,20 @@ def fit(model, train_batches: Callable[[], Iterable], epochs: int, val_batches: 
 
 
 # ------------------------------------------------------------------------------------------------ f2: masks
-def masks_from_predictions(pred, threshold: float = 0.5) -> np.ndarray:
+def masks_from_predictions(pred, threshold: float = 0.5, multiclass: str = "argmax") -> np.ndarray:
     """pred: model.predict output (a list when the model has deep-supervision outputs: Test.py:162-163 takes [0]);
-    one class: np.where(pred < threshold, 0, 1) (Test.py:176); several classes: channel arg-max."""
+    one class: np.where(pred < threshold, 0, 1) (Test.py:176); several classes: channel arg-max, or with
+    multiclass='count' what Test.py:169-174 spells out (the number of channels at or above the threshold; that branch
+    reads a variable it never initialises, so the reference itself cannot run it)."""
     if isinstance(pred, (list, tuple)):
         pred = pred[0]
     pred = np.asarray(pred)
     if pred.shape[-1] == 1:
         return np.where(pred < threshold, 0, 1).astype(np.int64)
+    if multiclass == "count":
+        return np.where(pred < threshold, 0, 1).sum(axis=-1, keepdims=True).astype(np.int64)
+    if multiclass != "argmax":
+        raise ValueError("multiclass must be 'argmax' or 'count'")
     return np.argmax(pred, axis=-1)[..., None].astype(np.int64)
 
 
@@ -156,6 +189,71 @@ def mask_grey_levels(mask: np.ndarray, normalizing_factor_msk: float = 255.0, cl
     """Test.py:181-183: `pred.astype(int8) * round(normalizing_factor_msk / class_number)` as an 8-bit 'L' image."""
     m = np.asarray(mask)[..., 0].astype(np.int8)
     return (m * np.round(normalizing_factor_msk / class_number)).astype(np.uint8)
+
+
+def predict_directory(model, image_dir: str, mask_dir: str, save_dir: Optional[str] = None, img_size=None,
+                      num_channels: int = 3, class_number: int = 1, threshold: float = 0.5,
+                      normalizing_factor_img: float = 255.0, normalizing_factor_msk: float = 255.0,
+                      patch_shape: Optional[Sequence[int]] = None, overlap_ratio: float = 0.5,
+                      multiclass: str = "argmax") -> Dict[str, np.ndarray]:
+    """The prediction loop of Test.py:118-200 for one fold: every image of image_dir (file order of os.listdir; the
+    mask of the same position in mask_dir's listing) is opened with PIL, resized with nearest-neighbour resampling when
+    its size differs, divided by its normalising factor, predicted ALONE (inference-mode BN; with patch_shape: cut
+    into overlapping patches, predicted, laid back with unpatchify), reduced to its first deep-supervision output,
+    thresholded, written to save_dir under the image's name as an 8-bit 'L' image of `mask * round(norm / classes)`,
+    and accumulated into the fold's confusion matrices and per-image Dice scores.
+
+    Returns {'names', 'cm' (classes x classes), 'cm_per_class' (classes x 2 x 2), 'dice' (per image)}."""
+    from PIL import Image
+    from . import data as D
+    H, W = img_size if img_size is not None else model.graph.nodes[model.graph.inputs[0]].shape[:2]
+    imgs, msks = os.listdir(image_dir), os.listdir(mask_dir)
+    if len(imgs) != len(msks):
+        raise ValueError("Number of Images and Masks should be the same!")
+    if save_dir is not None:
+        os.makedirs(save_dir, exist_ok=True)
+    labels = np.arange(max(2, class_number + (1 if multiclass == "count" else 0)))
+    cm = np.zeros((len(labels), len(labels)), np.int64)
+    cmc = np.zeros((len(labels), 2, 2), np.int64)
+    dices = []
+
+    def first(p):
+        return p[0] if isinstance(p, (list, tuple)) else p
+
+    for name, mname in zip(imgs, msks):
+        with Image.open(os.path.join(image_dir, name)) as im:
+            if im.size != (W, H):
+                im = im.resize((W, H), Image.Resampling.NEAREST)
+            img = np.asarray(im, np.float64) / normalizing_factor_img
+        if img.ndim == 2:
+            img = img[:, :, None]
+        if img.shape[2] != num_channels:
+            raise ValueError(f"{name}: {img.shape[2]} channels, the model takes {num_channels}")
+        with Image.open(os.path.join(mask_dir, mname)) as mk:
+            if mk.size != (W, H):
+                mk = mk.resize((W, H), Image.Resampling.NEAREST)
+            msk = np.asarray(mk, np.float64) / normalizing_factor_msk
+        if msk.ndim == 3:
+            msk = msk[:, :, 0]
+        msk = msk.astype(np.uint8)                                   # Test.py:124,147: a uint8 staging array
+        if patch_shape is not None:
+            pw, ph = int(patch_shape[0]), int(patch_shape[1])
+            p, n = D.create_patches(img, (pw, ph), overlap_ratio)
+            pred_p = first(model.predict(np.reshape(np.squeeze(p), (n, pw, ph, num_channels)).astype(np.float32)))
+            if pred_p.shape[-1] != 1:
+                raise ValueError("the patch path of the reference (Test.py:156-159) handles one-channel predictions only")
+            mp, _ = D.create_patches(msk, (pw, ph), overlap_ratio)
+            pred = D.unpatchify(np.reshape(np.squeeze(pred_p), mp.shape), msk.shape)[None, :, :, None]
+        else:
+            pred = first(model.predict(img[None].astype(np.float32)))
+        m = masks_from_predictions(pred, threshold, multiclass)[0]
+        if save_dir is not None:
+            Image.fromarray(mask_grey_levels(m[None], normalizing_factor_msk, class_number)[0], mode="L").save(os.path.join(save_dir, name))
+        yt, yp = msk.ravel().astype(np.int64), m.ravel()
+        cm += D.confusion_matrix(yt, yp, labels)
+        cmc += D.multilabel_confusion_matrix(yt, yp, labels)
+        dices.append(D.dice(msk, m[..., 0]))
+    return {"names": imgs, "cm": cm, "cm_per_class": cmc, "dice": np.asarray(dices)}
 
 
 # ------------------------------------------------------------------------------------------------ f3: weight files

@@ -1505,9 +1505,24 @@ class SegModel:
     __call__ = forward
 
     def predict(self, x, batch_size=None, verbose=0):
-        """model.predict (2DCNN/Test.py:153,161): inference-mode BN.  Returns numpy, a list when the model has several outputs."""
+        """model.predict (2DCNN/Test.py:153,161): inference-mode BN.  Returns numpy, a list when the model has several outputs.
+        Any number of samples: the engine's batch is fixed at build, so the input is processed in chunks of that size, the
+        last one padded with zeros (inference-mode BN keeps samples independent, the padding rows are dropped)."""
         x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x
-        outs = [o.cpu().numpy() for o in self.forward(x, training=False)]
+        if not self.built:
+            self.build(x.shape[0])
+        n, N = x.shape[0], self.N
+        if n == N:
+            outs = [o.cpu().numpy() for o in self.forward(x, training=False)]
+        else:
+            parts = []
+            for lo in range(0, n, N):
+                xb = x[lo:lo + N]
+                k = xb.shape[0]
+                if k < N:
+                    xb = torch.cat([xb, torch.zeros((N - k,) + tuple(xb.shape[1:]), dtype=xb.dtype, device=xb.device)], 0)
+                parts.append([o[:k].cpu().numpy() for o in self.forward(xb, training=False)])
+            outs = [np.concatenate([p[i] for p in parts], 0) for i in range(len(parts[0]))]
         return outs if len(outs) > 1 else outs[0]
 
     def adam_slices(self) -> List[Tuple[int, int, int]]:
