@@ -29,7 +29,11 @@ typedef void* seg_stream_t; /* hipStream_t */
 
 enum { SEG_OK = 0, SEG_ERR_ARG = -1, SEG_ERR_LAUNCH = -2, SEG_ERR_UNSUPPORTED = -3 };
 enum { SEG_ACT_NONE = 0, SEG_ACT_RELU = 1, SEG_ACT_LEAKY = 2, SEG_ACT_SIGMOID = 3, SEG_ACT_SOFTMAX = 4 };
-enum { SEG_LOSS_MSE = 0, SEG_LOSS_BCE = 1, SEG_LOSS_CCE = 2 };
+/* the 16 names of 2DCNN/utils/tf_losses.py:4-44, Keras 2.x formulas (eps 1e-7).  CCE / KLD / CATHINGE / COSINE /
+ * SPARSE_CCE reduce over the channel axis and average over pixels, the others average over every element. */
+enum { SEG_LOSS_MSE = 0, SEG_LOSS_BCE = 1, SEG_LOSS_CCE = 2, SEG_LOSS_MAE = 3, SEG_LOSS_MAPE = 4, SEG_LOSS_MSLE = 5,
+       SEG_LOSS_HUBER = 6, SEG_LOSS_LOGCOSH = 7, SEG_LOSS_POISSON = 8, SEG_LOSS_HINGE = 9, SEG_LOSS_SQHINGE = 10,
+       SEG_LOSS_FOCAL = 11, SEG_LOSS_KLD = 12, SEG_LOSS_CATHINGE = 13, SEG_LOSS_COSINE = 14, SEG_LOSS_SPARSE_CCE = 15 };
 
 #define SEG_MAX_SEG 8
 #define SEG_MAX_TAPS 16
@@ -239,6 +243,13 @@ int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int
  * loss_out[0] += loss ; dpred = d loss / d pred                                                               */
 int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C,
                      float* loss_out, float* dpred, seg_stream_t stream);
+/* The same with a loss weight (model.compile(loss_weights=...), 1D notebook cell 35): loss_out[0] += weight * loss,
+ * dpred = weight * d loss / d pred.  SEG_LOSS_SPARSE_CCE: target holds ONE class index per pixel (npix floats).
+ * binary_flag (device, may be NULL = 1): HINGE / SQHINGE read labels as 2t-1 when it is non-zero - Keras converts
+ * {0,1} labels to {-1,+1} only when every label of the batch is 0 or 1; seg_labels_binary computes that flag.    */
+int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float weight,
+                       const int32_t* binary_flag, float* loss_out, float* dpred, seg_stream_t stream);
+int seg_labels_binary(const float* target, int64_t n, int32_t* flag, seg_stream_t stream);
 /* amax[0] = max(amax[0], max |x|)  (amax must be zeroed by the caller)                                         */
 int seg_absmax(const float* x, int64_t n, float* amax, seg_stream_t stream);
 /* gs[0] = 2^k with amax*2^k in [target/2, target), gs[1] = 1/gs[0]  (gs[0] = 1 when amax is 0 or not finite)   */

@@ -1,6 +1,9 @@
 """ORACLE (test infrastructure) - Keras default train_step restated: forward (training-mode BN) -> sum of
-per-output losses with unit weights (`2D/Train.py:322-325`, no loss_weights) -> gradients -> Keras Adam
-(`2D/utils/tf_optimizers.py:11`: beta (0.9, 0.999), epsilon 1e-7).  PARITY UNPINNED (keras_ref.py header)."""
+per-output losses with unit weights (`2D/Train.py:322-325`, no loss_weights; the 1D notebook passes some) ->
+gradients -> Keras Adam (`2D/utils/tf_optimizers.py:11`: beta (0.9, 0.999), epsilon 1e-7).  The losses are the 16
+names of `2D/utils/tf_losses.py:9-39`; the reference only names them - the formulas are Keras 2.x's (keras/losses.py,
+keras/backend.py: a third-party dependency that is not in this image), restated here with torch ops and
+differentiated by autograd.  PARITY UNPINNED (keras_ref.py header)."""
 from __future__ import annotations
 
 import math
@@ -29,7 +32,97 @@ def categorical_crossentropy(pred, target):
     return -(target * torch.log(p)).sum(-1).mean()
 
 
-LOSSES = {"mse": mse, "bce": binary_crossentropy, "cce": categorical_crossentropy}
+def mae(pred, target):
+    """MeanAbsoluteError: mean |pred - target|."""
+    return (pred - target).abs().mean()
+
+
+def mape(pred, target):
+    """MeanAbsolutePercentageError: 100 * mean |(target - pred) / max(|target|, eps)|."""
+    return 100.0 * ((target - pred) / target.abs().clamp_min(K_EPS)).abs().mean()
+
+
+def msle(pred, target):
+    """MeanSquaredLogarithmicError: mean (log(max(pred, eps) + 1) - log(max(target, eps) + 1))^2."""
+    return ((torch.log(pred.clamp_min(K_EPS) + 1.0) - torch.log(target.clamp_min(K_EPS) + 1.0)) ** 2).mean()
+
+
+def huber(pred, target, delta=1.0):
+    """Huber(delta=1): 0.5 e^2 where |e| <= delta, else delta |e| - 0.5 delta^2."""
+    e = pred - target
+    a = e.abs()
+    return torch.where(a <= delta, 0.5 * e * e, delta * a - 0.5 * delta * delta).mean()
+
+
+def logcosh(pred, target):
+    """LogCosh: mean(x + softplus(-2x) - log 2), x = pred - target."""
+    x = pred - target
+    return (x + torch.nn.functional.softplus(-2.0 * x) - math.log(2.0)).mean()
+
+
+def poisson(pred, target):
+    """Poisson: mean(pred - target * log(pred + eps))."""
+    return (pred - target * torch.log(pred + K_EPS)).mean()
+
+
+def _pm1(target):
+    """keras.losses._maybe_convert_labels: {0,1} labels become {-1,+1} when EVERY label is 0 or 1."""
+    binary = bool(((target == 0) | (target == 1)).all())
+    return 2.0 * target - 1.0 if binary else target
+
+
+def hinge(pred, target):
+    """Hinge: mean max(1 - t' pred, 0)."""
+    return (1.0 - _pm1(target) * pred).clamp_min(0.0).mean()
+
+
+def squared_hinge(pred, target):
+    """SquaredHinge: mean max(1 - t' pred, 0)^2."""
+    return ((1.0 - _pm1(target) * pred).clamp_min(0.0) ** 2).mean()
+
+
+def binary_focal_crossentropy(pred, target, gamma=2.0):
+    """BinaryFocalCrossentropy(gamma=2, from_logits=False): (1 - p_t)^gamma * bce with p_t on the unclipped
+    prediction and the clipped prediction inside the cross-entropy (keras.backend.binary_focal_crossentropy)."""
+    p_t = target * pred + (1.0 - target) * (1.0 - pred)
+    pc = pred.clamp(K_EPS, 1.0 - K_EPS)
+    bce = -(target * torch.log(pc) + (1.0 - target) * torch.log(1.0 - pc))
+    return ((1.0 - p_t) ** gamma * bce).mean()
+
+
+def kl_divergence(pred, target):
+    """KLDivergence: both clipped to [eps, 1]; sum over the last axis of t log(t / p); mean."""
+    t, p = target.clamp(K_EPS, 1.0), pred.clamp(K_EPS, 1.0)
+    return (t * torch.log(t / p)).sum(-1).mean()
+
+
+def categorical_hinge(pred, target):
+    """CategoricalHinge: max(0, max((1 - t) p) - sum(t p) + 1) over the last axis; mean."""
+    pos = (target * pred).sum(-1)
+    neg = ((1.0 - target) * pred).max(-1).values
+    return (neg - pos + 1.0).clamp_min(0.0).mean()
+
+
+def cosine_similarity(pred, target):
+    """CosineSimilarity(axis=-1): -sum(l2n(t) l2n(p)), l2n(x) = x * rsqrt(max(sum x^2, 1e-12)) (tf.nn.l2_normalize)."""
+    def l2n(x):
+        return x * torch.rsqrt((x * x).sum(-1, keepdim=True).clamp_min(1e-12))
+    return -(l2n(target) * l2n(pred)).sum(-1).mean()
+
+
+def sparse_categorical_crossentropy(pred, target):
+    """SparseCategoricalCrossentropy(from_logits=False): probabilities clipped to [eps, 1 - eps], their logs fed to a
+    softmax cross-entropy against the class index (target: one index per pixel, trailing axis of size 1 or none)."""
+    q = pred.clamp(K_EPS, 1.0 - K_EPS)
+    idx = target.reshape(pred.shape[:-1]).long()
+    logq = torch.log(q)
+    return -(logq.gather(-1, idx[..., None])[..., 0] - torch.logsumexp(logq, -1)).mean()
+
+
+LOSSES = {"mse": mse, "bce": binary_crossentropy, "cce": categorical_crossentropy, "mae": mae, "mape": mape, "msle": msle,
+          "huber": huber, "logcosh": logcosh, "poisson": poisson, "hinge": hinge, "squared_hinge": squared_hinge,
+          "binary_focal": binary_focal_crossentropy, "kld": kl_divergence, "categorical_hinge": categorical_hinge,
+          "cosine": cosine_similarity, "sparse_cce": sparse_categorical_crossentropy}
 
 
 class KerasAdam:
@@ -56,14 +149,15 @@ class KerasAdam:
             p.sub_(a * self.m[k] / (self.v[k].sqrt() + self.eps))
 
 
-def loss_and_grads(layers, forward: Callable[[], List[torch.Tensor]], targets: Sequence[torch.Tensor], loss: str):
+def loss_and_grads(layers, forward: Callable[[], List[torch.Tensor]], targets: Sequence[torch.Tensor], loss: str,
+                   loss_weights: Sequence[float] = None):
     """One forward+backward.  Returns (total_loss, per-output losses, outputs, grads by parameter name)."""
     for p in layers.params.values():
         p.grad = None
     outs = forward()
     fn = LOSSES[loss]
     per = [fn(o, t) for o, t in zip(outs, targets)]
-    total = sum(per)
+    total = sum(per) if loss_weights is None else sum(w * l for w, l in zip(loss_weights, per))
     total.backward()
     grads = {k: v.grad.detach().clone() for k, v in layers.params.items() if v.grad is not None}
     return float(total.detach()), [float(p.detach()) for p in per], [o.detach() for o in outs], grads

@@ -147,3 +147,32 @@ def test_train_steps_follow_the_oracle():
     for k in ("X01/conv/kernel", "enc1/bn/moving_mean", "enc1/bn/moving_variance", "out/kernel"):
         d = np.abs(wg[k] - wr[k]).max()
         assert d < 5e-3 * max(1.0, np.abs(wr[k]).max()), (k, d)
+
+
+def test_registry_loss_with_loss_weights_follows_the_oracle():
+    """compile(loss='MeanSquaredLogarithmicError' - the Train_Configs.ini default -, loss_weights=1 - 0.1 k as the 1D
+    notebook passes them): two optimiser steps against the oracle's weighted sum."""
+    torch.manual_seed(5)
+    kw = dict(ds=1)
+    model = B("UNetPP", 32, 32, 16, 2, num_channels=3, **kw)
+    model.build(2)
+    lw = [1.0, 0.9, 0.8]
+    model.compile(loss="MeanSquaredLogarithmicError", lr=1e-3, loss_weights=lw)
+    x = torch.rand(2, 32, 32, 3)
+    tg = [torch.rand(2, 32, 32, 1)] * 3
+    L = Layers(2, seed=0)
+    L.set_weights(model.get_weights())
+    opt = KerasAdam({k: v for k, v in L.params.items() if L.trainable[k]}, lr=1e-3)
+    fwd = lambda: unet2d_forward(L, x, "UNetPP", 16, 2, **kw)
+    for _ in range(2):
+        gl = float(model.train_step(x, tg).cpu())
+        l, per, _o, grads = loss_and_grads(L, fwd, tg, "msle", lw)
+        opt.step(grads)
+        assert abs(gl - l) < 5e-3 * max(1.0, abs(l)), (gl, l)
+        assert abs(l - sum(w * p for w, p in zip(lw, per))) < 1e-6
+    with pytest.raises(ValueError):
+        model.compile(loss="Dice")
+    with pytest.raises(ValueError):
+        model.compile(loss="mse", loss_weights=[1.0])
+    model.compile(loss="mae", loss_weights={"out": 2.0})
+    assert model.loss_weights == [2.0, 1.0, 1.0]

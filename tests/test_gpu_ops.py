@@ -779,6 +779,92 @@ def test_losses_match_keras_definitions(kind, Cc):
     assert rel(dp.cpu(), pr.grad) < 1e-4
 
 
+ALL_LOSSES = ["mse", "bce", "cce", "mae", "mape", "msle", "huber", "logcosh", "poisson", "hinge", "squared_hinge", "binary_focal",
+              "kld", "categorical_hinge", "cosine", "sparse_cce"]
+
+
+def _loss_case(kind, npix, Cc, g):
+    """Predictions / targets in the domain the loss is used on (probabilities for the cross-entropies, unbounded
+    for the regression losses), with values on and beyond the clip edges mixed in."""
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    rndn = lambda *s: torch.randn(*s, generator=g)
+    if kind in ("cce", "kld", "categorical_hinge", "sparse_cce"):
+        p = torch.softmax(rndn(npix, Cc) * 3, -1)
+        cls = torch.randint(0, Cc, (npix,), generator=g)
+        t = cls.float().reshape(npix, 1) if kind == "sparse_cce" else F.one_hot(cls, Cc).float()
+        if kind == "kld":
+            t = torch.softmax(rndn(npix, Cc), -1)
+        if kind == "categorical_hinge":
+            p = rndn(npix, Cc)
+    elif kind in ("bce", "binary_focal"):
+        p = torch.sigmoid(rndn(npix, Cc) * 3)
+        t = (rnd(npix, Cc) > 0.5).float()
+        p[:7] = torch.tensor([0.0, 1.0, 1e-8, 1.0 - 1e-8, -0.2, 1.3, 0.5])[:, None]       # on / outside the clip range
+    elif kind in ("hinge", "squared_hinge"):
+        p = rndn(npix, Cc)
+        t = (rnd(npix, Cc) > 0.5).float()
+    elif kind in ("msle", "poisson"):
+        p = rnd(npix, Cc) * 3
+        t = rnd(npix, Cc) * 3
+        p[:3] = torch.tensor([0.0, 1e-9, -0.5])[:, None] if kind == "msle" else p[:3]
+    elif kind == "mape":
+        p = rndn(npix, Cc)
+        t = rndn(npix, Cc)
+        t[:4] = 0.0                                                                         # |t| below the eps floor
+    elif kind == "cosine":
+        p, t = rndn(npix, Cc), rndn(npix, Cc)
+    else:
+        p = rndn(npix, Cc) * 2
+        t = rndn(npix, Cc) * 2
+    return p, t
+
+
+@pytest.mark.parametrize("Cc", [1, 3])
+@pytest.mark.parametrize("kind", ALL_LOSSES)
+def test_every_registry_loss_and_its_gradient(kind, Cc):
+    """The 16 names of utils/tf_losses.py through seg_loss_fwd_bwd_w against the oracle's torch restatement, whose
+    gradient comes from autograd (the kernel's is derived by hand); with a loss weight."""
+    if Cc == 1 and kind in ("cce", "kld", "categorical_hinge", "sparse_cce", "cosine"):
+        Cc = 5
+    g = torch.Generator().manual_seed(sum(map(ord, kind)))
+    npix, w = 4099, 0.7
+    p, t = _loss_case(kind, npix, Cc, g)
+    pr = p.clone().requires_grad_(True)
+    L = w * TR.LOSSES[kind](pr, t)
+    L.backward()
+    lo = torch.zeros(1, device="cuda")
+    dp = torch.full((npix, Cc), 7.0, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pd, td = p.cuda(), t.contiguous().cuda()
+    ffi.call("seg_labels_binary", P(td), td.numel(), P(flag), stream())
+    ffi.call("seg_loss_fwd_bwd_w", ffi.LOSS[kind], P(pd), P(td), npix, Cc, w, P(flag), P(lo), P(dp), stream())
+    torch.cuda.synchronize()
+    assert int(flag.cpu()) == int(bool(((t == 0) | (t == 1)).all()))
+    assert abs(float(lo.cpu()) - float(L.detach())) < 3e-5 * max(1.0, abs(float(L.detach()))), (float(lo.cpu()), float(L))
+    ref = pr.grad
+    err = float((dp.cpu() - ref).abs().max())
+    assert err < 2e-5 * max(float(ref.abs().max()), 1e-6), (err, float(ref.abs().max()))
+
+
+def test_loss_names_of_the_reference_registry_and_hinge_label_rule():
+    assert all(ffi.LOSS[a] == ffi.LOSS[b] for a, b in ffi.LOSS_ALIASES.items()) and len(ffi.LOSS_ALIASES) == 16
+    # labels that are not all 0/1 are used as they are (keras _maybe_convert_labels)
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(1000, 2, generator=g)
+    for t in ((torch.rand(1000, 2, generator=g) > 0.5).float() * 2 - 1, (torch.rand(1000, 2, generator=g) > 0.5).float()):
+        pr = p.clone().requires_grad_(True)
+        L = TR.LOSSES["hinge"](pr, t)
+        L.backward()
+        lo = torch.zeros(1, device="cuda")
+        dp = torch.zeros(1000, 2, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pd, td = p.cuda(), t.cuda()
+        ffi.call("seg_labels_binary", P(td), td.numel(), P(flag), stream())
+        ffi.call("seg_loss_fwd_bwd_w", ffi.LOSS["Hinge"], P(pd), P(td), 1000, 2, 1.0, P(flag), P(lo), P(dp), stream())
+        torch.cuda.synchronize()
+        assert abs(float(lo.cpu()) - float(L.detach())) < 1e-5 and rel(dp.cpu(), pr.grad) < 1e-5
+
+
 def test_grad_scale_is_power_of_two_in_range():
     for amax in [3.7e-7, 0.0123, 1.0, 777.0, 5e4]:
         x = torch.zeros(1000, device="cuda")

@@ -12,7 +12,16 @@ LIB_PATH = os.path.join(_HERE, "libseg_hip.so")
 
 MAX_SEG, MAX_TAPS, MAX_CLS = 8, 16, 4
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "leaky_relu": 2, "sigmoid": 3, "softmax": 4}
-LOSS = {"mse": 0, "bce": 1, "cce": 2}
+LOSS = {"mse": 0, "bce": 1, "cce": 2, "mae": 3, "mape": 4, "msle": 5, "huber": 6, "logcosh": 7, "poisson": 8, "hinge": 9,
+        "squared_hinge": 10, "binary_focal": 11, "kld": 12, "categorical_hinge": 13, "cosine": 14, "sparse_cce": 15}
+# the names `TFLosses(name).loss()` takes (2DCNN/utils/tf_losses.py:9-39)
+LOSS_ALIASES = {"MeanSquaredError": "mse", "BinaryCrossentropy": "bce", "CategoricalCrossentropy": "cce",
+                "MeanAbsoluteError": "mae", "MeanAbsolutePercentageError": "mape", "MeanSquaredLogarithmicError": "msle",
+                "Huber": "huber", "LogCosh": "logcosh", "Poisson": "poisson", "Hinge": "hinge", "SquaredHinge": "squared_hinge",
+                "BinaryFocalCrossentropy": "binary_focal", "KLDivergence": "kld", "CategoricalHinge": "categorical_hinge",
+                "CosineSimilarity": "cosine", "SparseCategoricalCrossentropy": "sparse_cce"}
+for _long, _short in LOSS_ALIASES.items():
+    LOSS[_long] = LOSS[_short]
 
 
 class Geom(C.Structure):
@@ -79,6 +88,8 @@ _PROTOS = {
     "seg_head_fwd": ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp], C.c_int),
     "seg_head_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i64, vp], C.c_int),
     "seg_loss_fwd_bwd": ([i32, vp, vp, i64, i32, vp, vp, vp], C.c_int),
+    "seg_loss_fwd_bwd_w": ([i32, vp, vp, i64, i32, C.c_float, vp, vp, vp, vp], C.c_int),
+    "seg_labels_binary": ([vp, i64, vp, vp], C.c_int),
     "seg_absmax": ([vp, i64, vp, vp], C.c_int),
     "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),
     "seg_adam_step": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp], C.c_int),

@@ -1100,44 +1100,142 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_finalize_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ losses
-__global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, const float* target, int64_t npix, int C, float inv_n,
-                                                   float* loss_out, float* dpred) {
+// The 16 names of utils/tf_losses.py:4-44 with the Keras 2.x formulas (keras/losses.py, keras/backend.py; eps = 1e-7).
+// Element-wise kinds average f(pred, target) over every element; per-pixel kinds reduce over the channel axis first and
+// average over pixels.  dpred = weight * d loss / d pred, loss_out[0] += weight * loss.
+__device__ __forceinline__ bool loss_per_pixel(int kind) {
+  return kind == SEG_LOSS_CCE || kind == SEG_LOSS_KLD || kind == SEG_LOSS_CATHINGE || kind == SEG_LOSS_COSINE || kind == SEG_LOSS_SPARSE_CCE;
+}
+
+__device__ __forceinline__ float loss_elem(int kind, float p, float t, bool pm1, float& g) {
   const float EPS = 1e-7f;
+  switch (kind) {
+    case SEG_LOSS_MSE: { const float d = p - t; g = 2.f * d; return d * d; }
+    case SEG_LOSS_BCE: {   // probabilities clipped to [eps, 1 - eps], zero gradient outside
+      const float pc = fminf(fmaxf(p, EPS), 1.f - EPS);
+      const float inside = (p > EPS && p < 1.f - EPS) ? 1.f : 0.f;
+      g = inside * (-(t / pc) + (1.f - t) / (1.f - pc));
+      return -(t * __logf(pc) + (1.f - t) * __logf(1.f - pc));
+    }
+    case SEG_LOSS_MAE: { const float d = p - t; g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); return fabsf(d); }
+    case SEG_LOSS_MAPE: {  // 100 |(t - p) / max(|t|, eps)|
+      const float den = fmaxf(fabsf(t), EPS), d = p - t;
+      g = (d > 0.f ? 100.f : (d < 0.f ? -100.f : 0.f)) / den;
+      return 100.f * fabsf(d) / den;
+    }
+    case SEG_LOSS_MSLE: {  // (log(max(p, eps) + 1) - log(max(t, eps) + 1))^2
+      const float pc = fmaxf(p, EPS), d = log1pf(pc) - log1pf(fmaxf(t, EPS));
+      g = p >= EPS ? 2.f * d / (pc + 1.f) : 0.f;
+      return d * d;
+    }
+    case SEG_LOSS_HUBER: { // delta = 1
+      const float d = p - t, ad = fabsf(d);
+      g = ad <= 1.f ? d : (d > 0.f ? 1.f : -1.f);
+      return ad <= 1.f ? 0.5f * d * d : ad - 0.5f;
+    }
+    case SEG_LOSS_LOGCOSH: {  // x + softplus(-2x) - log 2
+      const float x = p - t, z = -2.f * x;
+      g = tanhf(x);
+      return x + fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))) - 0.69314718056f;
+    }
+    case SEG_LOSS_POISSON: { g = 1.f - t / (p + EPS); return p - t * logf(p + EPS); }
+    case SEG_LOSS_HINGE: case SEG_LOSS_SQHINGE: {   // labels in {0,1} are read as {-1,+1} (keras _maybe_convert_labels)
+      const float tt = pm1 ? 2.f * t - 1.f : t, m = fmaxf(1.f - tt * p, 0.f);
+      if (kind == SEG_LOSS_HINGE) { g = m > 0.f ? -tt : 0.f; return m; }
+      g = -2.f * tt * m;
+      return m * m;
+    }
+    default: {             // SEG_LOSS_FOCAL: (1 - p_t)^2 * bce, p_t = t p + (1 - t)(1 - p) on the unclipped prediction
+      const float pc = fminf(fmaxf(p, EPS), 1.f - EPS);
+      const float inside = (p > EPS && p < 1.f - EPS) ? 1.f : 0.f;
+      const float bce = -(t * logf(pc) + (1.f - t) * logf(1.f - pc));
+      const float dbce = inside * (-(t / pc) + (1.f - t) / (1.f - pc));
+      const float q = 1.f - (t * p + (1.f - t) * (1.f - p));
+      g = q * q * dbce - 2.f * q * (2.f * t - 1.f) * bce;
+      return q * q * bce;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, const float* target, int64_t npix, int C, float inv_n,
+                                                   float weight, const int* binary_flag, float* loss_out, float* dpred) {
+  const float EPS = 1e-7f;
+  const float gw = inv_n * weight;
   float local = 0.f;
-  if (kind == SEG_LOSS_CCE) {
+  if (loss_per_pixel(kind)) {
     for (int64_t pix = (int64_t)blockIdx.x * TPB + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * TPB) {
-      float s = 0.f;
-      for (int k = 0; k < C; ++k) s += pred[pix * C + k];
-      const float invs = 1.f / s;
-      // L = -sum_k t_k log(clip(p_k / s));  dL/dp_j = -t_j m_j / p_j + sum_k t_k m_k / s   (m = 1 inside the clip range)
-      float corr = 0.f;
-      for (int k = 0; k < C; ++k) {
-        const float q = pred[pix * C + k] * invs;
-        const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
-        corr += target[pix * C + k] * m;
-        local -= target[pix * C + k] * __logf(fminf(fmaxf(q, EPS), 1.f - EPS));
-      }
-      for (int k = 0; k < C; ++k) {
-        const float pk = pred[pix * C + k];
-        const float q = pk * invs;
-        const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
-        dpred[pix * C + k] = ((m > 0.f ? -target[pix * C + k] / pk : 0.f) + corr * invs) * inv_n;
+      const float* p = pred + pix * C;
+      float* d = dpred + pix * C;
+      if (kind == SEG_LOSS_CCE) {
+        const float* t = target + pix * C;
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s += p[k];
+        const float invs = 1.f / s;
+        // L = -sum_k t_k log(clip(p_k / s));  dL/dp_j = -t_j m_j / p_j + sum_k t_k m_k / s   (m = 1 inside the clip range)
+        float corr = 0.f;
+        for (int k = 0; k < C; ++k) {
+          const float q = p[k] * invs;
+          const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
+          corr += t[k] * m;
+          local -= t[k] * __logf(fminf(fmaxf(q, EPS), 1.f - EPS));
+        }
+        for (int k = 0; k < C; ++k) {
+          const float q = p[k] * invs;
+          const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
+          d[k] = ((m > 0.f ? -t[k] / p[k] : 0.f) + corr * invs) * gw;
+        }
+      } else if (kind == SEG_LOSS_SPARSE_CCE) {
+        // target: one class index per pixel.  q = clip(p, eps, 1 - eps); L = -log(q_c / sum q)  (the clipped
+        // probabilities go through log and a softmax cross-entropy, which renormalises them)
+        const int c = (int)target[pix];
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s += fminf(fmaxf(p[k], EPS), 1.f - EPS);
+        const bool valid = c >= 0 && c < C;
+        const float qc = valid ? fminf(fmaxf(p[c], EPS), 1.f - EPS) : 1.f;
+        if (valid) local += logf(s) - logf(qc);
+        for (int k = 0; k < C; ++k) {
+          const float m = (p[k] > EPS && p[k] < 1.f - EPS) ? 1.f : 0.f;
+          d[k] = valid ? m * (1.f / s - (k == c ? 1.f / qc : 0.f)) * gw : 0.f;
+        }
+      } else if (kind == SEG_LOSS_KLD) {
+        // sum_k tc_k log(tc_k / pc_k), both clipped to [eps, 1]
+        const float* t = target + pix * C;
+        for (int k = 0; k < C; ++k) {
+          const float tc = fminf(fmaxf(t[k], EPS), 1.f), pc = fminf(fmaxf(p[k], EPS), 1.f);
+          local += tc * logf(tc / pc);
+          d[k] = (p[k] >= EPS && p[k] <= 1.f) ? -tc / pc * gw : 0.f;
+        }
+      } else if (kind == SEG_LOSS_CATHINGE) {
+        // max(0, max_k((1 - t_k) p_k) - sum_k t_k p_k + 1)
+        const float* t = target + pix * C;
+        float pos = 0.f, neg = -3.4e38f;
+        int arg = 0;
+        for (int k = 0; k < C; ++k) {
+          pos += t[k] * p[k];
+          const float v = (1.f - t[k]) * p[k];
+          if (v > neg) { neg = v; arg = k; }
+        }
+        const float l = neg - pos + 1.f;
+        if (l > 0.f) local += l;
+        for (int k = 0; k < C; ++k) d[k] = l > 0.f ? (-t[k] + (k == arg ? 1.f - t[k] : 0.f)) * gw : 0.f;
+      } else {   // SEG_LOSS_COSINE: -sum_k l2n(t)_k l2n(p)_k, l2n(x) = x rsqrt(max(sum x^2, 1e-12))
+        const float* t = target + pix * C;
+        float pp = 0.f, tt = 0.f, pt = 0.f;
+        for (int k = 0; k < C; ++k) { pp += p[k] * p[k]; tt += t[k] * t[k]; pt += p[k] * t[k]; }
+        const float rp = rsqrtf(fmaxf(pp, 1e-12f)), rt = rsqrtf(fmaxf(tt, 1e-12f));
+        local -= pt * rp * rt;
+        // d/dp_j of (p.v) rp, v = t rt: v_j rp - (p.v) p_j rp^3 when sum p^2 is above the floor, else v_j rp
+        const float cub = pp > 1e-12f ? pt * rt * rp * rp * rp : 0.f;
+        for (int k = 0; k < C; ++k) d[k] = -(t[k] * rt * rp - cub * p[k]) * gw;
       }
     }
   } else {
     const int64_t n = npix * C;
+    const bool pm1 = binary_flag ? (binary_flag[0] != 0) : true;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-      const float p = pred[i], t = target[i];
-      if (kind == SEG_LOSS_MSE) {
-        const float d = p - t;
-        local += d * d;
-        dpred[i] = 2.f * d * inv_n;
-      } else {   // BCE on probabilities, clipped like Keras
-        const float pc = fminf(fmaxf(p, EPS), 1.f - EPS);
-        local -= t * __logf(pc) + (1.f - t) * __logf(1.f - pc);
-        const float inside = (p > EPS && p < 1.f - EPS) ? 1.f : 0.f;
-        dpred[i] = inside * (-(t / pc) + (1.f - t) / (1.f - pc)) * inv_n;
-      }
+      float g;
+      local += loss_elem(kind, pred[i], target[i], pm1, g);
+      dpred[i] = g * gw;
     }
   }
   local = wave_sum(local);
@@ -1147,8 +1245,16 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int k = 0; k < TPB / 64; ++k) s += sm[k];
-    atomicAdd(loss_out, s * inv_n);
+    atomicAdd(loss_out, s * gw);
   }
+}
+
+// flag[0] &= every label is 0 or 1  (flag preset to 1 by the launcher's first kernel)
+__global__ void set_flag_kernel(int* flag) { flag[0] = 1; }
+__global__ __launch_bounds__(TPB) void labels_binary_kernel(const float* t, int64_t n, int* flag) {
+  bool ok = true;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) ok = ok && (t[i] == 0.f || t[i] == 1.f);
+  if (!ok) atomicAnd(flag, 0);
 }
 
 __global__ __launch_bounds__(TPB) void absmax_kernel(const float* x, int64_t n, float* amax) {
@@ -1628,17 +1734,33 @@ static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int
 extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<half_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
 extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<float>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
 
-extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float* loss_out, float* dpred,
-                                seg_stream_t stream) {
-  SEG_CHECK_ARG(pred && target && loss_out && dpred && npix > 0 && C >= 1 && kind >= SEG_LOSS_MSE && kind <= SEG_LOSS_CCE,
+extern "C" int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float weight,
+                                  const int32_t* binary_flag, float* loss_out, float* dpred, seg_stream_t stream) {
+  SEG_CHECK_ARG(pred && target && loss_out && dpred && npix > 0 && C >= 1 && kind >= SEG_LOSS_MSE && kind <= SEG_LOSS_SPARSE_CCE,
                 "seg_loss_fwd_bwd: bad arguments");
-  const double n = (kind == SEG_LOSS_CCE) ? (double)npix : (double)npix * C;
-  const int64_t items = (kind == SEG_LOSS_CCE) ? npix : npix * C;
+  const bool pp = kind == SEG_LOSS_CCE || kind == SEG_LOSS_KLD || kind == SEG_LOSS_CATHINGE || kind == SEG_LOSS_COSINE || kind == SEG_LOSS_SPARSE_CCE;
+  const double n = pp ? (double)npix : (double)npix * C;
+  const int64_t items = pp ? npix : npix * C;
   int blocks = grid_for(items);
   if (blocks > 1024) blocks = 1024;      // every block ends with one atomic on the same loss word
-  hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), kind, pred, target, npix, C, (float)(1.0 / n), loss_out,
-                     dpred);
+  hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), kind, pred, target, npix, C, (float)(1.0 / n), weight,
+                     (const int*)binary_flag, loss_out, dpred);
   SEG_CHECK_LAUNCH("seg_loss_fwd_bwd");
+  return SEG_OK;
+}
+
+extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float* loss_out, float* dpred,
+                                seg_stream_t stream) {
+  return seg_loss_fwd_bwd_w(kind, pred, target, npix, C, 1.f, nullptr, loss_out, dpred, stream);
+}
+
+extern "C" int seg_labels_binary(const float* target, int64_t n, int32_t* flag, seg_stream_t stream) {
+  SEG_CHECK_ARG(target && flag && n > 0, "seg_labels_binary: bad arguments");
+  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, ST(stream), (int*)flag);
+  int blocks = grid_for(n);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(labels_binary_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), target, n, (int*)flag);
+  SEG_CHECK_LAUNCH("seg_labels_binary");
   return SEG_OK;
 }
 

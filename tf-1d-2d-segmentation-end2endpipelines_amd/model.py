@@ -1113,6 +1113,8 @@ class SegModel:
         self.adam_t = 0
         self.lr, self.beta_1, self.beta_2, self.epsilon = 2e-4, 0.9, 0.999, 1e-7
         self.loss_name = "mse"
+        self.loss_weights = None       # per-output loss weights (compile); None = unit weights
+        self._label_flag = None
         self.world_size = 1
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
@@ -1185,13 +1187,29 @@ class SegModel:
         step.graph = graph
         return step
 
-    def compile(self, loss="mse", optimizer="Adam", lr=2e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, metrics=None):
-        """model.compile(...) (2DCNN/Train.py:322-325).  Losses: 'mse' | 'bce' | 'cce' (mean reduction, applied to every
-        output and summed with unit weights); optimiser: Keras Adam."""
+    def compile(self, loss="mse", optimizer="Adam", lr=2e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, metrics=None, loss_weights=None):
+        """model.compile(...) (2DCNN/Train.py:322-325).  loss: any of the 16 names `TFLosses` takes
+        (utils/tf_losses.py:9-39, e.g. 'MeanSquaredLogarithmicError', the Train_Configs.ini default) or its short form
+        ('mse', 'bce', 'cce', 'mae', 'msle', ...: _ffi.LOSS); mean reduction, applied to every output and summed with
+        loss_weights (a list in output order or {output name: weight}; default: unit weights as in Train.py:322 - the 1D
+        notebook passes 1 - 0.1 k).  Optimiser: Keras Adam."""
         if loss not in LOSS:
-            raise ValueError(f"loss must be one of {sorted(LOSS)}")
+            raise ValueError("Please select a valid loss function. Check for spelling mistakes, capital/small letters, etc.")
         if str(optimizer).lower() != "adam":
             raise NotImplementedError("only the Adam optimiser is on the hot path (SURVEY.md f3)")
+        names = self.output_names
+        if loss_weights is None:
+            lw = [1.0] * len(names)
+        elif isinstance(loss_weights, dict):
+            unknown = [k for k in loss_weights if k not in names]
+            if unknown:
+                raise ValueError(f"loss_weights for unknown output(s) {unknown}; the outputs are {names}")
+            lw = [float(loss_weights.get(n, 1.0)) for n in names]
+        else:
+            lw = [float(w) for w in loss_weights]
+            if len(lw) != len(names):
+                raise ValueError(f"{len(lw)} loss_weights for {len(names)} outputs")
+        self.loss_weights = lw
         self.loss_name, self.lr, self.beta_1, self.beta_2, self.epsilon = loss, lr, beta_1, beta_2, epsilon
 
     # ---------------------------------------------------------------- build / lowering
@@ -1597,16 +1615,25 @@ class SegModel:
             torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def compute_loss(self, targets: Sequence[torch.Tensor], loss: Optional[str] = None) -> torch.Tensor:
-        """Sum over outputs of the mean-reduced loss (unit weights, 2DCNN/Train.py:322); fills the heads' dy buffers."""
+        """Sum over outputs of weight x mean-reduced loss (unit weights unless compile(loss_weights=...), 2DCNN/Train.py:322);
+        fills the heads' dy buffers.  'sparse_cce' takes one class index per pixel as its target."""
         kind = LOSS[loss or self.loss_name]
+        weights = self.loss_weights or [1.0] * len(self.out_heads)
         self.loss_buf.zero_()
         s = _stream()
-        for h, t in zip(self.out_heads, targets):
+        for h, t, w in zip(self.out_heads, targets, weights):
             t = t.to(device=_dev(), dtype=torch.float32).contiguous()
-            if t.numel() != h.y.numel():
-                raise ValueError(f"target for {h.node.name}: {tuple(t.shape)} vs output {tuple(h.y.shape)}")
             npix = h.y.numel() // h.cout
-            call("seg_loss_fwd_bwd", kind, _p(h.y), _p(t), npix, h.cout, _p(self.loss_buf), _p(h.dy), s)
+            if t.numel() != (npix if kind == LOSS["sparse_cce"] else h.y.numel()):
+                raise ValueError(f"target for {h.node.name}: {tuple(t.shape)} vs output {tuple(h.y.shape)}")
+            flag = None
+            if kind in (LOSS["hinge"], LOSS["squared_hinge"]):       # Keras reads {0,1} labels as {-1,+1} iff ALL of them are 0/1
+                if self._label_flag is None:
+                    self._label_flag = torch.ones(1, dtype=torch.int32, device=_dev())
+                flag = self._label_flag
+                call("seg_labels_binary", _p(t), t.numel(), _p(flag), s)
+            call("seg_loss_fwd_bwd_w", kind, _p(h.y), _p(t), npix, h.cout, float(w), _p(flag) if flag is not None else None,
+                 _p(self.loss_buf), _p(h.dy), s)
         return self.loss_buf
 
     def optimizer_step(self):
