@@ -240,7 +240,7 @@ int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int
                  int64_t work_elems, seg_stream_t stream);
 
 /* ---- losses used by the training harness (2DCNN/Train.py:322, utils/tf_losses.py:4-44): mean reduction.
- * loss_out[0] += loss ; dpred = d loss / d pred                                                               */
+ * loss_out[0] += loss ; dpred = d loss / d pred  (dpred may be NULL: value only)                                 */
 int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C,
                      float* loss_out, float* dpred, seg_stream_t stream);
 /* The same with a loss weight (model.compile(loss_weights=...), 1D notebook cell 35): loss_out[0] += weight * loss,
@@ -250,6 +250,14 @@ int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64
 int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float weight,
                        const int32_t* binary_flag, float* loss_out, float* dpred, seg_stream_t stream);
 int seg_labels_binary(const float* target, int64_t n, int32_t* flag, seg_stream_t stream);
+/* ---- metrics of utils/tf_metrics.py: the mean-type ones are seg_loss_fwd_bwd_w with dpred = NULL (value only).
+ * counts[0..3] += TP, FP, FN, TN with "pred > threshold" (BinaryAccuracy, Precision, Recall, TruePositives ...),
+ * counts[4..7] += the same with "pred >= threshold" (BinaryIoU); a label is positive when > 0.5.               */
+int seg_binary_counts(const float* pred, const float* target, int64_t n, float threshold, uint64_t* counts,
+                      seg_stream_t stream);
+/* counts[0] += pixels whose arg-max channel agrees (CategoricalAccuracy; sparse_target: one class index per pixel) */
+int seg_argmax_match(const float* pred, const float* target, int64_t npix, int32_t C, int32_t sparse_target,
+                     uint64_t* counts, seg_stream_t stream);
 /* amax[0] = max(amax[0], max |x|)  (amax must be zeroed by the caller)                                         */
 int seg_absmax(const float* x, int64_t n, float* amax, seg_stream_t stream);
 /* gs[0] = 2^k with amax*2^k in [target/2, target), gs[1] = 1/gs[0]  (gs[0] = 1 when amax is 0 or not finite)   */

@@ -206,3 +206,71 @@ def test_predict_any_sample_count_and_folder_loop(tmp_path):
     assert r["cm"].sum() == 6 * 32 * 32 and len(r["dice"]) == 6
     assert sorted(p.name for p in (tmp_path / "pred").iterdir()) == sorted(r["names"])
     assert set(np.unique(np.asarray(Image.open(tmp_path / "pred" / "0.png")))) <= {0, 255}
+
+
+def test_compiled_metrics_are_logged_under_keras_names():
+    """compile(metrics=[names of utils/tf_metrics.py]) -> fit logs them like Keras does; the validation values equal
+    numpy on predict() (inference-mode BN); the callbacks can monitor them (Train_Configs.ini: val_mean_squared_error)."""
+    b = segamd.unet_model_builder("UNet", 32, 32, 16, 3, ds=0, num_channels=3, train_mode="from_scratch", final_activation="sigmoid")
+    m = b.ResNet50()
+    m.build(4)
+    names = ["MeanSquaredError", "RootMeanSquaredError", "MeanAbsoluteError", "BinaryCrossentropy", "BinaryAccuracy", "BinaryIoU",
+             "Precision", "Recall", "TruePositives", "tf.keras.metrics.FalseNegatives"]
+    m.compile(loss="MeanSquaredLogarithmicError", lr=2e-3, metrics=names)
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.rand((4, 32, 32, 3), generator=g) for _ in range(3)]
+    data = [(x, (x[..., :1] > 0.5).float()) for x in xs]
+    rl = H.ReduceLROnPlateau("val_mean_squared_error", factor=0.5, patience=1, mode="min")
+    es = H.EarlyStopping("val_mean_squared_error", patience=50, mode="min")
+    hist = H.fit(m, data[:2], 3, val_batches=data[2:], callbacks=[es, rl])
+    keys = {"loss", "val_loss"}
+    for k in ("mean_squared_error", "root_mean_squared_error", "mean_absolute_error", "binary_crossentropy", "binary_accuracy",
+              "binary_io_u", "precision", "recall", "true_positives", "false_negatives"):
+        keys |= {k, "val_" + k}
+    assert set(hist) == keys | {"lr"} and all(len(v) == 3 and np.isfinite(v).all() for v in hist.values())   # ReduceLROnPlateau logs lr
+    p = m.predict(xs[2]).astype(np.float64)
+    t = data[2][1].numpy().astype(np.float64)
+    last = {k: v[-1] for k, v in hist.items()}
+    assert last["val_mean_squared_error"] == pytest.approx(((p - t) ** 2).mean(), rel=1e-5)
+    assert last["val_root_mean_squared_error"] == pytest.approx(np.sqrt(((p - t) ** 2).mean()), rel=1e-5)
+    assert last["val_mean_absolute_error"] == pytest.approx(np.abs(p - t).mean(), rel=1e-5)
+    pc = np.clip(p, 1e-7, 1 - 1e-7)
+    assert last["val_binary_crossentropy"] == pytest.approx(-(t * np.log(pc) + (1 - t) * np.log(1 - pc)).mean(), rel=1e-4)
+    hard = p > 0.5
+    tp, fp, fn, tn = (hard & (t == 1)).sum(), (hard & (t == 0)).sum(), (~hard & (t == 1)).sum(), (~hard & (t == 0)).sum()
+    assert last["val_true_positives"] == tp and last["val_false_negatives"] == fn
+    assert last["val_binary_accuracy"] == pytest.approx((tp + tn) / t.size)
+    assert last["val_precision"] == pytest.approx(tp / max(tp + fp, 1)) and last["val_recall"] == pytest.approx(tp / max(tp + fn, 1))
+    iou = np.mean([v for v, d in ((tn / max(tn + fn + fp, 1), tn + fn + fp), (tp / max(tp + fn + fp, 1), tp + fn + fp)) if d])
+    assert last["val_binary_io_u"] == pytest.approx(iou)
+    assert last["val_loss"] == pytest.approx(((np.log1p(np.maximum(p, 1e-7)) - np.log1p(np.maximum(t, 1e-7))) ** 2).mean(), rel=1e-4)
+    with pytest.raises(ValueError):
+        m.compile(loss="mse", metrics=["AUC"])
+
+
+def test_categorical_metrics_and_multi_output_prefixes():
+    b = segamd.unet_model_builder("UNet", 32, 32, 16, 2, ds=0, num_channels=3, output_nums=3, train_mode="from_scratch",
+                                  final_activation="softmax")
+    m = b.ResNet50()
+    m.build(2)
+    m.compile(loss="CategoricalCrossentropy", lr=1e-3, metrics=["CategoricalAccuracy", "CategoricalCrossentropy"])
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((2, 32, 32, 3), generator=g)
+    t = torch.nn.functional.one_hot(torch.randint(0, 3, (2, 32, 32), generator=g), 3).float()
+    logs = H.evaluate(m, [(x, t)], return_dict=True)
+    p = m.predict(x)
+    assert set(logs) == {"loss", "categorical_accuracy", "categorical_crossentropy"}
+    assert logs["categorical_accuracy"] == pytest.approx((p.argmax(-1) == t.numpy().argmax(-1)).mean())
+    q = np.clip(p / p.sum(-1, keepdims=True), 1e-7, 1 - 1e-7)
+    cce = -(t.numpy() * np.log(q)).sum(-1).mean()
+    assert logs["categorical_crossentropy"] == pytest.approx(cce, rel=1e-4) and logs["loss"] == pytest.approx(cce, rel=1e-4)
+    # several outputs: Keras prefixes every metric with the output's name
+    m2 = build(loss="mse")
+    m2.compile(loss="mse", lr=1e-3, metrics=["MeanSquaredError"], loss_weights=[1.0, 0.9, 0.8, 0.7])
+    x2 = torch.rand((4, 32, 32, 3), generator=g)
+    t2 = (x2[..., :1] > 0.5).float()
+    logs2 = H.evaluate(m2, [(x2, [t2] * 4)], return_dict=True)
+    assert set(logs2) == {"loss"} | {f"{o}_mean_squared_error" for o in m2.output_names}
+    per = [float(((pp - t2.numpy()) ** 2).mean()) for pp in m2.predict(x2)]
+    assert [logs2[f"{o}_mean_squared_error"] for o in m2.output_names] == pytest.approx(per, rel=1e-5)
+    assert logs2["loss"] == pytest.approx(sum(w * v for w, v in zip([1.0, 0.9, 0.8, 0.7], per)), rel=1e-5)

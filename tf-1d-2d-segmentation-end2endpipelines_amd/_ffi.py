@@ -90,6 +90,8 @@ _PROTOS = {
     "seg_loss_fwd_bwd": ([i32, vp, vp, i64, i32, vp, vp, vp], C.c_int),
     "seg_loss_fwd_bwd_w": ([i32, vp, vp, i64, i32, C.c_float, vp, vp, vp, vp], C.c_int),
     "seg_labels_binary": ([vp, i64, vp, vp], C.c_int),
+    "seg_binary_counts": ([vp, vp, i64, C.c_float, vp, vp], C.c_int),
+    "seg_argmax_match": ([vp, vp, i64, i32, i32, vp, vp], C.c_int),
     "seg_absmax": ([vp, i64, vp, vp], C.c_int),
     "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),
     "seg_adam_step": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp], C.c_int),

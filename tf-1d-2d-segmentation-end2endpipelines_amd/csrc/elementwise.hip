@@ -1165,7 +1165,9 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
   if (loss_per_pixel(kind)) {
     for (int64_t pix = (int64_t)blockIdx.x * TPB + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * TPB) {
       const float* p = pred + pix * C;
-      float* d = dpred + pix * C;
+      float scratch[1];
+      float* d = dpred ? dpred + pix * C : scratch;
+      const int ds = dpred ? 1 : 0;          // metric evaluation (dpred == NULL): every gradient store lands in scratch[0]
       if (kind == SEG_LOSS_CCE) {
         const float* t = target + pix * C;
         float s = 0.f;
@@ -1182,7 +1184,7 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
         for (int k = 0; k < C; ++k) {
           const float q = p[k] * invs;
           const float m = (q > EPS && q < 1.f - EPS) ? 1.f : 0.f;
-          d[k] = ((m > 0.f ? -t[k] / p[k] : 0.f) + corr * invs) * gw;
+          d[k * ds] = ((m > 0.f ? -t[k] / p[k] : 0.f) + corr * invs) * gw;
         }
       } else if (kind == SEG_LOSS_SPARSE_CCE) {
         // target: one class index per pixel.  q = clip(p, eps, 1 - eps); L = -log(q_c / sum q)  (the clipped
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
         if (valid) local += logf(s) - logf(qc);
         for (int k = 0; k < C; ++k) {
           const float m = (p[k] > EPS && p[k] < 1.f - EPS) ? 1.f : 0.f;
-          d[k] = valid ? m * (1.f / s - (k == c ? 1.f / qc : 0.f)) * gw : 0.f;
+          d[k * ds] = valid ? m * (1.f / s - (k == c ? 1.f / qc : 0.f)) * gw : 0.f;
         }
       } else if (kind == SEG_LOSS_KLD) {
         // sum_k tc_k log(tc_k / pc_k), both clipped to [eps, 1]
@@ -1203,7 +1205,7 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
         for (int k = 0; k < C; ++k) {
           const float tc = fminf(fmaxf(t[k], EPS), 1.f), pc = fminf(fmaxf(p[k], EPS), 1.f);
           local += tc * logf(tc / pc);
-          d[k] = (p[k] >= EPS && p[k] <= 1.f) ? -tc / pc * gw : 0.f;
+          d[k * ds] = (p[k] >= EPS && p[k] <= 1.f) ? -tc / pc * gw : 0.f;
         }
       } else if (kind == SEG_LOSS_CATHINGE) {
         // max(0, max_k((1 - t_k) p_k) - sum_k t_k p_k + 1)
@@ -1217,7 +1219,7 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
         }
         const float l = neg - pos + 1.f;
         if (l > 0.f) local += l;
-        for (int k = 0; k < C; ++k) d[k] = l > 0.f ? (-t[k] + (k == arg ? 1.f - t[k] : 0.f)) * gw : 0.f;
+        for (int k = 0; k < C; ++k) d[k * ds] = l > 0.f ? (-t[k] + (k == arg ? 1.f - t[k] : 0.f)) * gw : 0.f;
       } else {   // SEG_LOSS_COSINE: -sum_k l2n(t)_k l2n(p)_k, l2n(x) = x rsqrt(max(sum x^2, 1e-12))
         const float* t = target + pix * C;
         float pp = 0.f, tt = 0.f, pt = 0.f;
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
         local -= pt * rp * rt;
         // d/dp_j of (p.v) rp, v = t rt: v_j rp - (p.v) p_j rp^3 when sum p^2 is above the floor, else v_j rp
         const float cub = pp > 1e-12f ? pt * rt * rp * rp * rp : 0.f;
-        for (int k = 0; k < C; ++k) d[k] = -(t[k] * rt * rp - cub * p[k]) * gw;
+        for (int k = 0; k < C; ++k) d[k * ds] = -(t[k] * rt * rp - cub * p[k]) * gw;
       }
     }
   } else {
@@ -1235,7 +1237,7 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
       float g;
       local += loss_elem(kind, pred[i], target[i], pm1, g);
-      dpred[i] = g * gw;
+      if (dpred) dpred[i] = g * gw;
     }
   }
   local = wave_sum(local);
@@ -1247,6 +1249,45 @@ __global__ __launch_bounds__(TPB) void loss_kernel(int kind, const float* pred, 
     for (int k = 0; k < TPB / 64; ++k) s += sm[k];
     atomicAdd(loss_out, s * gw);
   }
+}
+
+// counts[0..3] += TP, FP, FN, TN with "pred > thr" (Keras BinaryAccuracy / Precision / Recall / TruePositives ...),
+// counts[4..7] += the same with "pred >= thr" (Keras BinaryIoU); a label counts as positive when it is > 0.5
+__global__ __launch_bounds__(TPB) void binary_counts_kernel(const float* pred, const float* target, int64_t n, float thr,
+                                                            unsigned long long* counts) {
+  unsigned c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float p = pred[i];
+    const bool t = target[i] > 0.5f;
+    const bool a = p > thr, b = p >= thr;
+    c[0] += (a && t);  c[1] += (a && !t);  c[2] += (!a && t);  c[3] += (!a && !t);      // TP FP FN TN
+    c[4] += (b && t);  c[5] += (b && !t);  c[6] += (!b && t);  c[7] += (!b && !t);
+  }
+  __shared__ unsigned sm[8];
+  if (threadIdx.x < 8) sm[threadIdx.x] = 0;
+  __syncthreads();
+  for (int k = 0; k < 8; ++k) {
+    unsigned v = c[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sm[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && sm[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)sm[threadIdx.x]);
+}
+
+// counts[0] += pixels whose arg-max channel of pred equals that of target (first maximum wins, as tf.argmax)
+__global__ __launch_bounds__(TPB) void argmax_match_kernel(const float* pred, const float* target, int64_t npix, int C, int sparse,
+                                                           unsigned long long* counts) {
+  unsigned c = 0;
+  for (int64_t pix = (int64_t)blockIdx.x * TPB + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * TPB) {
+    int ap = 0, at = 0;
+    for (int k = 1; k < C; ++k) if (pred[pix * C + k] > pred[pix * C + ap]) ap = k;
+    if (sparse) at = (int)target[pix];
+    else for (int k = 1; k < C; ++k) if (target[pix * C + k] > target[pix * C + at]) at = k;
+    c += (ap == at) ? 1u : 0u;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[0], (unsigned long long)c);
 }
 
 // flag[0] &= every label is 0 or 1  (flag preset to 1 by the launcher's first kernel)
@@ -1736,7 +1777,7 @@ extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, 
 
 extern "C" int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float weight,
                                   const int32_t* binary_flag, float* loss_out, float* dpred, seg_stream_t stream) {
-  SEG_CHECK_ARG(pred && target && loss_out && dpred && npix > 0 && C >= 1 && kind >= SEG_LOSS_MSE && kind <= SEG_LOSS_SPARSE_CCE,
+  SEG_CHECK_ARG(pred && target && loss_out && npix > 0 && C >= 1 && kind >= SEG_LOSS_MSE && kind <= SEG_LOSS_SPARSE_CCE,
                 "seg_loss_fwd_bwd: bad arguments");
   const bool pp = kind == SEG_LOSS_CCE || kind == SEG_LOSS_KLD || kind == SEG_LOSS_CATHINGE || kind == SEG_LOSS_COSINE || kind == SEG_LOSS_SPARSE_CCE;
   const double n = pp ? (double)npix : (double)npix * C;
@@ -1752,6 +1793,26 @@ extern "C" int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* 
 extern "C" int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float* loss_out, float* dpred,
                                 seg_stream_t stream) {
   return seg_loss_fwd_bwd_w(kind, pred, target, npix, C, 1.f, nullptr, loss_out, dpred, stream);
+}
+
+extern "C" int seg_binary_counts(const float* pred, const float* target, int64_t n, float threshold, uint64_t* counts, seg_stream_t stream) {
+  SEG_CHECK_ARG(pred && target && counts && n > 0, "seg_binary_counts: bad arguments");
+  int blocks = grid_for(n);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(binary_counts_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), pred, target, n, threshold, (unsigned long long*)counts);
+  SEG_CHECK_LAUNCH("seg_binary_counts");
+  return SEG_OK;
+}
+
+extern "C" int seg_argmax_match(const float* pred, const float* target, int64_t npix, int32_t C, int32_t sparse_target, uint64_t* counts,
+                                seg_stream_t stream) {
+  SEG_CHECK_ARG(pred && target && counts && npix > 0 && C >= 1, "seg_argmax_match: bad arguments");
+  int blocks = grid_for(npix);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(argmax_match_kernel, dim3(blocks), dim3(TPB), 0, ST(stream), pred, target, npix, C, sparse_target,
+                     (unsigned long long*)counts);
+  SEG_CHECK_LAUNCH("seg_argmax_match");
+  return SEG_OK;
 }
 
 extern "C" int seg_labels_binary(const float* target, int64_t n, int32_t* flag, seg_stream_t stream) {

@@ -126,15 +126,32 @@ def _batches(src):
     return src() if callable(src) else src
 
 
-def evaluate(model, batches: Iterable, loss: Optional[str] = None) -> float:
-    """Mean over batches of the summed per-output loss, inference-mode BN (Keras `evaluate`)."""
+def _metric_set(model):
+    """The device-side accumulator of the metrics the model was compiled with (None: no metrics / a duck-typed model)."""
+    if getattr(model, "metric_names", None) and hasattr(model, "out_heads"):
+        from .metrics import MetricSet
+        return MetricSet(model, model.metric_names)
+    return None
+
+
+def evaluate(model, batches: Iterable, loss: Optional[str] = None, return_dict: bool = False):
+    """Mean over batches of the summed per-output loss, inference-mode BN (Keras `evaluate`); with return_dict the
+    compiled metrics as well ({'loss': ..., '<metric>': ...})."""
     tot, n = 0.0, 0
+    ms = _metric_set(model) if return_dict else None
     for x, targets in _batches(batches):
         x, targets = _as_batch(model, x, targets)
         model.forward(x, training=False)
         tot += float(model.compute_loss(targets, loss).cpu())
+        if ms is not None:
+            ms.update(targets)
         n += 1
-    return tot / max(n, 1)
+    if not return_dict:
+        return tot / max(n, 1)
+    logs = {"loss": tot / max(n, 1)}
+    if ms is not None:
+        logs.update(ms.result())
+    return logs
 
 
 def fit(model, train_batches, epochs: int, val_batches=None,
@@ -145,17 +162,24 @@ def fit(model, train_batches, epochs: int, val_batches=None,
     Returns `history.history`."""
     hist: Dict[str, List[float]] = {}
     state = FitState(model)
+    ms = _metric_set(model)
     for epoch in range(int(epochs)):
         tot, n = 0.0, 0
+        if ms is not None:
+            ms.reset()
         for x, targets in _batches(train_batches):
             x, targets = _as_batch(model, x, targets)
             tot += float(model.train_step(x, targets).cpu())
+            if ms is not None:                  # Keras updates the metrics from the training-mode predictions of the step
+                ms.update(targets)
             n += 1
         if hasattr(train_batches, "on_epoch_end"):
             train_batches.on_epoch_end()
         logs = {"loss": tot / max(n, 1)}
+        if ms is not None:
+            logs.update(ms.result())
         if val_batches is not None:
-            logs["val_loss"] = evaluate(model, val_batches)
+            logs.update({"val_" + k: v for k, v in evaluate(model, val_batches, return_dict=True).items()})
         for cb in callbacks:
             cb.on_epoch_end(epoch, logs, state)
         for k, v in logs.items():

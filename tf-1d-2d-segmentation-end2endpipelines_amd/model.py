@@ -1114,6 +1114,7 @@ class SegModel:
         self.lr, self.beta_1, self.beta_2, self.epsilon = 2e-4, 0.9, 0.999, 1e-7
         self.loss_name = "mse"
         self.loss_weights = None       # per-output loss weights (compile); None = unit weights
+        self.metric_names: List[str] = []   # compile(metrics=[...]): names of utils/tf_metrics.py, evaluated by harness.fit
         self._label_flag = None
         self.world_size = 1
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
@@ -1192,7 +1193,9 @@ class SegModel:
         (utils/tf_losses.py:9-39, e.g. 'MeanSquaredLogarithmicError', the Train_Configs.ini default) or its short form
         ('mse', 'bce', 'cce', 'mae', 'msle', ...: _ffi.LOSS); mean reduction, applied to every output and summed with
         loss_weights (a list in output order or {output name: weight}; default: unit weights as in Train.py:322 - the 1D
-        notebook passes 1 - 0.1 k).  Optimiser: Keras Adam."""
+        notebook passes 1 - 0.1 k).  metrics: names of utils/tf_metrics.py (metrics.py lists the available ones); `fit`
+        logs them under Keras' names (`mean_squared_error`, `val_mean_squared_error`, with several outputs
+        `<output>_...`).  Optimiser: Keras Adam."""
         if loss not in LOSS:
             raise ValueError("Please select a valid loss function. Check for spelling mistakes, capital/small letters, etc.")
         if str(optimizer).lower() != "adam":
@@ -1210,6 +1213,15 @@ class SegModel:
             if len(lw) != len(names):
                 raise ValueError(f"{len(lw)} loss_weights for {len(names)} outputs")
         self.loss_weights = lw
+        if metrics:
+            from .metrics import log_names
+            self.metric_names = [metrics] if isinstance(metrics, str) else list(metrics)
+            try:
+                log_names(self.metric_names, names)
+            except KeyError as e:
+                raise ValueError(f"metric {e.args[0]!r} is not available (see metrics.py)") from None
+        else:
+            self.metric_names = []
         self.loss_name, self.lr, self.beta_1, self.beta_2, self.epsilon = loss, lr, beta_1, beta_2, epsilon
 
     # ---------------------------------------------------------------- build / lowering
