@@ -272,6 +272,25 @@ int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64
  * (the host refreshes *alpha_ptr before each replay)                                                             */
 int seg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const float* alpha_ptr,
                       float b1, float b2, float eps, float gmul, seg_stream_t stream);
+/* The other optimisers of utils/tf_optimizers.py:12-26, Keras (>= 2.11) update rules with the registry's fixed
+ * hyper-parameters; g is multiplied by gmul first, non-finite gradients are skipped, p16 as in seg_adam_step.
+ * s1 / s2: two state buffers of n floats; c: 5 HOST floats computed per step:
+ *   SGD       p -= c0 g                                                     c0 = lr
+ *   RMSPROP   s2 = c1 s2 + (1-c1) g^2 ; p -= c0 g / sqrt(s2 + c2)            c0 = lr, c1 = rho 0.9, c2 = eps
+ *   ADAGRAD   s2 += g^2 ; p -= c0 g / sqrt(s2 + c2)                          c0 = lr, c2 = eps; s2 starts at 0.1
+ *   ADADELTA  s1 = c1 s1 + (1-c1) g^2 ; d = -sqrt(s2+c2) g / sqrt(s1+c2) ;
+ *             s2 = c1 s2 + (1-c1) d^2 ; p += c0 d                            c0 = lr, c1 = rho 0.95, c2 = eps
+ *   ADAMAX    s1 += (g-s1)(1-c1) ; s2 = max(c2 s2, |g|) ; p -= c0 s1/(s2+c3) c0 = lr/(1-b1^t), c1 = b1, c2 = b2, c3 = eps
+ *   NADAM     s1 += 0.1 (g-s1) ; s2 += 0.001 (g^2-s2) ;
+ *             p -= c0 (c1 s1 + c2 g) / (sqrt(s2 c3) + c4)                    c1 = u_{t+1}/(1-prod u_{1..t+1}), c2 = (1-u_t)/(1-prod u_{1..t}),
+ *                                                                           c3 = 1/(1-b2^t), c4 = eps; u_k = 0.9 (1 - 0.5 * 0.96^k)
+ *   FTRL      a = s1 + g^2 ; s2 += g - (sqrt(a)-sqrt(s1))/c0 * p ; s1 = a ;
+ *             p = -s2 / (sqrt(a)/c0)                                        c0 = lr; s1 starts at 0.1 (lr_power -0.5, no l1/l2)   */
+enum { SEG_OPT_SGD = 0, SEG_OPT_RMSPROP = 1, SEG_OPT_ADAGRAD = 2, SEG_OPT_ADADELTA = 3, SEG_OPT_ADAMAX = 4, SEG_OPT_NADAM = 5,
+       SEG_OPT_FTRL = 6 };
+int seg_optimizer_step(int32_t kind, float* p, const float* g, float* s1, float* s2, void* p16, int64_t n, const float* c,
+                       float gmul, seg_stream_t stream);
+
 /* fp32 [rows][T][K] -> fp16 [K][T][rows_pad] (the data-gradient operand of the same layer)                     */
 int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                     seg_stream_t stream);

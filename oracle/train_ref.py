@@ -149,6 +149,76 @@ class KerasAdam:
             p.sub_(a * self.m[k] / (self.v[k].sqrt() + self.eps))
 
 
+class KerasOptimizer:
+    """The other seven optimisers `2D/utils/tf_optimizers.py:12-26` can select, with the hyper-parameters fixed there and
+    the update rules of Keras >= 2.11 (keras/optimizers/{sgd,rmsprop,adagrad,adadelta,adamax,nadam,ftrl}.py - third-party,
+    absent here; restated):
+      SGD       w -= lr g
+      RMSprop   v = rho v + (1 - rho) g^2 ; w -= lr g / sqrt(v + eps)                           rho 0.9
+      Adagrad   a += g^2 (a0 = 0.1) ; w -= lr g / sqrt(a + eps)
+      Adadelta  a = rho a + (1 - rho) g^2 ; d = -sqrt(D + eps) g / sqrt(a + eps) ;
+                D = rho D + (1 - rho) d^2 ; w += lr d                                            rho 0.95
+      Adamax    m += (g - m)(1 - b1) ; u = max(b2 u, |g|) ; w -= lr m / ((1 - b1^t)(u + eps))
+      Nadam     u_k = b1 (1 - 0.5 * 0.96^k) ; m += (g - m)(1 - b1) ; v += (g^2 - v)(1 - b2) ;
+                m^ = u_{t+1} m / (1 - prod u_{1..t+1}) + (1 - u_t) g / (1 - prod u_{1..t}) ;
+                w -= lr m^ / (sqrt(v / (1 - b2^t)) + eps)
+      FTRL      (lr_power -0.5, l1 = l2 = shrinkage = beta = 0, a0 = 0.1)  a' = a + g^2 ;
+                z += g - (sqrt(a') - sqrt(a)) / lr * w ; w = -z / (sqrt(a') / lr) ; a = a'"""
+
+    def __init__(self, name: str, params: Dict[str, torch.Tensor], lr=2e-4):
+        if name not in ("SGD", "RMSprop", "Adagrad", "Adadelta", "Adamax", "Nadam", "FTRL"):
+            raise ValueError(name)
+        self.name, self.params, self.lr, self.t = name, params, lr, 0
+        self.eps, self.b1, self.b2 = 1e-7, 0.9, 0.999
+        init1 = 0.1 if name == "FTRL" else 0.0
+        init2 = 0.1 if name == "Adagrad" else 0.0
+        self.s1 = {k: torch.full_like(v, init1) for k, v in params.items()}
+        self.s2 = {k: torch.full_like(v, init2) for k, v in params.items()}
+        self.u_product = 1.0
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor]):
+        self.t += 1
+        t, lr, eps, b1, b2 = self.t, self.lr, self.eps, self.b1, self.b2
+        if self.name == "Nadam":
+            u_t = b1 * (1.0 - 0.5 * 0.96 ** t)
+            u_t1 = b1 * (1.0 - 0.5 * 0.96 ** (t + 1))
+            self.u_product *= u_t
+            prod_t, prod_t1 = self.u_product, self.u_product * u_t1
+        for k, w in self.params.items():
+            g = grads.get(k)
+            if g is None:
+                continue
+            s1, s2 = self.s1[k], self.s2[k]
+            if self.name == "SGD":
+                w.sub_(lr * g)
+            elif self.name == "RMSprop":
+                s2.mul_(0.9).add_(g * g, alpha=0.1)
+                w.sub_(lr * g / torch.sqrt(s2 + eps))
+            elif self.name == "Adagrad":
+                s2.add_(g * g)
+                w.sub_(lr * g / torch.sqrt(s2 + eps))
+            elif self.name == "Adadelta":
+                s1.mul_(0.95).add_(g * g, alpha=0.05)
+                d = -torch.sqrt(s2 + eps) * g / torch.sqrt(s1 + eps)
+                s2.mul_(0.95).add_(d * d, alpha=0.05)
+                w.add_(lr * d)
+            elif self.name == "Adamax":
+                s1.add_((g - s1) * (1 - b1))
+                s2.copy_(torch.maximum(b2 * s2, g.abs()))
+                w.sub_(lr * s1 / ((1 - b1 ** t) * (s2 + eps)))
+            elif self.name == "Nadam":
+                s1.add_((g - s1) * (1 - b1))
+                s2.add_((g * g - s2) * (1 - b2))
+                m_hat = u_t1 * s1 / (1 - prod_t1) + (1 - u_t) * g / (1 - prod_t)
+                w.sub_(lr * m_hat / (torch.sqrt(s2 / (1 - b2 ** t)) + eps))
+            else:   # FTRL
+                a1 = s1 + g * g
+                s2.add_(g - (torch.sqrt(a1) - torch.sqrt(s1)) / lr * w)
+                w.copy_(-s2 / (torch.sqrt(a1) / lr))
+                s1.copy_(a1)
+
+
 def loss_and_grads(layers, forward: Callable[[], List[torch.Tensor]], targets: Sequence[torch.Tensor], loss: str,
                    loss_weights: Sequence[float] = None):
     """One forward+backward.  Returns (total_loss, per-output losses, outputs, grads by parameter name)."""

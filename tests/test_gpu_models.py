@@ -25,7 +25,7 @@ import segamd
 import gpu_util as U
 from oracle.keras_ref import Layers
 from oracle.models_ref import unet2d_forward
-from oracle.train_ref import KerasAdam, loss_and_grads
+from oracle.train_ref import KerasOptimizer, KerasAdam, loss_and_grads
 
 OUT_TOL = 1e-2
 # MultiRes models stack BatchNormalization on BatchNormalization over 5..16-channel tensors; channels whose batch
@@ -176,3 +176,32 @@ def test_registry_loss_with_loss_weights_follows_the_oracle():
         model.compile(loss="mse", loss_weights=[1.0])
     model.compile(loss="mae", loss_weights={"out": 2.0})
     assert model.loss_weights == [2.0, 1.0, 1.0]
+
+
+@pytest.mark.parametrize("name", ["SGD", "RMSprop", "Adagrad", "Adadelta", "Adamax", "Nadam", "FTRL"])
+def test_registry_optimizer_training_follows_the_oracle(name):
+    """compile(optimizer=<a name of utils/tf_optimizers.py>): three steps of the whole model against the oracle with the
+    same optimiser (fp32 mode, so the comparison is about the update rule and its state, not fp16 rounding)."""
+    torch.manual_seed(3)
+    kw = dict(ds=1)
+    model = B("UNetPP", 32, 32, 16, 2, num_channels=3, **kw)
+    model.build(2, dtype="f32")
+    lr = {"Adadelta": 1.0, "SGD": 1e-2, "FTRL": 1e-2}.get(name, 1e-3)
+    model.compile(loss="mse", optimizer=name, lr=lr)
+    x = torch.rand(2, 32, 32, 3)
+    tg = [(torch.rand(2, 32, 32, 1) > 0.5).float()] * 3
+    L = Layers(2, seed=0)
+    L.set_weights(model.get_weights())
+    opt = KerasOptimizer(name, {k: v for k, v in L.params.items() if L.trainable[k]}, lr=lr)
+    fwd = lambda: unet2d_forward(L, x, "UNetPP", 16, 2, **kw)
+    for _ in range(3):
+        gl = float(model.train_step(x, tg).cpu())
+        l, _per, _o, grads = loss_and_grads(L, fwd, tg, "mse")
+        opt.step(grads)
+        assert abs(gl - l) < 2e-3 * max(1.0, abs(l)), (name, gl, l)
+    wg, wr = model.get_weights(), L.get_weights()
+    for k in ("X01/conv/kernel", "enc1/conv/kernel", "out/kernel", "enc1/bn/gamma"):
+        d = np.abs(wg[k] - wr[k]).max()
+        assert d < 2e-3 * max(1.0, np.abs(wr[k]).max()), (name, k, d)
+    with pytest.raises(ValueError):
+        model.compile(loss="mse", optimizer="Lion")

@@ -897,6 +897,40 @@ def test_adam_matches_keras_adam_three_steps():
     assert torch.equal(p16.cpu(), p.cpu().half())
 
 
+@pytest.mark.parametrize("name", ["SGD", "RMSprop", "Adagrad", "Adadelta", "Adamax", "Nadam", "FTRL"])
+def test_registry_optimizers_match_the_oracle_four_steps(name):
+    """seg_optimizer_step driven the way SegModel drives it (per-step host scalars, state initialisation) against the
+    oracle's restatement of the Keras update rules, gradients spanning 7 decades."""
+    import ctypes as C
+    import math
+    n, lr = 10000, 3e-3
+    g0 = torch.Generator().manual_seed(sum(map(ord, name)))
+    p0 = torch.randn(n, generator=g0)
+    params = {"w": p0.clone()}
+    opt = TR.KerasOptimizer(name, params, lr=lr)
+    p = p0.clone().cuda()
+    s1 = torch.full((n,), 0.1 if name == "FTRL" else 0.0, device="cuda")
+    s2 = torch.full((n,), 0.1 if name == "Adagrad" else 0.0, device="cuda")
+    p16 = torch.zeros(n, dtype=torch.float16, device="cuda")
+    prod = 1.0
+    for t in range(1, 5):
+        g = torch.randn(n, generator=g0) * (10.0 ** torch.randint(-6, 1, (n,), generator=g0).float())
+        opt.step({"w": g})
+        c = {"SGD": [lr], "RMSprop": [lr, 0.9, 1e-7], "Adagrad": [lr, 0.0, 1e-7], "Adadelta": [lr, 0.95, 1e-7],
+             "Adamax": [lr / (1 - 0.9 ** t), 0.9, 0.999, 1e-7], "FTRL": [lr]}.get(name)
+        if name == "Nadam":
+            u_t, u_t1 = 0.9 * (1 - 0.5 * 0.96 ** t), 0.9 * (1 - 0.5 * 0.96 ** (t + 1))
+            prod *= u_t
+            c = [lr, u_t1 / (1 - prod * u_t1), (1 - u_t) / (1 - prod), 1 / (1 - 0.999 ** t), 1e-7]
+        cs = (C.c_float * 5)(*(c + [0.0] * (5 - len(c))))
+        gd = (g * 4).cuda()
+        ffi.call("seg_optimizer_step", ffi.OPTIMIZER[name], P(p), P(gd), P(s1), P(s2), P(p16), n, cs, 0.25, stream())
+        torch.cuda.synchronize()
+    ref = params["w"]
+    assert float((p.cpu() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max())), name
+    assert torch.equal(p16.cpu(), p.cpu().half())
+
+
 def test_pack_unpack_input():
     x = torch.rand(3, 5, 7, 3)
     y = torch.zeros((3, 5, 7, 8), dtype=torch.float16, device="cuda")

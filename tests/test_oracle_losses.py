@@ -41,3 +41,31 @@ def test_hinge_labels_converted_only_when_all_binary():
 
 def test_registry_has_the_sixteen_names():
     assert len(T.LOSSES) == 16
+
+
+# one step from w = 1 with g = 0.5 and lr = 0.1, worked by hand from the rules in KerasOptimizer's docstring
+OPT_KNOWN = {
+    "SGD": 0.95,                                        # 1 - 0.1 * 0.5
+    "RMSprop": 1 - 0.05 / (0.025 + 1e-7) ** 0.5,        # v = 0.1 * 0.25
+    "Adagrad": 1 - 0.05 / (0.35 + 1e-7) ** 0.5,         # a = 0.1 + 0.25
+    "Adadelta": 1 - 0.1 * (1e-7 ** 0.5) * 0.5 / (0.0125 + 1e-7) ** 0.5,
+    "Adamax": 1 - 0.1 * 0.05 / (0.1 * (0.5 + 1e-7)),    # m = 0.05, u = 0.5
+    "Nadam": 1 - 0.1 * (0.48528 * 0.05 / (1 - 0.468 * 0.48528) + 0.5) / (0.5 + 1e-7),
+    "FTRL": (0.5 - (0.35 ** 0.5 - 0.1 ** 0.5) / 0.1) / -(0.35 ** 0.5 / 0.1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPT_KNOWN))
+def test_optimizer_first_step_by_hand(name):
+    w = {"w": f([1.0])}
+    T.KerasOptimizer(name, w, lr=0.1).step({"w": f([0.5])})
+    assert float(w["w"]) == pytest.approx(OPT_KNOWN[name], rel=2e-6)
+
+
+def test_nadam_momentum_schedule_product_carries_over_steps():
+    w = {"w": f([1.0])}
+    o = T.KerasOptimizer("Nadam", w, lr=0.1)
+    for _ in range(3):
+        o.step({"w": f([0.5])})
+    u = [0.9 * (1 - 0.5 * 0.96 ** k) for k in (1, 2, 3)]
+    assert o.u_product == pytest.approx(u[0] * u[1] * u[2])

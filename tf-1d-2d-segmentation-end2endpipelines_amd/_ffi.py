@@ -14,6 +14,8 @@ MAX_SEG, MAX_TAPS, MAX_CLS = 8, 16, 4
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "leaky_relu": 2, "sigmoid": 3, "softmax": 4}
 LOSS = {"mse": 0, "bce": 1, "cce": 2, "mae": 3, "mape": 4, "msle": 5, "huber": 6, "logcosh": 7, "poisson": 8, "hinge": 9,
         "squared_hinge": 10, "binary_focal": 11, "kld": 12, "categorical_hinge": 13, "cosine": 14, "sparse_cce": 15}
+# the names `TFOptimizers(name, lr).optimizer()` takes (2DCNN/utils/tf_optimizers.py:10-26); Adam has its own entry points
+OPTIMIZER = {"SGD": 0, "RMSprop": 1, "Adagrad": 2, "Adadelta": 3, "Adamax": 4, "Nadam": 5, "FTRL": 6}
 # the names `TFLosses(name).loss()` takes (2DCNN/utils/tf_losses.py:9-39)
 LOSS_ALIASES = {"MeanSquaredError": "mse", "BinaryCrossentropy": "bce", "CategoricalCrossentropy": "cce",
                 "MeanAbsoluteError": "mae", "MeanAbsolutePercentageError": "mape", "MeanSquaredLogarithmicError": "msle",
@@ -90,6 +92,7 @@ _PROTOS = {
     "seg_loss_fwd_bwd": ([i32, vp, vp, i64, i32, vp, vp, vp], C.c_int),
     "seg_loss_fwd_bwd_w": ([i32, vp, vp, i64, i32, C.c_float, vp, vp, vp, vp], C.c_int),
     "seg_labels_binary": ([vp, i64, vp, vp], C.c_int),
+    "seg_optimizer_step": ([i32, vp, vp, vp, vp, vp, i64, vp, C.c_float, vp], C.c_int),
     "seg_binary_counts": ([vp, vp, i64, C.c_float, vp, vp], C.c_int),
     "seg_argmax_match": ([vp, vp, i64, i32, i32, vp, vp], C.c_int),
     "seg_absmax": ([vp, i64, vp, vp], C.c_int),

@@ -35,7 +35,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from ._ffi import TransposeDesc, ACT, LOSS, Geom, IgemmFwdArgs, IgemmWgradArgs
+from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs
 from .graph import Graph, Node
 
 BN_PARTS_BWD = 1024        # partial rows of the BN / bias backward reductions: 70 -> 51 us per 134 MB tensor against 512 (tools/ew_bench.py EW_PARTS sweep)
@@ -1114,6 +1114,8 @@ class SegModel:
         self.lr, self.beta_1, self.beta_2, self.epsilon = 2e-4, 0.9, 0.999, 1e-7
         self.loss_name = "mse"
         self.loss_weights = None       # per-output loss weights (compile); None = unit weights
+        self.optimizer = "Adam"        # one of utils/tf_optimizers.py's names
+        self._u_product = 1.0          # Nadam: running product of the momentum schedule
         self.metric_names: List[str] = []   # compile(metrics=[...]): names of utils/tf_metrics.py, evaluated by harness.fit
         self._label_flag = None
         self.world_size = 1
@@ -1193,13 +1195,22 @@ class SegModel:
         (utils/tf_losses.py:9-39, e.g. 'MeanSquaredLogarithmicError', the Train_Configs.ini default) or its short form
         ('mse', 'bce', 'cce', 'mae', 'msle', ...: _ffi.LOSS); mean reduction, applied to every output and summed with
         loss_weights (a list in output order or {output name: weight}; default: unit weights as in Train.py:322 - the 1D
-        notebook passes 1 - 0.1 k).  metrics: names of utils/tf_metrics.py (metrics.py lists the available ones); `fit`
+        notebook passes 1 - 0.1 k).  optimizer: 'Adam' | 'Adadelta' | 'Adagrad' | 'Adamax' | 'FTRL' | 'Nadam' | 'RMSprop' |
+        'SGD' with the fixed hyper-parameters of utils/tf_optimizers.py:10-26 (changing it restarts the state).  metrics: names of utils/tf_metrics.py (metrics.py lists the available ones); `fit`
         logs them under Keras' names (`mean_squared_error`, `val_mean_squared_error`, with several outputs
         `<output>_...`).  Optimiser: Keras Adam."""
         if loss not in LOSS:
             raise ValueError("Please select a valid loss function. Check for spelling mistakes, capital/small letters, etc.")
-        if str(optimizer).lower() != "adam":
-            raise NotImplementedError("only the Adam optimiser is on the hot path (SURVEY.md f3)")
+        if optimizer != "Adam" and optimizer not in OPTIMIZER:
+            if str(optimizer).lower() == "adam":
+                optimizer = "Adam"
+            else:
+                raise ValueError("Please select a valid optimizer function. Check for spelling mistakes, capital/small letters, etc.")
+        if optimizer != self.optimizer:
+            self.optimizer = optimizer
+            self.adam_t = 0
+            if self.built:
+                self._init_optimizer_state()
         names = self.output_names
         if loss_weights is None:
             lw = [1.0] * len(names)
@@ -1403,6 +1414,7 @@ class SegModel:
         if self.use_side_stream and not _DryRun.on:
             self.side_stream = torch.cuda.Stream()
         self.built = True
+        self._init_optimizer_state()
         return self
 
     def _build_transpose_table(self):
@@ -1648,16 +1660,56 @@ class SegModel:
                  _p(self.loss_buf), _p(h.dy), s)
         return self.loss_buf
 
+    def _init_optimizer_state(self):
+        """The slot variables as Keras creates them: zeros, except the accumulators of Adagrad and FTRL (0.1)."""
+        st = self.store
+        self._join_side()
+        st.M.zero_()
+        st.V.zero_()
+        if self.optimizer == "Adagrad":
+            st.V.fill_(0.1)
+        elif self.optimizer == "FTRL":
+            st.M.fill_(0.1)
+        self._u_product = 1.0
+
+    def _optimizer_scalars(self):
+        """The five per-step host scalars of seg_optimizer_step (include/seg_hip.h) for step self.adam_t."""
+        t, lr, eps = max(self.adam_t, 1), self.lr, 1e-7
+        o = self.optimizer
+        if o == "RMSprop":
+            c = [lr, 0.9, eps]
+        elif o == "Adadelta":
+            c = [lr, 0.95, eps]
+        elif o == "Adamax":
+            c = [lr / (1.0 - 0.9 ** t), 0.9, 0.999, eps]
+        elif o == "Nadam":
+            u_t = 0.9 * (1.0 - 0.5 * 0.96 ** t)
+            u_t1 = 0.9 * (1.0 - 0.5 * 0.96 ** (t + 1))
+            prod_t = self._u_product * u_t
+            self._u_product = prod_t
+            c = [lr, u_t1 / (1.0 - prod_t * u_t1), (1.0 - u_t) / (1.0 - prod_t), 1.0 / (1.0 - 0.999 ** t), eps]
+        else:                           # SGD, Adagrad, FTRL
+            c = [lr, 0.0, eps]
+        return (C.c_float * 5)(*(c + [0.0] * (5 - len(c))))
+
     def optimizer_step(self):
         st = self.store
         self._enter()
         if not self._graph_mode:          # (a captured step gets its step count / size from graphed_train_step)
             self.adam_t += 1
         a_t = self.lr * math.sqrt(1.0 - self.beta_2 ** max(self.adam_t, 1)) / (1.0 - self.beta_1 ** max(self.adam_t, 1))
+        other = None
+        if self.optimizer != "Adam":
+            if self._graph_mode:
+                raise NotImplementedError("a captured training step supports the Adam optimiser only")
+            other = (OPTIMIZER[self.optimizer], self._optimizer_scalars())
 
         def adam(lo, hi):
             off = lambda t: C.c_void_p(t.data_ptr() + lo * t.element_size())
-            if self._graph_mode:         # the step size comes from device memory (refreshed before every replay)
+            if other is not None:        # the rest of the registry: same slices, same streams, another update rule
+                call("seg_optimizer_step", other[0], off(st.P), off(st.G), off(st.M), off(st.V), off(st.P16) if self.dtype == "f16" else None,
+                     hi - lo, other[1], 1.0 / self.world_size, _stream())
+            elif self._graph_mode:       # the step size comes from device memory (refreshed before every replay)
                 call("seg_adam_step_dev", off(st.P), off(st.G), off(st.M), off(st.V), off(st.P16) if self.dtype == "f16" else None, hi - lo,
                      _p(self._alpha_dev), self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _stream())
             else:
