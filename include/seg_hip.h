@@ -239,6 +239,17 @@ int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int
                  void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work,
                  int64_t work_elems, seg_stream_t stream);
 
+/* ---- output heads with more than 8 channels (unet_variants.py:1106 with a large output_nums): the 1x1 conv runs as an
+ * implicit GEMM (seg_igemm_fwd / _wgrad, logits in the storage type, channel stride cs); these are the fp32 activation
+ * on top.  fwd: y[pix][k] = act(x[pix*cs + k]) (SEG_ACT_NONE / SIGMOID / SOFTMAX);  bwd: dx[pix*cs + k] (+)= gs[0] *
+ * d act / d logit . dy, channels C..cs-1 are written as zeros.                                                      */
+int seg_head_act_fwd(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream);
+int seg_head_act_fwd_f32(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream);
+int seg_head_act_bwd(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr,
+                     void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream);
+int seg_head_act_bwd_f32(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr,
+                         void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream);
+
 /* ---- losses used by the training harness (2DCNN/Train.py:322, utils/tf_losses.py:4-44): mean reduction.
  * loss_out[0] += loss ; dpred = d loss / d pred  (dpred may be NULL: value only)                                 */
 int seg_loss_fwd_bwd(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C,

@@ -73,7 +73,7 @@ def test_model_parity_fp32_mode(name):
     assert U.grad_rel_err(r, floor=1e-3) < 5e-2
 
 
-@pytest.mark.parametrize("name", ["unet_softmax_cce", "unet_w64_bce", "unet1d_softmax_cce", "unetpp_ds_mse"])
+@pytest.mark.parametrize("name", ["unet_softmax_cce", "unet_w64_bce", "unet1d_softmax_cce", "unetpp_ds_mse", "unet_21class_softmax_cce"])
 def test_masks_bit_exact_fp32_mode(name):
     torch.manual_seed(3)
     model, x, targets, loss = CASES[name]()

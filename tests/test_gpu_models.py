@@ -45,6 +45,10 @@ def one_hot(shape, ncls):
 CASES = {
     "unet_softmax_cce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=3, output_nums=4, final_activation="softmax"),
                                  torch.rand(2, 32, 32, 3), [one_hot((2, 32, 32), 4)], "cce"),
+    "unet_21class_softmax_cce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=3, output_nums=21, final_activation="softmax"),
+                                         torch.rand(2, 32, 32, 3), [one_hot((2, 32, 32), 21)], "cce"),
+    "unet_12label_sigmoid_bce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=3, output_nums=12, final_activation="sigmoid"),
+                                         torch.rand(2, 32, 32, 3), [(torch.rand(2, 32, 32, 12) > 0.5).float()], "bce"),
     "unetpp_ds_mse": lambda: (B("UNetPP", 32, 32, 16, 3, num_channels=3, ds=1), torch.rand(2, 32, 32, 3),
                               [(torch.rand(2, 32, 32, 1) > 0.5).float()] * 4, "mse"),
     "unet_convlstm_bce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=1, lstm=1), torch.rand(2, 32, 32, 1),

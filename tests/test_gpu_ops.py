@@ -779,6 +779,35 @@ def test_losses_match_keras_definitions(kind, Cc):
     assert rel(dp.cpu(), pr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("act", ["none", "sigmoid", "softmax"])
+@pytest.mark.parametrize("Cc", [9, 21])
+def test_wide_head_activation_fwd_bwd(Cc, act):
+    """The fp32 activation on GEMM-produced logits (heads with more than 8 channels) and its backward, padding channels
+    of the logits' gradient zeroed, accumulate flag honoured."""
+    npix, cs, gsv = 1500, (Cc + 7) // 8 * 8, 64.0
+    x = torch.randn(npix, Cc) * 3
+    xd = torch.zeros(npix, cs, dtype=torch.float16, device="cuda")
+    xd[:, :Cc] = x.half().cuda()
+    xr = xd[:, :Cc].float().cpu().requires_grad_(True)
+    ref = {"none": xr, "sigmoid": torch.sigmoid(xr), "softmax": torch.softmax(xr, -1)}[act]
+    y = torch.zeros(npix, Cc, device="cuda")
+    ffi.call("seg_head_act_fwd", P(xd), cs, npix, Cc, ffi.ACT[act], P(y), stream())
+    torch.cuda.synchronize()
+    assert float((y.cpu() - ref.detach()).abs().max()) < 2e-6
+    dy = torch.randn(npix, Cc)
+    ref.backward(dy)
+    gs = torch.tensor([gsv, 1 / gsv], device="cuda")
+    dyd = dy.cuda()
+    for accumulate in (0, 1):
+        dx = torch.full((npix, cs), 0.5, dtype=torch.float16, device="cuda")
+        ffi.call("seg_head_act_bwd", P(dyd), P(y), npix, Cc, ffi.ACT[act], P(gs), P(dx), cs, accumulate, stream())
+        torch.cuda.synchronize()
+        want = xr.grad * gsv + (0.5 if accumulate else 0.0)
+        got = dx.float().cpu()
+        assert float((got[:, :Cc] - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
+        assert bool((got[:, Cc:] == (0.5 if accumulate else 0.0)).all())
+
+
 ALL_LOSSES = ["mse", "bce", "cce", "mae", "mape", "msle", "huber", "logcosh", "poisson", "hinge", "squared_hinge", "binary_focal",
               "kld", "categorical_hinge", "cosine", "sparse_cce"]
 

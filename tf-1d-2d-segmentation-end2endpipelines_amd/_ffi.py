@@ -89,6 +89,8 @@ _PROTOS = {
     "seg_convlstm_gate_bwd": ([vp, i32, vp, i32, vp, i64, i32, vp], C.c_int),
     "seg_head_fwd": ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp], C.c_int),
     "seg_head_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i64, vp], C.c_int),
+    "seg_head_act_fwd": ([vp, i32, i64, i32, i32, vp, vp], C.c_int),
+    "seg_head_act_bwd": ([vp, vp, i64, i32, i32, vp, vp, i32, i32, vp], C.c_int),
     "seg_loss_fwd_bwd": ([i32, vp, vp, i64, i32, vp, vp, vp], C.c_int),
     "seg_loss_fwd_bwd_w": ([i32, vp, vp, i64, i32, C.c_float, vp, vp, vp, vp], C.c_int),
     "seg_labels_binary": ([vp, i64, vp, vp], C.c_int),
@@ -110,7 +112,7 @@ _PROTOS = {
 DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
         "seg_add_act_bwd", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
-        "seg_head_fwd", "seg_head_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")
+        "seg_head_fwd", "seg_head_bwd", "seg_head_act_fwd", "seg_head_act_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")
 for _n in DUAL:
     _PROTOS[_n + "_f32"] = _PROTOS[_n]
 

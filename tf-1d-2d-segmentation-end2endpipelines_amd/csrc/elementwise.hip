@@ -1099,6 +1099,46 @@ __global__ __launch_bounds__(TPB) void head_bwd_dw_finalize_kernel(const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wide output heads
+// Heads with more than 8 output channels run their 1x1 conv on the implicit-GEMM path (logits in the storage type);
+// these two kernels are the fp32 activation on top: y = act(logits) and d logits = gs * act'(y) dy (padding channels 0).
+template <typename T>
+__global__ __launch_bounds__(TPB) void head_act_fwd_kernel(const T* x, int cs, int64_t npix, int C, int act, float* y) {
+  for (int64_t pix = (int64_t)blockIdx.x * TPB + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * TPB) {
+    const T* xp = x + pix * cs;
+    float* yp = y + pix * C;
+    if (act == SEG_ACT_SOFTMAX) {
+      float mx = -3.4e38f;
+      for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)xp[k]);
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s += expf((float)xp[k] - mx);
+      const float inv = 1.f / s;
+      for (int k = 0; k < C; ++k) yp[k] = expf((float)xp[k] - mx) * inv;
+    } else {
+      for (int k = 0; k < C; ++k) yp[k] = seg_act((float)xp[k], act, 0.f);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void head_act_bwd_kernel(const float* dy, const float* y, int64_t npix, int C, int act, const float* gs_ptr,
+                                                           T* dx, int cs, int accumulate) {
+  const float gs = gs_ptr ? gs_ptr[0] : 1.f;
+  for (int64_t pix = (int64_t)blockIdx.x * TPB + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * TPB) {
+    const float* dp = dy + pix * C;
+    const float* yp = y + pix * C;
+    T* xp = dx + pix * cs;
+    float dot = 0.f;
+    if (act == SEG_ACT_SOFTMAX)
+      for (int k = 0; k < C; ++k) dot += dp[k] * yp[k];
+    for (int k = 0; k < cs; ++k) {
+      float d = 0.f;
+      if (k < C) d = (act == SEG_ACT_SOFTMAX ? yp[k] * (dp[k] - dot) : dp[k] * seg_act_grad_from_out(yp[k], act, 0.f)) * gs;
+      xp[k] = accumulate ? (T)((float)xp[k] + d) : (T)d;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ losses
 // The 16 names of utils/tf_losses.py:4-44 with the Keras 2.x formulas (keras/losses.py, keras/backend.py; eps = 1e-7).
 // Element-wise kinds average f(pred, target) over every element; per-pixel kinds reduce over the channel axis first and
@@ -1835,6 +1875,27 @@ static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int
 }
 extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<half_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
 extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<float>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
+
+template <typename T>
+static int seg_head_act_fwd_impl(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && npix > 0 && C >= 1 && cs >= C && act >= SEG_ACT_NONE && act <= SEG_ACT_SOFTMAX, "seg_head_act_fwd: bad arguments");
+  hipLaunchKernelGGL((head_act_fwd_kernel<T>), dim3(grid_for(npix)), dim3(TPB), 0, ST(stream), (const T*)x, cs, npix, C, act, y);
+  SEG_CHECK_LAUNCH("seg_head_act_fwd");
+  return SEG_OK;
+}
+extern "C" int seg_head_act_fwd(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) { return seg_head_act_fwd_impl<half_t>(x, cs, npix, C, act, y, stream); }
+extern "C" int seg_head_act_fwd_f32(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) { return seg_head_act_fwd_impl<float>(x, cs, npix, C, act, y, stream); }
+
+template <typename T>
+static int seg_head_act_bwd_impl(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs,
+                                 int32_t accumulate, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && y && dx && npix > 0 && C >= 1 && cs >= C && act >= SEG_ACT_NONE && act <= SEG_ACT_SOFTMAX, "seg_head_act_bwd: bad arguments");
+  hipLaunchKernelGGL((head_act_bwd_kernel<T>), dim3(grid_for(npix)), dim3(TPB), 0, ST(stream), dy, y, npix, C, act, gs_ptr, (T*)dx, cs, accumulate);
+  SEG_CHECK_LAUNCH("seg_head_act_bwd");
+  return SEG_OK;
+}
+extern "C" int seg_head_act_bwd(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream) { return seg_head_act_bwd_impl<half_t>(dy, y, npix, C, act, gs_ptr, dx, cs, accumulate, stream); }
+extern "C" int seg_head_act_bwd_f32(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream) { return seg_head_act_bwd_impl<float>(dy, y, npix, C, act, gs_ptr, dx, cs, accumulate, stream); }
 
 extern "C" int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float weight,
                                   const int32_t* binary_flag, float* loss_out, float* dpred, seg_stream_t stream) {

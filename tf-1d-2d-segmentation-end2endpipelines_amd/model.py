@@ -891,7 +891,7 @@ class HeadOp(Op):
         self.sy, self.sx = sh, sw
         self.cin, self.cout = x.C, node.shape[2]
         if self.cout > 8:
-            raise NotImplementedError("output heads with more than 8 channels are not implemented yet")
+            raise ValueError("HeadOp handles up to 8 output channels; wider heads are lowered as WideHeadOp")
         self.w_ld = x.cs
         self.act = ACT[node.attrs["activation"]]
         Ho, Wo = node.shape[0], node.shape[1]
@@ -925,6 +925,30 @@ class HeadOp(Op):
              self.sy, self.sx, st.ptr(self.wname), self.w_ld, self.cout, self.act,
              _p(self.x.grad) if self.acc is not None else None, self.acc or 0, _p(self.m.gs), st.ptr(self.wname, "G"),
              st.ptr(self.bname, "G"), _p(self.work), self.work.numel(), _stream())
+
+
+class WideHeadOp(HeadOp):
+    """Model output with more than 8 channels: the 1x1 conv is a ConvOp on the implicit-GEMM path (its bias in the GEMM
+    epilogue, its gradients from the GEMM kernels); this op is the fp32 activation on the logits and its backward."""
+
+    def __init__(self, m, node: Node, logits: DevTensor):
+        self.m, self.node, self.x = m, node, logits
+        self.cin = self.cout = node.shape[2]
+        self.act = ACT[node.attrs["activation"]]
+        self.y = torch.zeros((logits.N, logits.H, logits.W, self.cout), dtype=torch.float32, device=_dev())
+        self.dy = torch.zeros_like(self.y)
+
+    def forward(self, training):
+        x = self.x
+        call("seg_head_act_fwd", _p(x.buf), x.cs, x.npix, self.cout, self.act, _p(self.y), _stream())
+
+    def plan_backward(self):
+        self.acc = self.x.claim()
+
+    def backward(self):
+        x = self.x
+        call("seg_head_act_bwd", _p(self.dy), _p(self.y), x.npix, self.cout, self.act, _p(self.m.gs), _p(x.grad), x.cs, self.acc,
+             _stream())
 
 
 class BNOp(Op):
@@ -1313,7 +1337,12 @@ class SegModel:
                 val[i] = segs
             elif k in ("conv", "convT", "convlstm"):
                 if k == "conv" and i in outset and n.attrs["kernel"] == (1, 1):
-                    op = HeadOp(self, n, tensor_of(n.inputs[0]))
+                    if n.shape[2] > 8:       # a wide head: GEMM-shaped, so the conv goes where the other convs go
+                        logits = DevTensor(n.name + ":logits", N, n.shape[0], n.shape[1], n.shape[2])
+                        self.ops.append(ConvOp(self, n, k, segs_of(n.inputs[0]), None, None, 0.0, logits, None, (1, 1), 0))
+                        op = WideHeadOp(self, n, logits)
+                    else:
+                        op = HeadOp(self, n, tensor_of(n.inputs[0]))
                     self.ops.append(op)
                     self.heads.append(op)
                     val[i] = op
