@@ -191,7 +191,7 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False):
     # activation gradients: a ConvOp leaves dL/d(conv output) in its out.grad (in place); other tensors keep dL/d(tensor)
     seen = set()
     for op in model.ops:
-        if isinstance(op, M.ConvOp) and getattr(op, "live", False) and op.kind != "convlstm":
+        if isinstance(op, M.ConvOp) and getattr(op, "live", False) and op.kind != "convlstm" and op.node.name in vals:
             ref = vals[op.node.name].grad
             t = op.out
             if ref is not None and t.grad is not None:

@@ -49,6 +49,10 @@ CASES = {
                                          torch.rand(2, 32, 32, 3), [one_hot((2, 32, 32), 21)], "cce"),
     "unet_12label_sigmoid_bce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=3, output_nums=12, final_activation="sigmoid"),
                                          torch.rand(2, 32, 32, 3), [(torch.rand(2, 32, 32, 12) > 0.5).float()], "bce"),
+    "unet_autoencoder_mse": lambda: (B("UNet", 32, 32, 16, 2, num_channels=3, ae=1, feature_number=24), torch.rand(2, 32, 32, 3),
+                                     [torch.rand(2, 32, 32, 1)], "mse"),
+    "unet1d_autoencoder_mse": lambda: (segamd.UNet1D(128, 2, 1, 16, 3, ds=0, ae=1, feature_number=40).UNet(), torch.rand(4, 128, 1),
+                                       [torch.rand(4, 128, 1)], "mse"),
     "unetpp_ds_mse": lambda: (B("UNetPP", 32, 32, 16, 3, num_channels=3, ds=1), torch.rand(2, 32, 32, 3),
                               [(torch.rand(2, 32, 32, 1) > 0.5).float()] * 4, "mse"),
     "unet_convlstm_bce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=1, lstm=1), torch.rand(2, 32, 32, 1),
@@ -209,3 +213,28 @@ def test_registry_optimizer_training_follows_the_oracle(name):
         assert d < 2e-3 * max(1.0, np.abs(wr[k]).max()), (name, k, d)
     with pytest.raises(ValueError):
         model.compile(loss="mse", optimizer="Lion")
+
+
+@pytest.mark.parametrize("kw", [dict(ae=1, feature_number=24), dict(output_nums=12, final_activation="sigmoid")],
+                         ids=["autoencoder", "wide_head"])
+def test_multi_op_nodes_train_like_the_oracle(kw):
+    """Graph nodes that lower to several ops (Dense bottleneck = reshape + 2 GEMMs + reshape; a wide head = GEMM +
+    activation) over three optimiser steps: their parameters must be updated before the next forward reads them."""
+    torch.manual_seed(2)
+    model = B("UNet", 32, 32, 16, 2, num_channels=3, **kw)
+    model.build(2, dtype="f32")
+    model.compile(loss="mse", lr=1e-3)
+    x = torch.rand(2, 32, 32, 3)
+    tg = [torch.rand(2, 32, 32, kw.get("output_nums", 1))]
+    L = Layers(2, seed=0)
+    L.set_weights(model.get_weights())
+    opt = KerasAdam({k: v for k, v in L.params.items() if L.trainable[k]}, lr=1e-3)
+    fwd = lambda: unet2d_forward(L, x, "UNet", 16, 2, **kw)
+    for _ in range(3):
+        gl = float(model.train_step(x, tg).cpu())
+        l, _per, _o, grads = loss_and_grads(L, fwd, tg, "mse")
+        opt.step(grads)
+        assert abs(gl - l) < 1e-3 * max(1.0, abs(l)), (gl, l)
+    wg, wr = model.get_weights(), L.get_weights()
+    worst = max(float(np.abs(wg[k] - wr[k]).max()) for k in wr if L.trainable.get(k, False))
+    assert worst < 2e-3, worst

@@ -113,7 +113,9 @@ def test_pack_gemm_weight_places_segments():
 
 
 def test_unsupported_layers_say_so():
-    with pytest.raises(NotImplementedError):
-        B("UNet", 32, 32, 8, 2, ae=1, feature_number=16).build(2)
+    m = B("UNet", 32, 32, 8, 2, ae=1, feature_number=16)             # the autoencoder bottleneck lowers to two 1x1-image GEMMs
+    m.build(2)
+    kinds = [type(o).__name__ for o in m.ops]
+    assert kinds.count("ReshapeOp") == 2 and m.store.slots["ae/features/kernel"].spec.shape == (8 * 8 * 32, 16)
     with pytest.raises(NotImplementedError, match="ConvLSTM filters"):
         B("UNet", 32, 32, 8, 2, lstm=1).build(2)

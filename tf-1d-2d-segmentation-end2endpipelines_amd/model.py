@@ -36,7 +36,7 @@ import torch
 
 from . import _ffi
 from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs
-from .graph import Graph, Node
+from .graph import Graph, Node, ParamSpec
 
 BN_PARTS_BWD = 1024        # partial rows of the BN / bias backward reductions: 70 -> 51 us per 134 MB tensor against 512 (tools/ew_bench.py EW_PARTS sweep)
 GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
@@ -951,6 +951,39 @@ class WideHeadOp(HeadOp):
              _stream())
 
 
+class ReshapeOp(Op):
+    """Flatten / Reshape around the Dense pair of the autoencoder bottleneck (1DCNN unet_variants.py:127-133): the
+    H*W*C values of a sample, channels fastest (Keras' Flatten order on NHWC), become the channel axis of a 1x1 image
+    or the other way round.  One element-granular channel copy each way (`seg_copy_channels`); `to_flat` tells which
+    side holds the (N, 1, 1, H*W*C) tensor."""
+
+    def __init__(self, m, x: DevTensor, out: DevTensor, to_flat: bool):
+        self.m, self.x, self.out, self.to_flat = m, x, out, to_flat
+        img, flat = (x, out) if to_flat else (out, x)
+        if flat.cs != img.H * img.W * img.C:
+            raise NotImplementedError(f"{flat.name}: the flattened extent H*W*C = {img.H * img.W * img.C} must be a multiple of 8")
+        self.img, self.flat = img, flat
+
+    def _copy(self, src_is_img: bool, src, dst, accumulate: int):
+        img = self.img
+        if src_is_img:
+            call("seg_copy_channels", _p(src), img.cs, 0, _p(dst), img.C, 0, img.C, img.npix, accumulate, _stream())
+        else:
+            call("seg_copy_channels", _p(src), img.C, 0, _p(dst), img.cs, 0, img.C, img.npix, accumulate, _stream())
+
+    def forward(self, training):
+        self._copy(self.to_flat, self.x.buf, self.out.buf, 0)
+
+    def plan_backward(self):
+        self.live = self.out.gw
+        self.acc = self.x.claim() if (self.live and self.x.needs_grad) else None
+
+    def backward(self):
+        if not self.live or self.acc is None:
+            return
+        self._copy(not self.to_flat, self.out.grad, self.x.grad, self.acc)
+
+
 class BNOp(Op):
     """Stand-alone BatchNormalization (+ activation) on an existing tensor (MultiResBlock / ResPath tails)."""
 
@@ -1315,7 +1348,10 @@ class SegModel:
             nonlocal n_ops_seen, n_train_seen
             if len(self.ops) > n_ops_seen:
                 if self.store.n_train > n_train_seen:
-                    self._op_grad_range[len(self.ops) - 1] = (n_train_seen, self.store.n_train)
+                    # owner = the FIRST op this graph node appended (a node may lower to several ops, e.g. a wide head =
+                    # conv + activation): the forward pass must have these parameters before that op runs, and the backward
+                    # sweep (descending op index) has finished their gradients only after it
+                    self._op_grad_range[n_ops_seen] = (n_train_seen, self.store.n_train)
                 n_ops_seen, n_train_seen = len(self.ops), self.store.n_train
 
         for i in live:
@@ -1379,6 +1415,29 @@ class SegModel:
                 if pool_node is not None:
                     val[pool_node.idx] = pooled
                     done.add(pool_node.idx)
+            elif k == "dense_ae":
+                # Flatten -> Dense(features) -> Dense(H*W*C') -> Reshape: the two Dense layers are 1x1 convs over a 1x1 image
+                # whose channel axis is the flattened sample (GEMM rows = the batch), on the implicit-GEMM path
+                x = self._materialise(val, n.inputs[0])
+                H_, W_, Co = n.shape
+                nin, F_, nout = x.H * x.W * x.C, int(n.attrs["features"]), H_ * W_ * Co
+                flat = DevTensor(n.name + ":flat", N, 1, 1, nin)
+                feat = DevTensor(n.name + ":features", N, 1, 1, F_)
+                expd = DevTensor(n.name + ":expand", N, 1, 1, nout)
+                out = DevTensor(n.name, N, H_, W_, Co)
+                self.ops.append(ReshapeOp(self, x, flat, True))
+                for src, dst, specs, cin, cout_ in ((flat, feat, n.params[0:2], nin, F_), (feat, expd, n.params[2:4], F_, nout)):
+                    k4 = ParamSpec(specs[0].name, (1, 1, cin, cout_), specs[0].init, True, specs[0].fan)
+                    fake = Node(-1, "conv", specs[0].name.rsplit("/", 1)[0], [], (1, 1, cout_),
+                                dict(kernel=(1, 1), strides=(1, 1), activation=None), [k4, specs[1]])
+                    self.ops.append(ConvOp(self, fake, "conv", [(src, cin)], None, None, 0.0, dst, None, (1, 1), 0))
+                    slot = self.store.slots[specs[0].name]                      # the parameter keeps its Dense shape (in, out)
+                    te, fe = slot.to_engine, slot.from_engine
+                    slot.spec = specs[0]
+                    slot.to_engine = lambda kern, te=te, c=cin, o=cout_: te(np.asarray(kern).reshape(1, 1, c, o))
+                    slot.from_engine = lambda f, fe=fe, c=cin, o=cout_: np.asarray(fe(f)).reshape(c, o)
+                self.ops.append(ReshapeOp(self, expd, out, False))
+                val[i] = out
             elif k == "bn":
                 act, alpha, last = None, 0.0, n
                 an = only_consumer(i, "act")
