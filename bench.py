@@ -138,12 +138,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # (more ranks than GPUs - e.g. two gloo ranks on a one-GPU box to exercise the exchange path - share devices)
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     pkg = importlib.import_module(PKG)
     modelmod = importlib.import_module(PKG + ".model")
     dp = importlib.import_module(PKG + ".dp")
     if world > 1 or args.force_exchange:
-        dp.init_process_group_from_env("nccl")
+        os.environ["LOCAL_RANK"] = str(local_rank)
+        dp.init_process_group_from_env(os.environ.get("SEG_DIST_BACKEND", "nccl"))      # "nccl" is RCCL on ROCm
     import torch.distributed as dist
 
     kw, H, W, Cin, bs, loss, desc = WORKLOADS[args.workload]
@@ -185,14 +188,18 @@ def main():
     flop_img = 2.0 * macs * 3 - 2.0 * first_macs          # fwd + dgrad + wgrad, no dgrad into the image
 
     roofline = None
-    if not args.no_profile and rank == 0:
+    if not args.no_profile:
+        # one more step with every launch alone on one stream, timed per kernel on rank 0.  EVERY rank runs it: with
+        # data parallelism the step contains the gradient all-reduces, which all ranks have to enter.
         KP = modelmod.KernelProfile
         KP.records.clear()
-        KP.on = True
-        side, model.side_stream = model.side_stream, None     # per-kernel durations: every launch alone on one stream
+        KP.on = rank == 0
+        side, model.side_stream = model.side_stream, None
         model.train_step(x, targets)
         model.side_stream = side
         KP.on = False
+        torch.cuda.synchronize()
+    if not args.no_profile and rank == 0:
         summ = KP.summary()
         if args.dump_launches:
             rows = [dict(kernel=n, tag=t, flops=f, ms=e0.elapsed_time(e1)) for n, t, f, _b, e0, e1 in KP.records]

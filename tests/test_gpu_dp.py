@@ -1,0 +1,104 @@
+"""GPU: the data-parallel step with real kernels - two ranks (gloo, both on cuda:0: a one-GPU box cannot host two RCCL
+ranks) train on different shards; the result must be what one process gets by averaging the two replicas' gradients by
+hand (per-replica BN statistics, one sum all-reduce, 1/world folded into the optimiser)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "tf-1d-2d-segmentation-end2endpipelines_amd"
+STEPS = 2
+
+
+def _model(pkg):
+    m = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, num_channels=3, train_mode="from_scratch").ResNet50()
+    m.build(2, dtype="f32")                  # fp32 mode: the comparison is about the exchange, not fp16 rounding
+    m.compile(loss="mse", lr=1e-3)
+    return m
+
+
+def _shards():
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.rand((2, 32, 32, 3), generator=g) for _ in range(2)]
+    return xs, [(x[..., :1] > 0.5).float() for x in xs]
+
+
+def _worker(rank, world, port, overlap, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import torch.distributed as dist
+        pkg = importlib.import_module(PKG)
+        dp = importlib.import_module(PKG + ".dp")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        M = importlib.import_module(PKG + ".model")
+        m = _model(pkg)
+        m.set_weights({p.name: M.init_param(p, 100 + rank) for p in m.graph.param_specs()})    # the broadcast has to make the replicas identical
+        d = dp.DataParallel(m, bucket_elems=20000, overlap=overlap)
+        xs, ts = _shards()
+        x, t = xs[rank].cuda(), ts[rank].cuda()
+        losses = [float(d.train_step(x, [t] * len(m.out_heads)).cpu()) for _ in range(STEPS)]
+        m._join_side()
+        torch.cuda.synchronize()
+        q.put((rank, m.store.P.cpu().numpy(), losses, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:      # pragma: no cover
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_equal_hand_averaged_replicas(overlap):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, P, losses, err in res:
+        assert err is None, err
+    assert np.array_equal(res[0][1], res[1][1])                 # the replicas stay bit-identical
+
+    # the same two steps in one process: two replicas, gradients averaged by hand
+    import segamd
+    M = importlib.import_module(PKG + ".model")
+    a, b = _model(segamd), _model(segamd)
+    a.set_weights({p.name: M.init_param(p, 100) for p in a.graph.param_specs()})
+    b.set_weights(a.get_weights())
+    xs, ts = _shards()
+    ref_losses = []
+    for _ in range(STEPS):
+        gs = []
+        for m, x, t in ((a, xs[0], ts[0]), (b, xs[1], ts[1])):
+            m.forward(x.cuda(), training=True)
+            ref_losses.append(float(m.compute_loss([t.cuda()] * len(m.out_heads)).cpu()))
+            m.backward(None)
+            torch.cuda.synchronize()
+            gs.append(m.store.G.clone())
+        for m in (a, b):
+            m.store.G.copy_((gs[0] + gs[1]) * 0.5)
+            m.optimizer_step()
+            m._join_side()
+    torch.cuda.synchronize()
+    want = a.store.P.cpu().numpy()
+    assert np.abs(res[0][1] - want).max() < 1e-6, np.abs(res[0][1] - want).max()
+    assert res[0][2] == pytest.approx(ref_losses[0::2], rel=1e-5) and res[1][2] == pytest.approx(ref_losses[1::2], rel=1e-5)
