@@ -37,6 +37,8 @@ WORKLOADS = {
            "cce", "UNet d5 w64 256x256x3 4-class bs16 (BASELINE.json configs[1])"),
     "C5": (dict(decoder_name="UNet", model_width=64, model_depth=4, lstm=1), 256, 256, 1, 8, "bce",
            "UNet + ConvLSTM skip ('BCDUNet') d4 w64 256x256x1 bs8/GPU (BASELINE.json configs[4])"),
+    "C4": (dict(decoder_name="MultiResUNet", model_width=64, model_depth=5, ag=1, alpha=1.0), 512, 512, 3, 8, "bce",
+           "MultiResUNet alpha 1.0 d5 w64 + attention gates 512x512x3 bs8/GPU (BASELINE.json configs[3])"),
     "tiny": (dict(decoder_name="UNetPP", model_width=16, model_depth=3, ds=1), 64, 64, 3, 4, "mse", "UNet++ d3 w16 64x64 bs4 (plumbing check)"),
 }
 
