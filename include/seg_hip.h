@@ -134,6 +134,10 @@ typedef struct seg_igemm_wgrad_args {
                                     fp32 [2 * splitk][2][n_rows] - row (py * splitk + z), plane 0 = sum, plane 1 = 0,
                                     the layout seg_bn_bwd_finalize reduces (dgamma = NULL, dbeta = the bias gradient).
                                     Must be NULL otherwise.                                                   */
+  int32_t overwrite;             /* variant 2 with splitk == 1 only: dw is known to hold zeros where this call writes (the
+                                    engine clears the gradient buffer once per step), so the single writer of each tile
+                                    stores instead of read-modify-writing - deep layers (8x8 / 16x16 images, 2048-channel
+                                    kernels) are otherwise bound by that epilogue.  0: always accumulate                  */
 } seg_igemm_wgrad_args;
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
 /* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */

@@ -98,8 +98,9 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
     return res, (stats.sum(0).cpu() if stats is not None else None), pad
 
 
-def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None, f32=False, bias_parts=False):
-    """Returns dW in Keras layout (numpy)."""
+def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None, f32=False, bias_parts=False,
+                overwrite=0, prefill=0.0):
+    """Returns dW in Keras layout (numpy).  prefill: what dw holds before the launch (the launch accumulates unless overwrite)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kshape[:2]
     transposed = kind == "convT"
@@ -116,7 +117,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
     T = kh * kw
     g = M.geom_convT(N, H, W, kh, kw, *strides) if transposed else M.geom_conv(N, H, W, kh, kw, *strides)
     dzd = to_dev_nhwc(dz, dt)
-    dw = torch.zeros(n_rows * T * Kpad, dtype=torch.float32, device="cuda")
+    dw = torch.full((n_rows * T * Kpad,), float(prefill), dtype=torch.float32, device="cuda")
     a = ffi.IgemmWgradArgs()
     a.g = g
     a.nseg = len(xs)
@@ -130,6 +131,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
         tm, tn = tile
     a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)
     a.scale, a.scale_ptr, a.variant = 1.0, None, variant
+    a.overwrite = overwrite
     bp = None
     if bias_parts:
         bp = torch.full((2 * a.splitk, 2, n_rows), 1e30, dtype=torch.float32, device="cuda")

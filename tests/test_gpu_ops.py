@@ -402,6 +402,30 @@ def test_wgrad_halo_kernel_matches_autograd(case):
     assert rel(torch.from_numpy(got), kern.grad) < 1e-4
 
 
+@pytest.mark.parametrize("kind", ["conv", "convT"])
+def test_wgrad_halo_overwrite_flag(kind):
+    """splitk == 1 + overwrite: the single writer of a tile stores (whatever dw held is replaced on the tiles written);
+    without the flag, and with splitk > 1 whatever the flag says, the launch accumulates."""
+    xs = [h16(torch.randn(2, 8, 8, 64))]
+    if kind == "conv":
+        kshape = (3, 3, 64, 72)
+        kern = torch.zeros(kshape, requires_grad=True)
+        y = K.conv2d_same(xs[0], kern, None, (1, 1))
+        strides = (1, 1)
+    else:
+        kshape = (4, 4, 72, 64)
+        kern = torch.zeros(kshape, requires_grad=True)
+        y = K.conv2d_transpose_same(xs[0], kern, None, (2, 2))
+        strides = (2, 2)
+    dz = h16(torch.randn_like(y))
+    (y * dz).sum().backward()
+    ref = kern.grad
+    scale = float(ref.abs().max())
+    for sk, ow, pre, want in ((1, 1, 5.0, ref), (1, 0, 5.0, ref + 5.0), (2, 1, 5.0, ref + 5.0), (1, 1, 0.0, ref)):
+        got = torch.from_numpy(U.igemm_wgrad(xs, dz, kshape, kind, strides, 2, sk, None, overwrite=ow, prefill=pre))
+        assert float((got - want).abs().max()) < 2e-4 * scale + 1e-4, (sk, ow, pre)
+
+
 @pytest.mark.parametrize("case", [
     dict(shape=(2, 8, 32), cins=[128], cout=64, sk=2),
     dict(shape=(2, 16, 16), cins=[72], cout=24, sk=1),

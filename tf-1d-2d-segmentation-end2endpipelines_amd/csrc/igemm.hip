@@ -1542,7 +1542,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
         const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
         if (row < p.n_rows) {
           float* d = dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol;
-          if (p.splitk == 1) *d += acc[t][q] * sc_mul;       // this block is the only writer of its tile: no atomic needed
+          if (p.splitk == 1) {       // this block is the only writer of its tile: no atomic needed, and no read either
+            if (p.overwrite) *d = acc[t][q] * sc_mul;          // when the caller vouches that dw holds zeros
+            else *d += acc[t][q] * sc_mul;
+          }
           else atomicAdd(d, acc[t][q] * sc_mul);
         }
       }
@@ -1754,7 +1757,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
         const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
         if (row < p.n_rows) {
           float* d = dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol;
-          if (p.splitk == 1) *d += acc[t][q] * sc_mul;       // this block is the only writer of its tile: no atomic needed
+          if (p.splitk == 1) {       // this block is the only writer of its tile: no atomic needed, and no read either
+            if (p.overwrite) *d = acc[t][q] * sc_mul;          // when the caller vouches that dw holds zeros
+            else *d += acc[t][q] * sc_mul;
+          }
           else atomicAdd(d, acc[t][q] * sc_mul);
         }
       }

@@ -41,6 +41,7 @@ from .graph import Graph, Node, ParamSpec
 BN_PARTS_BWD = 1024        # partial rows of the BN / bias backward reductions: 70 -> 51 us per 134 MB tensor against 512 (tools/ew_bench.py EW_PARTS sweep)
 GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
 WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
+WGRAD_OVERWRITE = os.environ.get("SEG_WGRAD_OVERWRITE", "1") != "0"   # single-writer weight-gradient tiles store into the cleared buffer
 WGRAD_HALO = os.environ.get("SEG_WGRAD_HALO", "1") != "0"      # variant 2 (LDS-DMA halo tiles) for the 3x3 stride-1 layers
 
 
@@ -386,7 +387,8 @@ def wgrad_halo_class_groups(g: Geom) -> int:
     return 2
 
 
-HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "512"))          # resident blocks of the variant-2 kernel: 2 per CU x 256 CUs
+WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
+HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
 
 
 def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1):
@@ -410,7 +412,7 @@ def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0):
     tn = 128 if max(seg_cs) > 64 else 64
     ntb = wgrad_taps_per_block(tm, tn, ntaps, variant)
     tiles = _cdiv(n_rows, tm) * sum(_cdiv(c, tn) for c in seg_cs) * ncls * (ntaps // ntb)
-    splitk = max(1, min(_cdiv(1536, tiles), _cdiv(M, 512)))
+    splitk = max(1, min(_cdiv(WGRAD_BLOCKS, tiles), _cdiv(M, 512)))
     return tm, tn, splitk
 
 
@@ -651,6 +653,9 @@ class ConvOp(Op):
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = variant
+        # the gradient buffer is cleared once per step (backward() / the side stream after the optimiser), and with
+        # splitk == 1 every tile has one writer: it may store instead of read-modify-write
+        wg.overwrite = 1 if (WGRAD_OVERWRITE and variant == 2 and sk == 1) else 0
         # transposed convs on the class-pair kernel: the bias gradient (column sums of dz) comes out of the weight-gradient
         # launch as per-block partial rows instead of a separate pass over dz
         self.bias_from_wgrad = (BIAS_FROM_WGRAD and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
