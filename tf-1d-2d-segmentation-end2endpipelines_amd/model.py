@@ -387,6 +387,7 @@ def wgrad_halo_class_groups(g: Geom) -> int:
     return 2
 
 
+HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
 
@@ -926,10 +927,23 @@ class HeadOp(Op):
         st = self.m.store
         if self.acc == 0 and (self.sy, self.sx) != (1, 1):
             self.x.grad.zero_()
-        call("seg_head_bwd", _p(self.dy), _p(self.y), _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W,
-             self.sy, self.sx, st.ptr(self.wname), self.w_ld, self.cout, self.act,
-             _p(self.x.grad) if self.acc is not None else None, self.acc or 0, _p(self.m.gs), st.ptr(self.wname, "G"),
-             st.ptr(self.bname, "G"), _p(self.work), self.work.numel(), _stream())
+        def launch(dx, dw):
+            call("seg_head_bwd", _p(self.dy), _p(self.y), _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W,
+                 self.sy, self.sx, st.ptr(self.wname), self.w_ld, self.cout, self.act,
+                 (_p(self.x.grad) if self.acc is not None else None) if dx else None, self.acc or 0, _p(self.m.gs),
+                 st.ptr(self.wname, "G") if dw else None, st.ptr(self.bname, "G") if dw else None,
+                 _p(self.work) if dw else None, self.work.numel() if dw else 0, _stream())
+
+        side = self.m.side_stream if HEAD_DW_SIDE else None
+        if side is None:
+            launch(True, True)
+        else:
+            # like the convs' weight gradients: the head's dw / db only feed the optimiser, so they leave the main stream
+            if self.acc is not None:
+                launch(True, False)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                launch(False, True)
 
 
 class WideHeadOp(HeadOp):
