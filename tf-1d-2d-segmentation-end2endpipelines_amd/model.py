@@ -324,7 +324,7 @@ FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
-ADAM_SLICE_ELEMS = 4 << 20
+ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
