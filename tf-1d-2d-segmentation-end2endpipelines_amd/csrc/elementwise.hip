@@ -25,9 +25,10 @@ constexpr int TPB = 256;
 constexpr int MAX_BLOCKS = 4096;     // grid-stride streaming kernels: measured flat from 2048 up, 10-15 % better than 1024 (tools/ew_bench.py)
 
 inline int grid_for(int64_t items) {
+  static const int cap = getenv("SEG_EW_MAX_BLOCKS") ? atoi(getenv("SEG_EW_MAX_BLOCKS")) : MAX_BLOCKS;
   int64_t b = (items + TPB - 1) / TPB;
   if (b < 1) b = 1;
-  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  if (b > cap) b = cap;
   return (int)b;
 }
 inline int pow2ceil(int v) {

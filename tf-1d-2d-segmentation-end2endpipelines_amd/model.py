@@ -38,7 +38,7 @@ from . import _ffi
 from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs
 from .graph import Graph, Node, ParamSpec
 
-BN_PARTS_BWD = 1024        # partial rows of the BN / bias backward reductions: 70 -> 51 us per 134 MB tensor against 512 (tools/ew_bench.py EW_PARTS sweep)
+BN_PARTS_BWD = int(os.environ.get("SEG_BN_PARTS_BWD", "1024"))
 GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
 WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
 WGRAD_OVERWRITE = os.environ.get("SEG_WGRAD_OVERWRITE", "1") != "0"   # single-writer weight-gradient tiles store into the cleared buffer
