@@ -389,6 +389,7 @@ def wgrad_halo_class_groups(g: Geom) -> int:
 
 HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
+HALO_BLOCKS_TC = int(os.environ.get("SEG_HALO_BLOCKS_TC", os.environ.get("SEG_HALO_BLOCKS", "256")))   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
 
 
@@ -398,9 +399,10 @@ def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1):
     tiles = ncls * _cdiv(n_rows, 64) * sum(_cdiv(c, 64) for c in seg_cs)
     npatch = M // 64
     best, best_eff = 1, 0.0
-    for sk in range(1, max(1, min(npatch // 8, _cdiv(2 * HALO_BLOCKS, tiles))) + 1):
+    HB = HALO_BLOCKS_TC if ncls > 1 else HALO_BLOCKS
+    for sk in range(1, max(1, min(npatch // 8, _cdiv(2 * HB, tiles))) + 1):
         blocks = tiles * sk
-        eff = blocks / (_cdiv(blocks, HALO_BLOCKS) * HALO_BLOCKS)
+        eff = blocks / (_cdiv(blocks, HB) * HB)
         if eff > best_eff + 1e-9:
             best, best_eff = sk, eff
     return best
