@@ -69,7 +69,12 @@ def _worker(rank, world, port, q):
         M._DryRun.log.clear()
         m2.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m2.out_heads])
         n_adam = sum(1 for c in M._DryRun.log if c == "seg_adam_step")        # one optimiser launch per exchanged slice (+ padding tail)
-        ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen[:len(bk)] == [(lo, hi) for lo, hi, _ in reversed(bk)] \
+        # hook order: the slices whose exchange would finish before the sweep does go out as they become final (reverse
+        # order); the others are held back and issued after the sweep, most urgent (= forward order) first
+        holds = m2.bucket_holds()
+        want = [(lo, hi) for (lo, hi, _), h in zip(reversed(bk), reversed(holds)) if not h] + \
+               [(lo, hi) for (lo, hi, _), h in zip(bk, holds) if h]
+        ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen[:len(bk)] == want and holds[0] \
             and bool((m2.store.G[:m2.store.n_train] == 3.0).all()) and not d2.pending and len(bk) <= n_adam <= len(bk) + 1
         q.put((rank, ok1, ok2, ok3 and ok4, None))
         dist.destroy_process_group()

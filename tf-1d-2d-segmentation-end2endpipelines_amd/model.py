@@ -324,6 +324,9 @@ FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
+DP_ASYNC = os.environ.get("SEG_DP_ASYNC", "1") != "0"           # data parallel: exchanged slices are awaited + updated on the side stream under the next forward
+DP_URGENT_ELEMS = int(os.environ.get("SEG_DP_URGENT_ELEMS", str(4 << 20)))     # size at which the first (most urgent) gradient slice closes
+DP_BUSBW_GBS = float(os.environ.get("SEG_DP_BUSBW_GBS", "300"))                 # all-reduce bus bandwidth the hold-back estimate assumes
 ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
@@ -1705,12 +1708,41 @@ class SegModel:
         for oi, (a, b) in owners:
             if lo is None:
                 lo, first = a, oi
-            if b - lo >= self.bucket_elems:
+            # the first slice (the encoder's first layers) is what the next forward pass needs first and what the backward
+            # sweep finishes last: with more than one rank it is kept small so that its exchange is short (DP_ASYNC)
+            limit = min(self.bucket_elems, DP_URGENT_ELEMS) if (not out and DP_ASYNC and self.world_size > 1) else self.bucket_elems
+            if b - lo >= limit:
                 out.append((lo, b, first))
                 lo = None
         if lo is not None:
             out.append((lo, owners[-1][1][1], first))
         return out
+
+    def bucket_holds(self) -> List[bool]:
+        """For every slice of grad_buckets(): hold its all-reduce back until the backward sweep has ended?  A collective that
+        cannot finish before the sweep does would still be on the (in-order) RCCL stream when the more urgent slices - the
+        encoder's, needed first by the next forward pass, finished last by this sweep - become ready, and delay them.  Held
+        slices are issued after the sweep in forward order.  Estimate: ring all-reduce time 2 (w-1)/w x bytes / bus bandwidth
+        (SEG_DP_BUSBW_GBS, default 300: xGMI rings are per-link bound), collectives queued one after the other, against the
+        remaining GEMM work of the sweep at 600 TFLOP/s (fwd-shaped data gradient + weight gradient = 4 x MACs)."""
+        bk = self.grad_buckets()
+        w = self.world_size
+        if w <= 1 or not DP_ASYNC:
+            return [False] * len(bk)
+        cost = [4.0 * op.M * op.T * op.Kpad * op.n_rows / 600e12 if isinstance(op, ConvOp) else 0.0 for op in self.ops]
+        remaining = [0.0]
+        for c in cost:
+            remaining.append(remaining[-1] + c)                  # remaining[oi] = cost of the ops the sweep still has to run after op oi
+        holds, busy_until = [False] * len(bk), -1e30             # times relative to the end of the sweep (negative = before it)
+        for j in range(len(bk) - 1, -1, -1):                     # the order in which the sweep completes the slices
+            lo, hi, oi = bk[j]
+            start = max(-remaining[oi], busy_until)              # collectives run one after the other
+            end = start + 2.0 * (w - 1) / w * (hi - lo) * 4 / (DP_BUSBW_GBS * 1e9)
+            if end > 0.0:
+                holds[j] = True
+            else:
+                busy_until = end
+        return holds
 
     def backward(self, grads: Optional[Sequence[torch.Tensor]] = None):
         """Backward pass.  grads[i] = dLoss/d output_i (fp32, same shape as the output); None: use the gradients the
@@ -1731,19 +1763,29 @@ class SegModel:
         self._g_clean = False
         ready = {}
         if self.bucket_hook is not None:
-            for lo, hi, oi in self.grad_buckets():
-                ready.setdefault(oi, []).append((lo, hi))
+            for (lo, hi, oi), hold in zip(self.grad_buckets(), self.bucket_holds()):
+                ready.setdefault(oi, []).append((lo, hi, hold))
+
+        def exchange(lo, hi):
+            if self.side_stream is not None:
+                # the slice holds weight gradients (side stream) and BN / bias gradients (this stream): issue the
+                # exchange from the side stream after it has caught up with this one - this stream never stalls
+                self.side_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side_stream):
+                    self.bucket_hook(lo, hi)
+            else:
+                self.bucket_hook(lo, hi)
+
+        held = []
         for oi in range(len(self.ops) - 1, -1, -1):
             self.ops[oi].backward()
-            for lo, hi in ready.get(oi, ()):
-                if self.side_stream is not None:
-                    # the slice holds weight gradients (side stream) and BN / bias gradients (this stream): issue the
-                    # exchange from the side stream after it has caught up with this one - this stream never stalls
-                    self.side_stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self.side_stream):
-                        self.bucket_hook(lo, hi)
+            for lo, hi, hold in ready.get(oi, ()):
+                if hold:
+                    held.append((lo, hi))          # see bucket_holds(): issued after the sweep, most urgent first
                 else:
-                    self.bucket_hook(lo, hi)
+                    exchange(lo, hi)
+        for lo, hi in sorted(held):
+            exchange(lo, hi)
         if self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
 
@@ -1826,7 +1868,32 @@ class SegModel:
                      self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _stream())
 
         n = st.P.numel()
-        if self.bucket_waits is not None:
+        if self.bucket_waits is not None and DP_ASYNC and self.side_stream is not None and not self._graph_mode:
+            # overlapped data parallel, cross-iteration: the waits for the exchanged slices and their optimiser updates go to
+            # the side stream, in forward order, each followed by an event; the next forward pass starts at once and every op
+            # waits only for the slice holding its own parameters.  The encoder's small first slice is exchanged first after
+            # the sweep (bucket_holds), so the big bottleneck slices travel under the encoder's forward pass.
+            first_of = {lo: oi for lo, _hi, oi in self.grad_buckets()}
+            side = self.side_stream
+            side.wait_stream(torch.cuda.current_stream())
+            events, pos = [], 0
+            with torch.cuda.stream(side):
+                for lo, hi, work in sorted(self.bucket_waits(), key=lambda t: t[0]):
+                    work.wait()                    # stream-side for RCCL: the side stream waits for this collective
+                    if lo > pos:
+                        adam(pos, lo)
+                    adam(lo, hi)
+                    pos = hi
+                    e = torch.cuda.Event()
+                    e.record(side)
+                    events.append((first_of.get(lo, 0), e))
+                if pos < n:                        # alignment padding behind the last parameter
+                    adam(pos, n)
+                    e = torch.cuda.Event()
+                    e.record(side)
+                    events.append((len(self.ops), e))
+            self._param_events = events
+        elif self.bucket_waits is not None:
             # overlapped data parallel: update each slice of the flat buffers as soon as ITS all-reduce has finished (the
             # waits are stream-side), so the optimiser of the decoder's slices runs under the exchange of the encoder's
             done = []
