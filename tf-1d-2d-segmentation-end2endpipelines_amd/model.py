@@ -390,6 +390,7 @@ def wgrad_halo_class_groups(g: Geom) -> int:
     return 2
 
 
+WGRAD_FORK_EARLY = os.environ.get("SEG_WGRAD_FORK_EARLY", "1") != "0"   # side stream forks when dz is final, before the op's data gradients are enqueued
 HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = int(os.environ.get("SEG_HALO_BLOCKS_TC", os.environ.get("SEG_HALO_BLOCKS", "256")))   # the same for the transposed-conv class-pair kernel
@@ -796,6 +797,22 @@ class ConvOp(Op):
                 call("seg_act_bwd", _p(dz), _p(self.out.buf), _p(dz), self.out.npix, self.out.cs, self.cout, ACT[self.act],
                      float(self.alpha), None, 1.0, None, s)
             self._bias_grad(dz, s, gs_inv)
+        self.wg_args.dz = dz.data_ptr()
+        def wgrad(stream):
+            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+            if self.bias_from_wgrad:
+                call("seg_bn_bwd_finalize", _p(self.wg_bpart), self.wg_bias_parts, self.n_rows, self.z.npix, None, st.ptr(self.bname, "G"),
+                     1.0, gs_inv, _p(self.c1), _p(self.c2), stream)
+
+        # the weight gradient is only needed by the optimiser: it runs on a second stream, next to this op's own data
+        # gradients (dz is final here - forking before they are enqueued lets both start at once) and to the HBM-bound
+        # BN / activation backward kernels of the layers that follow
+        side = self.m.side_stream
+        early = side is not None and WGRAD_FORK_EARLY
+        if early:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wgrad(_stream())
         for a, zero_first, fl in self.dg_args:
             for t in zero_first:
                 t.grad.zero_()
@@ -804,19 +821,9 @@ class ConvOp(Op):
         self.dz_ptr = dz.data_ptr()
         for grp in self.gather_launch:
             grp.launch(s)
-        self.wg_args.dz = dz.data_ptr()
-        def wgrad(stream):
-            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
-            if self.bias_from_wgrad:
-                call("seg_bn_bwd_finalize", _p(self.wg_bpart), self.wg_bias_parts, self.n_rows, self.z.npix, None, st.ptr(self.bname, "G"),
-                     1.0, gs_inv, _p(self.c1), _p(self.c2), stream)
-
-        side = self.m.side_stream
         if side is None:
             wgrad(s)
-        else:
-            # the weight gradient is only needed by the optimiser: run it on a second stream so that this MFMA-bound
-            # kernel overlaps the HBM-bound BN / activation backward kernels of the layers that follow
+        elif not early:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 wgrad(_stream())
