@@ -107,3 +107,33 @@ def test_bucket_bounds_cover_exactly():
         bb = dp.bucket_bounds(n, b)
         assert bb[0][0] == 0 and bb[-1][1] == n and all(a[1] == c[0] for a, c in zip(bb, bb[1:]))
         assert all(hi - lo <= b for lo, hi in bb)
+
+
+def test_bucket_holds_follow_the_queue_model():
+    """Host logic of the cross-iteration exchange: which slices wait for the end of the backward sweep (dry run)."""
+    M = importlib.import_module(PKG + ".model")
+    pkg = importlib.import_module(PKG)
+    M._DryRun.on = True
+    try:
+        m = pkg.unet_model_builder("UNetPP", 32, 32, 16, 3, ds=1, train_mode="from_scratch").ResNet50()
+        m.build(2)
+        m.bucket_elems = 20000
+        assert m.bucket_holds() == [False] * len(m.grad_buckets())            # one rank: nothing to hold
+        m.world_size = 8
+        bk = m.grad_buckets()
+        assert len(bk) > 3 and bk[0][0] == 0 and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
+        old = M.DP_BUSBW_GBS
+        try:
+            M.DP_BUSBW_GBS = 1e-6                                               # a link that never finishes in time: all held
+            assert all(m.bucket_holds())
+            M.DP_BUSBW_GBS = 1e12                                               # an infinitely fast link: only slices that complete
+            h = m.bucket_holds()                                               # with the sweep's very last GEMM are held
+            cost_before = [sum(1 for op in m.ops[:oi] if isinstance(op, M.ConvOp)) for _lo, _hi, oi in bk]
+            assert h == [c == 0 for c in cost_before] and h[0]
+            M.DP_BUSBW_GBS = old
+            h = m.bucket_holds()
+            assert h[0] and len(h) == len(bk)                                  # the sweep's last slice can never finish before it ends
+        finally:
+            M.DP_BUSBW_GBS = old
+    finally:
+        M._DryRun.on = False
