@@ -328,6 +328,7 @@ DP_ASYNC = os.environ.get("SEG_DP_ASYNC", "1") != "0"           # data parallel:
 DP_URGENT_ELEMS = int(os.environ.get("SEG_DP_URGENT_ELEMS", str(4 << 20)))     # size at which the first (most urgent) gradient slice closes
 DP_BUSBW_GBS = float(os.environ.get("SEG_DP_BUSBW_GBS", "300"))                 # all-reduce bus bandwidth the hold-back estimate assumes
 ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
+ADAM_URGENT_FIRST = os.environ.get("SEG_ADAM_URGENT_FIRST", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
@@ -1695,7 +1696,10 @@ class SegModel:
             for oi, (a, b) in owners:
                 if lo is None:
                     lo, first = a, oi
-                if b - lo >= ADAM_SLICE_ELEMS:
+                # the first slices are what the next forward pass waits for at the step boundary (the main stream idles
+                # until the first layer's weights are updated): they are kept short - first layer alone, then 256 K elements
+                limit = ADAM_SLICE_ELEMS if (len(out) >= 2 or not ADAM_URGENT_FIRST) else (1 if not out else 1 << 18)
+                if b - lo >= limit:
                     out.append([lo, b, first])
                     lo = None
             if lo is not None:

@@ -1,0 +1,42 @@
+"""Step-boundary analysis of a rocprofv3 kernel trace of bench.py: for every optimiser step, the idle time of the main
+queue between the last backward kernel and the first forward kernel of the next step, and what the side queue ran then.
+
+  rocprofv3 --kernel-trace -d /tmp/tr -o run --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-profile
+  python3 tools/step_gap.py /tmp/tr
+"""
+import csv
+import glob
+import sys
+from collections import Counter
+
+
+def main(d):
+    f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
+    starts = [i for i, r in enumerate(rows) if "pack_input" in r["Kernel_Name"]]
+    qcount = Counter(r["Queue_Id"] for r in rows)
+    main_q = rows[starts[-1]]["Queue_Id"]
+    print("queues:", dict(qcount), "main:", main_q)
+    for a, b in zip(starts[-4:-1], starts[-3:]):
+        step = rows[a:b]
+        t0, t1 = rows[a]["s"], rows[b]["s"]
+        mainq = [r for r in step if r["Queue_Id"] == main_q]
+        side = [r for r in step if r["Queue_Id"] != main_q]
+        busy_main = sum(r["e"] - r["s"] for r in mainq)
+        last_main_end = max(r["e"] for r in mainq)
+        gap = t1 - last_main_end
+        in_gap = [r for r in side if r["e"] > last_main_end]
+        print(f"step {(t1 - t0) / 1e6:.3f} ms: main-queue kernel time {busy_main / 1e6:.3f} ms, idle {((t1 - t0) - busy_main) / 1e6:.3f} ms; "
+              f"end-of-step gap {gap / 1e3:.1f} us with {len(in_gap)} side kernels: "
+              + ", ".join(f"{r['Kernel_Name'][:28]}({(r['e'] - max(r['s'], last_main_end)) / 1e3:.0f}us)" for r in in_gap[:8]))
+        # largest idle intervals of the main queue inside the step
+        gaps = sorted(((mainq[i + 1]["s"] - mainq[i]["e"], mainq[i]["Kernel_Name"][:30], mainq[i + 1]["Kernel_Name"][:30]) for i in range(len(mainq) - 1)),
+                      reverse=True)[:6]
+        print("   largest main-queue gaps (us):", [(round(g / 1e3, 1), x, y) for g, x, y in gaps])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
