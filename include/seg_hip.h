@@ -306,6 +306,23 @@ enum { SEG_OPT_SGD = 0, SEG_OPT_RMSPROP = 1, SEG_OPT_ADAGRAD = 2, SEG_OPT_ADADEL
 int seg_optimizer_step(int32_t kind, float* p, const float* g, float* s1, float* s2, void* p16, int64_t n, const float* c,
                        float gmul, seg_stream_t stream);
 
+/* ---- the forms the engine calls (SegModel.optimizer_step): as above, plus
+ *   g_dtype    SEG_GRAD_F32: g is the fp32 gradient buffer the weight-gradient kernels accumulated into;
+ *              SEG_GRAD_BF16: g is a bf16 slice that came back from the data-parallel all-reduce (dp.py; the sum over the
+ *              ranks, widened to fp32 before the update - state and master weights stay fp32)
+ *   alpha_ptr  (Adam) when not NULL the step size is alpha_t * *alpha_ptr, read on the device (hipGraph replay)
+ *   nonfinite  when not NULL: *nonfinite += number of elements whose gradient was NaN / +-Inf (their update is skipped,
+ *              as in the plain forms - Keras would propagate the NaN; here the count makes the overflow visible and
+ *              harness.fit reacts by halving the fp16 loss scale)                                                       */
+enum { SEG_GRAD_F32 = 0, SEG_GRAD_BF16 = 1 };
+int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float* m, float* v, void* p16, int64_t n, float alpha_t,
+                     const float* alpha_ptr, float b1, float b2, float eps, float gmul, uint32_t* nonfinite, seg_stream_t stream);
+int seg_optimizer_step_ex(int32_t kind, float* p, const void* g, int32_t g_dtype, float* s1, float* s2, void* p16, int64_t n,
+                          const float* c, float gmul, uint32_t* nonfinite, seg_stream_t stream);
+/* y[i] = bf16(x[i]), round to nearest even, NaN / Inf preserved: packs a finished slice of the flat fp32 gradient buffer
+ * for the data-parallel exchange (half the bytes over xGMI).  x 32-byte, y 16-byte aligned.               */
+int seg_cast_f32_bf16(const float* x, void* y, int64_t n, seg_stream_t stream);
+
 /* fp32 [rows][T][K] -> fp16 [K][T][rows_pad] (the data-gradient operand of the same layer)                     */
 int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                     seg_stream_t stream);

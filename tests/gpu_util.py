@@ -155,22 +155,29 @@ def ref_conv(xs, kern, bias, kind, strides):
 
 
 # ------------------------------------------------------------------------------------------------ whole-model compare
-def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False):
-    """Runs forward(training) + loss + backward on the GPU model and on the oracle primitives wired by the same
-    graph (the wiring itself is checked against the independent oracle wiring in test_graph_builders.py).
-    Returns per-node forward errors, loss pair, per-node activation-gradient errors and per-parameter gradient
-    errors (all 'max abs err', with the reference magnitude beside it)."""
-    g = model.graph
-    w_np = model.get_weights()
-    W = {k: torch.from_numpy(v.copy()).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
+def oracle_run(g, w_np, x, targets, loss, emulate_fp16=False):
+    """Forward (training-mode BN) + loss + backward of the oracle primitives wired by graph g.  Returns what
+    compare_model needs; computed once and shared when several engine modes are compared at an expensive size."""
+    W = {k: torch.from_numpy(np.array(v, np.float32)).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
          for k, v in w_np.items()}
     outs_ref, vals = run_graph(g, x, W, training=True, return_all=True, emulate_fp16=emulate_fp16)
     for v in vals.values():
         if v.requires_grad:
             v.retain_grad()
-    lossf = LOSSES[loss]
-    ref_loss = sum(lossf(o, t) for o, t in zip(outs_ref, targets))
+    ref_loss = sum(LOSSES[loss](o, t) for o, t in zip(outs_ref, targets))
     ref_loss.backward()
+    return dict(W=W, outs=outs_ref, vals=vals, loss=ref_loss)
+
+
+def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, oracle=None):
+    """Runs forward(training) + loss + backward on the GPU model and on the oracle primitives wired by the same
+    graph (the wiring itself is checked against the independent oracle wiring in test_graph_builders.py).
+    Returns per-node forward errors, loss pair, per-node activation-gradient errors and per-parameter gradient
+    errors (all 'max abs err', with the reference magnitude beside it)."""
+    g = model.graph
+    if oracle is None:
+        oracle = oracle_run(g, model.get_weights(), x, targets, loss, emulate_fp16)
+    W, outs_ref, vals, ref_loss = oracle["W"], oracle["outs"], oracle["vals"], oracle["loss"]
     outs = model.forward(x, training=True)
     lv = model.compute_loss(targets, loss)
     model.backward(None)
@@ -188,8 +195,11 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False):
             continue
         res["nodes"].append((name, float((got - ref).abs().max()), float(ref.abs().max())))
     for o, r in zip(outs, outs_ref):
-        res["outs"].append(float((o.cpu() - r.detach()).abs().max()))
-        res.setdefault("out_mag", []).append(float(r.detach().abs().max()))
+        oc, rd = o.cpu(), r.detach()
+        res["outs"].append(float((oc - rd).abs().max()))
+        res.setdefault("out_mag", []).append(float(rd.abs().max()))
+        res.setdefault("out_rms", []).append(float((oc - rd).pow(2).mean().sqrt()))
+        res.setdefault("out_tensors", []).append((oc.clone(), rd))
     # activation gradients: a ConvOp leaves dL/d(conv output) in its out.grad (in place); other tensors keep dL/d(tensor)
     seen = set()
     for op in model.ops:

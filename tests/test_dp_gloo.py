@@ -50,11 +50,11 @@ def _worker(rank, world, port, q):
             return None
         m.backward = noop_backward                       # keep the per-rank gradient we planted
         m.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m.out_heads])
-        ok3 = bool((m.store.G == 3.0).all()) and m.world_size == world and "seg_adam_step" in M._DryRun.log
+        ok3 = bool((m.store.G == 3.0).all()) and m.world_size == world and "seg_adam_step_ex" in M._DryRun.log
         # 3. overlapped exchange: the backward sweep hands over op-aligned slices as they become final
         m2 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
         m2.build(2)
-        d2 = dp.DataParallel(m2, bucket_elems=20000, overlap=True)
+        d2 = dp.DataParallel(m2, bucket_elems=20000, overlap=True, grad_dtype="f32")
         bk = m2.grad_buckets()
         tiles = bk[0][0] == 0 and bk[-1][1] == m2.store.n_train and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
         order = [oi for _lo, _hi, oi in bk]
@@ -68,7 +68,7 @@ def _worker(rank, world, port, q):
         m2.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m2.out_heads])
         M._DryRun.log.clear()
         m2.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m2.out_heads])
-        n_adam = sum(1 for c in M._DryRun.log if c == "seg_adam_step")        # one optimiser launch per exchanged slice (+ padding tail)
+        n_adam = sum(1 for c in M._DryRun.log if c == "seg_adam_step_ex")        # one optimiser launch per exchanged slice (+ padding tail)
         # hook order: the slices whose exchange would finish before the sweep does go out as they become final (reverse
         # order); the others are held back and issued after the sweep, most urgent (= forward order) first
         holds = m2.bucket_holds()
@@ -76,7 +76,25 @@ def _worker(rank, world, port, q):
                [(lo, hi) for (lo, hi, _), h in zip(bk, holds) if h]
         ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen[:len(bk)] == want and holds[0] \
             and bool((m2.store.G[:m2.store.n_train] == 3.0).all()) and not d2.pending and len(bk) <= n_adam <= len(bk) + 1
-        q.put((rank, ok1, ok2, ok3 and ok4, None))
+        # 4. the same with bf16 slices (the default with more than one rank): every finished slice is packed, the all-reduce
+        #    runs on the bf16 image, the optimiser reads its gradient from there.  The optimiser state of a model that has
+        #    already taken steps travels with the weights.
+        m3 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
+        m3.build(2)
+        m3.adam_t, m3.lr = (7, 3e-4) if rank == 0 else (0, 1e-3)
+        m3.store.M.fill_(float(rank + 5))
+        d3 = dp.DataParallel(m3, bucket_elems=20000)
+        ok5 = d3.grad_dtype == "bf16" and m3.store.G16 is not None and m3.store.G16.dtype == torch.bfloat16
+        ok5 = ok5 and m3.adam_t == 7 and m3.lr == 3e-4 and bool((m3.store.M == 5.0).all())
+        for op in m3.ops:
+            op.backward = (lambda: None)
+        m3.store.G.zero_ = lambda: None
+        m3.store.G16.fill_(float(rank + 1))               # (dry run: the pack kernel is only recorded)
+        M._DryRun.log.clear()
+        m3.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m3.out_heads])
+        nb = len(m3.grad_buckets())
+        ok5 = ok5 and M._DryRun.log.count("seg_cast_f32_bf16") == nb and bool((m3.store.G16[:m3.store.n_train].float() == 3.0).all())
+        q.put((rank, ok1, ok2, ok3 and ok4 and ok5, None))
         dist.destroy_process_group()
     except Exception as e:      # pragma: no cover
         import traceback

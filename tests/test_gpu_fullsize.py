@@ -1,0 +1,152 @@
+"""GPU parity at the BASELINE configurations' OWN geometry: the five configs of BASELINE.json built with
+their real depth / width / resolution and compared with the oracle (fp32 torch-CPU restatement of the reference)
+through the C ABI.  This exercises what the reduced-size cases of test_gpu_models.py cannot: the kernels' full-size
+selection (halo-tile forward / weight-gradient kernels, 64-deep K ring, split-K), the 8x8 level with 1024-2048
+channels (K = 18 432 fp16 contraction) and the multi-GB activation plan.
+
+  C1  1D UNet d3 w16 L1024 1ch 2-class, bs 8 (exactly the BASELINE batch)
+  C2  UNet d5 w64 256x256x3 4-class softmax, batch 2      C3  UNet++ d5 w64 +DS 256x256x3, batch 2
+  C4  MultiResUNet alpha 1 d5 W=32 + AG 512x512x3, batch 1 C5  UNet + ConvLSTM skip d4 w64 256x256x1, batch 2
+(the oracle costs seconds per image on the host cores, hence the reduced batch; bench.py runs the full batch.)
+
+Asserted per config, with the oracle computed ONCE and shared by both modes:
+  f32 mode  every output within 1e-3 of the oracle (the north star, as written; measured ~1e-6), masks bit-exact,
+            every node within 1e-4 relative, gradients to 5e-3 relative L2 per parameter tensor
+  f16 mode  every output within F16_TOL x max(1, |ref|) (fp16 operand rounding: 2^-12 relative per stored value and
+            weight, accumulating as sqrt(depth) - DESIGN.md section 3), masks identical on every pixel whose margin to
+            the decision boundary exceeds that bound, per-node error of the 8x8 / 16x16 level reported and bounded,
+            gradient direction (cosine) per parameter tensor
+  both      channel padding of every stored tensor exactly zero
+and a 3-step loss decrease at the BASELINE batch in f16 mode (test_three_steps_reduce_the_loss_at_the_baseline_batch)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import segamd
+import gpu_util as U
+from test_gpu_models import masks, margin
+
+NORTH_STAR_TOL = 1e-3
+F16_TOL = {"C1": 4e-3, "C2": 4e-3, "C3": 4e-3, "C5": 4e-3, "C4": 3e-2}     # x max(1, |ref|); C4: ~40 BN-normalised layers in sequence
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_report.json")
+
+
+def B(*a, **k):
+    return segamd.unet_model_builder(*a, train_mode="from_scratch", **k).ResNet50()
+
+
+def one_hot(shape, ncls):
+    return F.one_hot(torch.randint(0, ncls, shape), ncls).float()
+
+
+def bern(*shape):
+    return (torch.rand(*shape) > 0.5).float()
+
+
+CONFIGS = {
+    "C1": lambda n: (segamd.UNet1D(1024, 3, 1, 16, 3, "Classification", output_nums=2, ds=0).UNet(), torch.rand(n, 1024, 1),
+                     [one_hot((n, 1024), 2)], "cce"),
+    "C2": lambda n: (B("UNet", 256, 256, 64, 5, num_channels=3, output_nums=4, final_activation="softmax"), torch.rand(n, 256, 256, 3),
+                     [one_hot((n, 256, 256), 4)], "cce"),
+    "C3": lambda n: (B("UNetPP", 256, 256, 64, 5, num_channels=3, ds=1), torch.rand(n, 256, 256, 3), [bern(n, 256, 256, 1)] * 6, "mse"),
+    "C4": lambda n: (B("MultiResUNet", 512, 512, 32, 5, num_channels=3, ag=1, alpha=1.0), torch.rand(n, 512, 512, 3),
+                     [bern(n, 512, 512, 1)], "bce"),
+    "C5": lambda n: (B("UNet", 256, 256, 64, 4, num_channels=1, lstm=1), torch.rand(n, 256, 256, 1), [bern(n, 256, 256, 1)], "bce"),
+}
+ORACLE_BATCH = {"C1": 8, "C2": 2, "C3": 2, "C4": 1, "C5": 2}
+BASELINE_BATCH = {"C1": 8, "C2": 16, "C3": 16, "C4": 8, "C5": 8}
+
+
+def pads_are_zero(model):
+    for name, t in model.tensors.items():
+        if t.cs > t.C and float(t.buf[..., t.C:].abs().max()) != 0.0:
+            return name
+    return None
+
+
+def _record(cfg, mode, entry):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT):
+        with open(REPORT) as fh:
+            data = json.load(fh)
+    data.setdefault(cfg, {})[mode] = entry
+    with open(REPORT, "w") as fh:
+        json.dump(data, fh, indent=1)
+
+
+@pytest.mark.parametrize("cfg", sorted(CONFIGS))
+def test_baseline_config_at_its_own_size(cfg):
+    torch.manual_seed(11)
+    n = ORACLE_BATCH[cfg]
+    model32, x, targets, loss = CONFIGS[cfg](n)
+    model32.build(n, dtype="f32")
+    w = model32.get_weights()
+    oracle = U.oracle_run(model32.graph, w, x, targets, loss)
+    deep = lambda name: any(name.startswith(p) for p in ("latent", "enc6", "enc5", "X41", "X4", "dec0", "bottleneck"))
+
+    # ---- exact mode: the north star as written
+    r = U.compare_model(model32, x, targets, loss, oracle=oracle)
+    worst_node = max(((e / max(1.0, m)), nm) for nm, e, m in r["nodes"])
+    _record(cfg, "f32", {"out_err": r["outs"], "out_mag": r["out_mag"], "worst_node_rel": worst_node[0], "worst_node": worst_node[1],
+                         "loss": r["loss"]})
+    for e in r["outs"]:
+        assert e < NORTH_STAR_TOL, (cfg, r["outs"])
+    for got, ref in r["out_tensors"]:
+        assert torch.equal(masks(got), masks(ref)), f"{cfg}: masks differ in f32 mode"
+    assert worst_node[0] < 1e-4, worst_node
+    assert abs(r["loss"][0] - r["loss"][1]) < 1e-5 * max(1.0, abs(r["loss"][1]))
+    gn = max(nrm for _e, nrm in r["gl2"].values())
+    for k, (e, nrm) in r["gl2"].items():
+        assert e < 5e-3 * (nrm + 1e-3 * gn), (cfg, k, e, nrm)
+    assert pads_are_zero(model32) is None
+    del model32, r
+    torch.cuda.empty_cache()
+
+    # ---- throughput mode (fp16 MFMA operands) against the SAME fp32 oracle
+    model16, _x, _t, _l = CONFIGS[cfg](n)
+    model16.build(n, dtype="f16")
+    model16.set_weights(w)
+    r = U.compare_model(model16, x, targets, loss, oracle=oracle)
+    tol = F16_TOL[cfg]
+    deep_nodes = [(nm, e, m) for nm, e, m in r["nodes"] if deep(nm)]
+    worst_deep = max(((e / max(1.0, m)), nm) for nm, e, m in (deep_nodes or r["nodes"]))
+    worst_node = max(((e / max(1.0, m)), nm) for nm, e, m in r["nodes"])
+    agree = [float((masks(got) == masks(ref)).float().mean()) for got, ref in r["out_tensors"]]
+    _record(cfg, "f16", {"out_err": r["outs"], "out_rms": r["out_rms"], "out_mag": r["out_mag"], "tol_x_max1ref": tol,
+                         "worst_node_rel": worst_node[0], "worst_node": worst_node[1],
+                         "worst_deep_node_rel": worst_deep[0], "worst_deep_node": worst_deep[1], "mask_agreement": agree, "loss": r["loss"],
+                         "min_grad_cos": min((c for c, _r, mag in r["gcos"].values() if mag >= 1e-3 * r["gmax"]), default=1.0)})
+    for e, m in zip(r["outs"], r["out_mag"]):
+        assert e < tol * max(1.0, m), (cfg, r["outs"], r["out_mag"])
+    for got, ref in r["out_tensors"]:
+        same = masks(got) == masks(ref)
+        assert bool(same[margin(ref) > tol].all()), f"{cfg}: a mask pixel outside the near-tie band differs"
+        assert float(same.float().mean()) >= 0.99
+    assert worst_deep[0] < 10 * tol, worst_deep          # the 8x8 / 16x16 level (K up to 18 432) stays in line with the rest
+    for k, (cos, ratio, mag) in r["gcos"].items():
+        if mag < 1e-3 * r["gmax"]:
+            continue
+        assert cos > (0.90 if cfg != "C4" else 0.70), (cfg, k, cos)
+    assert pads_are_zero(model16) is None
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C3", "C5", "C4"])
+def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg):
+    torch.manual_seed(5)
+    n = BASELINE_BATCH[cfg]
+    model, x, targets, loss = CONFIGS[cfg](n)
+    model.build(n, dtype="f16")
+    model.compile(loss=loss, lr=2e-4)
+    losses = [float(model.train_step(x, targets).cpu()) for _ in range(4)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[3] < losses[0], (cfg, losses)

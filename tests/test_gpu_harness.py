@@ -117,7 +117,8 @@ def test_bucketed_optimizer_path_matches_flat_adam():
 
 
 def test_graphed_train_step_matches_eager():
-    """One hipGraph replay per optimiser step (both streams captured) must train exactly like the eager step."""
+    """One hipGraph replay per optimiser step (both streams captured) must train exactly like the eager step; capturing
+    itself must not train (its warm-up step is undone), and an eager step in between must not race the next replay."""
     g = torch.Generator().manual_seed(0)
     xs = [torch.rand((4, 32, 32, 3), generator=g).cuda() for _ in range(4)]
 
@@ -125,18 +126,24 @@ def test_graphed_train_step_matches_eager():
         m = build("f16", loss="mse")
         tgs = [[(x[..., :1] > 0.5).float() for _ in m.out_heads] for x in xs]
         losses = []
-        step = m.graphed_train_step(xs[0], tgs[0]) if graphed else None
-        for x, tg in zip(xs[1:] if graphed else xs, tgs[1:] if graphed else tgs):
-            lv = step(x, tg) if graphed else m.train_step(x, tg)
+        if graphed:
+            p_before = m.store.P.clone()
+            step = m.graphed_train_step(xs[3], tgs[3])           # example batch: any batch of the right shape
+            assert torch.equal(m.store.P, p_before) and m.adam_t == 0, "capturing must leave the model as it was"
+        for i, (x, tg) in enumerate(zip(xs, tgs)):
+            if graphed and i == 2:
+                lv = m.train_step(x, tg)                         # an eager step between two replays (side-stream Adam in flight)
+            else:
+                lv = step(x, tg) if graphed else m.train_step(x, tg)
             losses.append(float(lv.cpu()))
         m._join_side()
         torch.cuda.synchronize()
         return m.store.P.clone(), losses, m.adam_t
 
     p0, l0, t0 = run(False)
-    p1, l1, t1 = run(True)          # the capture warm-up is the step on xs[0]
+    p1, l1, t1 = run(True)
     assert t0 == t1 == 4
-    same_training(p0, p1, l0[1:], l1)
+    same_training(p0, p1, l0, l1)
 
 
 @pytest.mark.parametrize("overlap", [True, False])

@@ -41,7 +41,7 @@ def test_unetpp_fusion_counts():
     assert c["seg_igemm_wgrad"] == convs + nodes     # + one transposed conv per node
     assert c["seg_maxpool_bwd"] == d                 # pooling fused into bn_act_apply forward; only the backward is a launch
     assert c["seg_maxpool_fwd"] == 0
-    assert c["seg_adam_step"] == 1                   # ONE flat optimiser launch
+    assert c["seg_adam_step_ex"] == 1                   # ONE flat optimiser launch
     # no concat is ever materialised: every tensor in the registry is a real layer output
     assert not any(n.endswith("/cat") for n in m.tensors)
     # data-gradient launches: ONE per conv (split output), none for the first layer (the image needs no gradient)

@@ -1379,86 +1379,7 @@ __global__ void grad_scale_kernel(const float* amax, float target, float* gs) {
   gs[1] = 1.f / s;
 }
 
-// ------------------------------------------------------------------------------------------------ optimiser / packing
-__global__ __launch_bounds__(TPB) void adam_kernel(float* p, const float* g, float* m, float* v, half_t* p16, int64_t n, float alpha_t,
-                                                   float b1, float b2, float eps, float gmul, const float* alpha_ptr) {
-  if (alpha_ptr != nullptr) alpha_t *= *alpha_ptr;      // step size from device memory: a captured hipGraph replays with a fresh value
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    const float gi = g[i] * gmul;
-    float pi = p[i];
-    if (gi == gi && fabsf(gi) < 3.0e38f) {
-      const float mi = b1 * m[i] + (1.f - b1) * gi;
-      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-      m[i] = mi;
-      v[i] = vi;
-      pi -= alpha_t * mi / (sqrtf(vi) + eps);
-      p[i] = pi;
-    }
-    if (p16) p16[i] = (half_t)pi;
-  }
-}
-
-// The other optimisers of utils/tf_optimizers.py:12-26 with the Keras (>= 2.11) update rules; s1 / s2 are the two state
-// buffers (the flat m / v buffers of the parameter store), c[] the per-step scalars the host computes (seg_hip.h).
-__global__ __launch_bounds__(TPB) void optimizer_kernel(int kind, float* p, const float* g, float* s1, float* s2, half_t* p16, int64_t n,
-                                                        float c0, float c1, float c2, float c3, float c4, float gmul) {
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-    const float gi = g[i] * gmul;
-    float pi = p[i];
-    if (gi == gi && fabsf(gi) < 3.0e38f) {
-      switch (kind) {
-        case SEG_OPT_SGD: pi -= c0 * gi; break;                                       // c0 = lr
-        case SEG_OPT_RMSPROP: {                                                        // c0 = lr, c1 = rho, c2 = eps
-          const float v = c1 * s2[i] + (1.f - c1) * gi * gi;
-          s2[i] = v;
-          pi -= c0 * gi / sqrtf(v + c2);
-          break;
-        }
-        case SEG_OPT_ADAGRAD: {                                                        // c0 = lr, c2 = eps; s2 starts at 0.1
-          const float a = s2[i] + gi * gi;
-          s2[i] = a;
-          pi -= c0 * gi / sqrtf(a + c2);
-          break;
-        }
-        case SEG_OPT_ADADELTA: {                                                       // c0 = lr, c1 = rho, c2 = eps
-          const float ag = c1 * s1[i] + (1.f - c1) * gi * gi;
-          const float d = -sqrtf(s2[i] + c2) * gi / sqrtf(ag + c2);
-          s1[i] = ag;
-          s2[i] = c1 * s2[i] + (1.f - c1) * d * d;
-          pi += c0 * d;
-          break;
-        }
-        case SEG_OPT_ADAMAX: {                                                         // c0 = lr / (1 - b1^t), c1 = b1, c2 = b2, c3 = eps
-          const float m = s1[i] + (gi - s1[i]) * (1.f - c1);
-          const float u = fmaxf(c2 * s2[i], fabsf(gi));
-          s1[i] = m;
-          s2[i] = u;
-          pi -= c0 * m / (u + c3);
-          break;
-        }
-        case SEG_OPT_NADAM: {   // c0 = lr, c1 = u_{t+1} / (1 - prod u_{1..t+1}), c2 = (1 - u_t) / (1 - prod u_{1..t}), c3 = 1 / (1 - b2^t), c4 = eps
-          const float m = s1[i] + (gi - s1[i]) * (1.f - 0.9f);
-          const float v = s2[i] + (gi * gi - s2[i]) * (1.f - 0.999f);
-          s1[i] = m;
-          s2[i] = v;
-          pi -= c0 * (c1 * m + c2 * gi) / (sqrtf(v * c3) + c4);
-          break;
-        }
-        default: {              // SEG_OPT_FTRL (lr_power -0.5, no l1 / l2 / shrinkage): c0 = lr; s1 = accumulator (starts at 0.1), s2 = linear
-          const float a0 = s1[i], a1 = a0 + gi * gi;
-          const float lin = s2[i] + gi - (sqrtf(a1) - sqrtf(a0)) / c0 * pi;
-          s1[i] = a1;
-          s2[i] = lin;
-          pi = -lin / (sqrtf(a1) / c0);
-          break;
-        }
-      }
-      p[i] = pi;
-    }
-    if (p16) p16[i] = (half_t)pi;
-  }
-}
-
+// ------------------------------------------------------------------------------------------------ packing (the optimiser kernels live in optim.hip)
 template <typename T>
 __global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, T* wt, int rows, int Tn, int K, int rows_pad) {
   // out[k][t][r] = in[r][t][k]: 32 x 32 (r, k) tiles through LDS so that both the fp32 reads (k fastest) and the
@@ -1961,41 +1882,6 @@ extern "C" int seg_grad_scale(const float* amax, float target, float* gs, seg_st
   SEG_CHECK_ARG(amax && gs && target > 0.f, "seg_grad_scale: bad arguments");
   hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, ST(stream), amax, target, gs);
   SEG_CHECK_LAUNCH("seg_grad_scale");
-  return SEG_OK;
-}
-
-// The optimiser streams 30 B per parameter next to the forward GEMMs of the following step (SegModel runs it on the side
-// stream): 1024 blocks keep the HBM busy and leave CUs to the GEMMs - measured on C3 against 256 / 512 / 2048 / 4096 blocks
-// (25.2 / 24.1 / 23.7 / 23.8 ms per step; 1024: 23.5).  SEG_ADAM_BLOCKS overrides.
-static int optimizer_grid(int64_t n) {
-  static const int cap = getenv("SEG_ADAM_BLOCKS") ? atoi(getenv("SEG_ADAM_BLOCKS")) : 1024;
-  int blocks = grid_for(n);
-  if (cap > 0 && blocks > cap) blocks = cap;
-  return blocks;
-}
-
-extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1, float b2, float eps,
-                             float gmul, seg_stream_t stream) {
-  SEG_CHECK_ARG(p && g && m && v && n > 0, "seg_adam_step: bad arguments");
-  hipLaunchKernelGGL(adam_kernel, dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, g, m, v, (half_t*)p16, n, alpha_t, b1, b2, eps, gmul,
-                     (const float*)nullptr);
-  SEG_CHECK_LAUNCH("seg_adam_step");
-  return SEG_OK;
-}
-extern "C" int seg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const float* alpha_ptr, float b1, float b2,
-                                 float eps, float gmul, seg_stream_t stream) {
-  SEG_CHECK_ARG(p && g && m && v && alpha_ptr && n > 0, "seg_adam_step_dev: bad arguments");
-  hipLaunchKernelGGL(adam_kernel, dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, g, m, v, (half_t*)p16, n, 1.0f, b1, b2, eps, gmul, alpha_ptr);
-  SEG_CHECK_LAUNCH("seg_adam_step_dev");
-  return SEG_OK;
-}
-
-extern "C" int seg_optimizer_step(int32_t kind, float* p, const float* g, float* s1, float* s2, void* p16, int64_t n, const float* c,
-                                  float gmul, seg_stream_t stream) {
-  SEG_CHECK_ARG(p && g && s1 && s2 && c && n > 0 && kind >= SEG_OPT_SGD && kind <= SEG_OPT_FTRL, "seg_optimizer_step: bad arguments");
-  hipLaunchKernelGGL(optimizer_kernel, dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), kind, p, g, s1, s2, (half_t*)p16, n, c[0], c[1], c[2],
-                     c[3], c[4], gmul);
-  SEG_CHECK_LAUNCH("seg_optimizer_step");
   return SEG_OK;
 }
 

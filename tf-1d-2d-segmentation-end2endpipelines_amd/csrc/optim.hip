@@ -1,0 +1,208 @@
+// Optimiser kernels of the train step (Keras Adam, 2DCNN/Train.py:322 via utils/tf_optimizers.py:11, and the seven other
+// registry optimisers) on the flat parameter buffers, plus the bf16 packing of gradient slices for the data-parallel
+// exchange.  HBM-bound streaming kernels: 30 B per parameter (26 B when the gradient arrives as bf16).
+//
+// Gradient operand: fp32 (single GPU; the weight-gradient kernels accumulate there) or bf16 (what travelled over xGMI:
+// the sum of the ranks' slices, SURVEY.md 8e mitigation 1) - always widened to fp32 before the update, the optimiser state
+// and the master weights stay fp32.
+// Non-finite gradients: the update of that element is skipped AND counted into a device counter the caller owns, so
+// that an overflow of the fp16 backward pass is visible (SegModel.nonfinite_updates(), harness.fit backs the loss scale off).
+#include "seg_common.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int TPB = 256;
+#define ST(s) ((hipStream_t)(s))
+
+__device__ __forceinline__ float grad_load(const float* g, int64_t i) { return g[i]; }
+__device__ __forceinline__ float grad_load(const uint16_t* g, int64_t i) { return __uint_as_float((uint32_t)g[i] << 16); }     // bf16
+
+__device__ __forceinline__ void count_nonfinite(uint32_t* counter, uint32_t mine) {
+  if (counter == nullptr) return;
+  // rare path: one atomic per wave that saw any
+  const unsigned long long any = __ballot(mine != 0);
+  if (any == 0) return;
+  uint32_t tot = mine;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(counter, tot);
+}
+
+template <typename GT>
+__global__ __launch_bounds__(TPB) void adam_kernel(float* p, const GT* g, float* m, float* v, half_t* p16, int64_t n, float alpha_t,
+                                                   float b1, float b2, float eps, float gmul, const float* alpha_ptr, uint32_t* nonfinite) {
+  if (alpha_ptr != nullptr) alpha_t *= *alpha_ptr;      // step size from device memory: a captured hipGraph replays with a fresh value
+  uint32_t bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float gi = grad_load(g, i) * gmul;
+    float pi = p[i];
+    if (gi == gi && fabsf(gi) < 3.0e38f) {
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      pi -= alpha_t * mi / (sqrtf(vi) + eps);
+      p[i] = pi;
+    } else {
+      ++bad;
+    }
+    if (p16) p16[i] = (half_t)pi;
+  }
+  count_nonfinite(nonfinite, bad);
+}
+
+// The other optimisers of utils/tf_optimizers.py:12-26 with the Keras (>= 2.11) update rules; s1 / s2 are the two state
+// buffers (the flat m / v buffers of the parameter store), c[] the per-step scalars the host computes (seg_hip.h).
+template <typename GT>
+__global__ __launch_bounds__(TPB) void optimizer_kernel(int kind, float* p, const GT* g, float* s1, float* s2, half_t* p16, int64_t n,
+                                                        float c0, float c1, float c2, float c3, float c4, float gmul, uint32_t* nonfinite) {
+  uint32_t bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const float gi = grad_load(g, i) * gmul;
+    float pi = p[i];
+    if (gi == gi && fabsf(gi) < 3.0e38f) {
+      switch (kind) {
+        case SEG_OPT_SGD: pi -= c0 * gi; break;                                       // c0 = lr
+        case SEG_OPT_RMSPROP: {                                                        // c0 = lr, c1 = rho, c2 = eps
+          const float vv = c1 * s2[i] + (1.f - c1) * gi * gi;
+          s2[i] = vv;
+          pi -= c0 * gi / sqrtf(vv + c2);
+          break;
+        }
+        case SEG_OPT_ADAGRAD: {                                                        // c0 = lr, c2 = eps; s2 starts at 0.1
+          const float a = s2[i] + gi * gi;
+          s2[i] = a;
+          pi -= c0 * gi / sqrtf(a + c2);
+          break;
+        }
+        case SEG_OPT_ADADELTA: {                                                       // c0 = lr, c1 = rho, c2 = eps
+          const float ag = c1 * s1[i] + (1.f - c1) * gi * gi;
+          const float d = -sqrtf(s2[i] + c2) * gi / sqrtf(ag + c2);
+          s1[i] = ag;
+          s2[i] = c1 * s2[i] + (1.f - c1) * d * d;
+          pi += c0 * d;
+          break;
+        }
+        case SEG_OPT_ADAMAX: {                                                         // c0 = lr / (1 - b1^t), c1 = b1, c2 = b2, c3 = eps
+          const float mm = s1[i] + (gi - s1[i]) * (1.f - c1);
+          const float u = fmaxf(c2 * s2[i], fabsf(gi));
+          s1[i] = mm;
+          s2[i] = u;
+          pi -= c0 * mm / (u + c3);
+          break;
+        }
+        case SEG_OPT_NADAM: {   // c0 = lr, c1 = u_{t+1} / (1 - prod u_{1..t+1}), c2 = (1 - u_t) / (1 - prod u_{1..t}), c3 = 1 / (1 - b2^t), c4 = eps
+          const float mm = s1[i] + (gi - s1[i]) * (1.f - 0.9f);
+          const float vv = s2[i] + (gi * gi - s2[i]) * (1.f - 0.999f);
+          s1[i] = mm;
+          s2[i] = vv;
+          pi -= c0 * (c1 * mm + c2 * gi) / (sqrtf(vv * c3) + c4);
+          break;
+        }
+        default: {              // SEG_OPT_FTRL (lr_power -0.5, no l1 / l2 / shrinkage): c0 = lr; s1 = accumulator (starts at 0.1), s2 = linear
+          const float a0 = s1[i], a1 = a0 + gi * gi;
+          const float lin = s2[i] + gi - (sqrtf(a1) - sqrtf(a0)) / c0 * pi;
+          s1[i] = a1;
+          s2[i] = lin;
+          pi = -lin / (sqrtf(a1) / c0);
+          break;
+        }
+      }
+      p[i] = pi;
+    } else {
+      ++bad;
+    }
+    if (p16) p16[i] = (half_t)pi;
+  }
+  count_nonfinite(nonfinite, bad);
+}
+
+// fp32 -> bf16, round to nearest even; NaN stays NaN, +-Inf stays +-Inf (so that the receiving optimiser still sees and
+// counts a non-finite gradient).  8 elements per thread: 32-B loads, 16-B stores.
+__global__ __launch_bounds__(TPB) void cast_bf16_kernel(const float* x, uint16_t* y, int64_t n) {
+  auto cvt = [](float f) -> uint32_t {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;         // NaN: keep it quiet and non-zero in the mantissa
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                         // Inf + rounding stays Inf (mantissa is zero)
+  };
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * TPB) {
+    const f4 a = *reinterpret_cast<const f4*>(x + 8 * i), b = *reinterpret_cast<const f4*>(x + 8 * i + 4);
+    u4 o;
+    o[0] = cvt(a[0]) | (cvt(a[1]) << 16);
+    o[1] = cvt(a[2]) | (cvt(a[3]) << 16);
+    o[2] = cvt(b[0]) | (cvt(b[1]) << 16);
+    o[3] = cvt(b[2]) | (cvt(b[3]) << 16);
+    *reinterpret_cast<u4*>(y + 8 * i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = (n8 << 3) + threadIdx.x;
+    y[i] = (uint16_t)cvt(x[i]);
+  }
+}
+
+// The optimiser streams 30 B per parameter next to the forward GEMMs of the following step (SegModel runs it on the side
+// stream): 1024 blocks keep the HBM busy and leave CUs to the GEMMs - measured on C3 against 256 / 512 / 2048 / 4096 blocks
+// (25.2 / 24.1 / 23.7 / 23.8 ms per step; 1024: 23.5).  SEG_ADAM_BLOCKS overrides.
+int optimizer_grid(int64_t n) {
+  static const int cap = getenv("SEG_ADAM_BLOCKS") ? atoi(getenv("SEG_ADAM_BLOCKS")) : 1024;
+  int64_t blocks = (n + TPB - 1) / TPB;
+  if (blocks < 1) blocks = 1;
+  if (cap > 0 && blocks > cap) blocks = cap;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float* m, float* v, void* p16, int64_t n, float alpha_t,
+                                const float* alpha_ptr, float b1, float b2, float eps, float gmul, uint32_t* nonfinite, seg_stream_t stream) {
+  SEG_CHECK_ARG(p && g && m && v && n > 0, "seg_adam_step_ex: bad arguments");
+  SEG_CHECK_ARG(g_dtype == SEG_GRAD_F32 || g_dtype == SEG_GRAD_BF16, "seg_adam_step_ex: g_dtype=%d", g_dtype);
+  if (g_dtype == SEG_GRAD_F32)
+    hipLaunchKernelGGL((adam_kernel<float>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, (const float*)g, m, v, (half_t*)p16, n, alpha_t,
+                       b1, b2, eps, gmul, alpha_ptr, nonfinite);
+  else
+    hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, (const uint16_t*)g, m, v, (half_t*)p16, n,
+                       alpha_t, b1, b2, eps, gmul, alpha_ptr, nonfinite);
+  SEG_CHECK_LAUNCH("seg_adam_step_ex");
+  return SEG_OK;
+}
+
+extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1, float b2, float eps,
+                             float gmul, seg_stream_t stream) {
+  return seg_adam_step_ex(p, g, SEG_GRAD_F32, m, v, p16, n, alpha_t, nullptr, b1, b2, eps, gmul, nullptr, stream);
+}
+extern "C" int seg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const float* alpha_ptr, float b1, float b2,
+                                 float eps, float gmul, seg_stream_t stream) {
+  SEG_CHECK_ARG(alpha_ptr != nullptr, "seg_adam_step_dev: null alpha_ptr");
+  return seg_adam_step_ex(p, g, SEG_GRAD_F32, m, v, p16, n, 1.0f, alpha_ptr, b1, b2, eps, gmul, nullptr, stream);
+}
+
+extern "C" int seg_optimizer_step_ex(int32_t kind, float* p, const void* g, int32_t g_dtype, float* s1, float* s2, void* p16, int64_t n,
+                                     const float* c, float gmul, uint32_t* nonfinite, seg_stream_t stream) {
+  SEG_CHECK_ARG(p && g && s1 && s2 && c && n > 0 && kind >= SEG_OPT_SGD && kind <= SEG_OPT_FTRL, "seg_optimizer_step_ex: bad arguments");
+  SEG_CHECK_ARG(g_dtype == SEG_GRAD_F32 || g_dtype == SEG_GRAD_BF16, "seg_optimizer_step_ex: g_dtype=%d", g_dtype);
+  if (g_dtype == SEG_GRAD_F32)
+    hipLaunchKernelGGL((optimizer_kernel<float>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), kind, p, (const float*)g, s1, s2, (half_t*)p16,
+                       n, c[0], c[1], c[2], c[3], c[4], gmul, nonfinite);
+  else
+    hipLaunchKernelGGL((optimizer_kernel<uint16_t>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), kind, p, (const uint16_t*)g, s1, s2,
+                       (half_t*)p16, n, c[0], c[1], c[2], c[3], c[4], gmul, nonfinite);
+  SEG_CHECK_LAUNCH("seg_optimizer_step_ex");
+  return SEG_OK;
+}
+extern "C" int seg_optimizer_step(int32_t kind, float* p, const float* g, float* s1, float* s2, void* p16, int64_t n, const float* c,
+                                  float gmul, seg_stream_t stream) {
+  return seg_optimizer_step_ex(kind, p, g, SEG_GRAD_F32, s1, s2, p16, n, c, gmul, nullptr, stream);
+}
+
+extern "C" int seg_cast_f32_bf16(const float* x, void* y, int64_t n, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && n > 0 && ((uintptr_t)x & 31) == 0 && ((uintptr_t)y & 15) == 0, "seg_cast_f32_bf16: bad arguments (x 32-B, y 16-B aligned)");
+  int64_t blocks = ((n >> 3) + TPB - 1) / TPB;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(TPB), 0, ST(stream), x, (uint16_t*)y, n);
+  SEG_CHECK_LAUNCH("seg_cast_f32_bf16");
+  return SEG_OK;
+}

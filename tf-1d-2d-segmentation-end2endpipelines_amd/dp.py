@@ -1,6 +1,9 @@
 """Data-parallel training: one process per GPU, minibatch sharded across ranks (weak scaling, bs/GPU fixed),
 per-replica BatchNorm statistics (the reference has no SyncBN), and ONE exchange step per optimiser step: a sum
-all-reduce of the flat fp32 gradient buffer over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
+all-reduce of the flat gradient buffer over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).  With more
+than one rank the slices travel as bf16 (half the bytes per link, SURVEY.md 8e mitigation 1: C3 795 MB -> 398 MB per
+step): a finished fp32 slice is packed by `seg_cast_f32_bf16`, summed by RCCL in bf16, and the optimiser kernel widens
+it back to fp32 - optimiser state and master weights never leave fp32.  `grad_dtype="f32"` exchanges the buffer itself.
 
 The reference is single-device (no tf.distribute anywhere); this is the data-parallel
 train_step the north star adds around `2DCNN/Train.py:394-415`.
@@ -67,9 +70,12 @@ class DataParallel:
     asynchronously on RCCL's stream while the remaining backward kernels keep running; Adam runs per slice as soon as
     that slice's exchange has finished."""
 
-    def __init__(self, model, bucket_elems: int = 32 << 20, group=None, overlap: bool = True, force_exchange: bool = False):
+    def __init__(self, model, bucket_elems: int = 32 << 20, group=None, overlap: bool = True, force_exchange: bool = False,
+                 grad_dtype: Optional[str] = None):
         """force_exchange: take the exchange path even in a group of one rank (tests: the RCCL launches, their stream
-        ordering against the side stream and the per-slice optimiser can then be exercised on a single GPU)."""
+        ordering against the side stream and the per-slice optimiser can then be exercised on a single GPU).
+        grad_dtype: "bf16" | "f32" - what the all-reduce moves (default: SEG_DP_GRAD_DTYPE, else bf16 when there is an
+        exchange with more than one rank, f32 otherwise)."""
         self.model, self.group, self.bucket_elems = model, group, bucket_elems
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -78,22 +84,45 @@ class DataParallel:
         model.world_size = self.world_size
         model.bucket_elems = bucket_elems
         exchange = self.world_size > 1 or (force_exchange and dist.is_initialized())
+        if grad_dtype is None:
+            grad_dtype = os.environ.get("SEG_DP_GRAD_DTYPE") or ("bf16" if (exchange and self.world_size > 1) else "f32")
+        if grad_dtype not in ("bf16", "f32"):
+            raise ValueError("grad_dtype must be 'bf16' or 'f32'")
+        self.grad_dtype = grad_dtype if (exchange and overlap) else "f32"      # (the non-overlapped path exchanges the buffer itself)
+        model.grad_dtype = self.grad_dtype
+        if self.grad_dtype == "bf16":
+            model.store.G16 = torch.zeros(model.store.G.numel(), dtype=torch.bfloat16, device=model.store.G.device)
         if overlap and exchange:
             model.bucket_hook = self._bucket_ready
             model.bucket_waits = self._take_pending
         elif exchange:
             model.allreduce = self._allreduce       # (a single rank keeps the model's own single-GPU optimiser path)
         if self.world_size > 1:
+            # identical replicas: weights, BN moving statistics AND the optimiser's view of the run (state buffers, step
+            # count, Nadam's momentum product, learning rate) come from rank 0 - a model that has already taken steps, or
+            # ranks that loaded different checkpoints, would otherwise apply different updates to the same summed gradient
             st = model.store
-            broadcast_flat(st.P, 0, group)
-            broadcast_flat(st.S, 0, group)
+            model._join_side()
+            for buf in (st.P, st.S, st.M, st.V):
+                broadcast_flat(buf, 0, group)
+            scal = torch.tensor([float(model.adam_t), float(model._u_product), float(model.lr)], dtype=torch.float64, device=st.P.device)
+            broadcast_flat(scal, 0, group)
+            model.adam_t, model._u_product, model.lr = int(scal[0].item()), float(scal[1].item()), float(scal[2].item())
             model._refresh_copies()
 
     def _allreduce(self, flat_grads: torch.Tensor):
         allreduce_flat(flat_grads, self.bucket_elems, self.group, force=self.force_exchange)
 
     def _bucket_ready(self, lo: int, hi: int):
-        self.pending.append((lo, hi, dist.all_reduce(self.model.store.G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        """G[lo:hi] is final on the calling stream: pack it (bf16 mode) and start its all-reduce."""
+        st = self.model.store
+        if self.grad_dtype == "bf16":
+            from . import model as _m
+            _m.call("seg_cast_f32_bf16", _m.C.c_void_p(st.G.data_ptr() + lo * 4), _m.C.c_void_p(st.G16.data_ptr() + lo * 2), hi - lo, _m._stream())
+            buf = st.G16[lo:hi]
+        else:
+            buf = st.G[lo:hi]
+        self.pending.append((lo, hi, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def _take_pending(self):
         """[(lo, hi, work)] in issue order; the optimiser waits for each and updates that slice (Adam per bucket: the

@@ -225,9 +225,10 @@ class Graph:
                 cons[j].append(i)
         return cons
 
-    def macs(self) -> int:
+    def macs(self, convlstm_gates: int = 4) -> int:
         """Algorithmic multiply-accumulates per sample: conv, convT (no zero insertion),
-        ConvLSTM input conv with all four gates as written."""
+        ConvLSTM input conv with all four gates as written (convlstm_gates=3: without the forget gate, which is dead at
+        T = 1 - the conservative figure SURVEY.md 8d prescribes for roofline fractions)."""
         tot = 0
         for i in self.live_nodes():
             n = self.nodes[i]
@@ -242,8 +243,21 @@ class Graph:
             elif n.kind == "convlstm":
                 kh, kw = n.attrs["kernel"]
                 cin = self.nodes[n.inputs[0]].shape[2]
-                tot += n.shape[0] * n.shape[1] * kh * kw * cin * 4 * n.attrs["filters"]
+                tot += n.shape[0] * n.shape[1] * kh * kw * cin * convlstm_gates * n.attrs["filters"]
         return tot
+
+    def conv_io_elements(self) -> Tuple[int, int]:
+        """(activation elements read + written by the conv / convT / ConvLSTM layers per sample, weight elements):
+        the algorithmic HBM traffic of a fully fused forward pass (the HBM-bound configurations)."""
+        act = wts = 0
+        for i in self.live_nodes():
+            n = self.nodes[i]
+            if n.kind in ("conv", "convT", "convlstm"):
+                hi, wi, ci = self.nodes[n.inputs[0]].shape
+                act += hi * wi * ci + n.shape[0] * n.shape[1] * n.shape[2]
+                k = n.params[0].shape
+                wts += k[0] * k[1] * k[2] * k[3]
+        return act, wts
 
     def summary(self) -> str:
         lines = [f"Graph {self.name!r}: {len(self.live_nodes())} live nodes, {self.count_params():,} params"]

@@ -63,7 +63,9 @@ class ModelCheckpoint:
             if cur is None or not self.better(cur, self.best):
                 return
             self.best = cur
-        state.model.save_weights(self.path)
+        if _dist_rank() == 0:          # data parallel: the replicas are identical; one writer, the others wait for the file
+            state.model.save_weights(self.path)
+        _dist_barrier()
         self.saved_epochs.append(epoch)
 
 
@@ -104,6 +106,60 @@ class FitState:
     def __init__(self, model):
         self.model = model
         self.stop_training = False
+
+
+# ---- data parallel (dp.DataParallel installed on the model): every rank feeds its own shard, so the per-rank losses and
+# metrics differ.  The callbacks must see the SAME numbers on every rank, or one rank stops / lowers its learning rate
+# while the others sit in the next gradient all-reduce.
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:          # pragma: no cover
+        return None
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+def _dist_rank() -> int:
+    d = _dist()
+    return d.get_rank() if d is not None else 0
+
+
+def _dist_barrier():
+    d = _dist()
+    if d is not None:
+        d.barrier()
+
+
+def _dist_device():
+    import torch
+    d = _dist()
+    return torch.device("cuda", torch.cuda.current_device()) if (d is not None and d.get_backend() == "nccl") else torch.device("cpu")
+
+
+def sync_logs(logs: Dict[str, float]) -> Dict[str, float]:
+    """Mean over the ranks of every entry (same keys in the same order on every rank); identity without a process group."""
+    d = _dist()
+    if d is None or not logs:
+        return logs
+    import torch
+    keys = sorted(logs)
+    t = torch.tensor([float(logs[k]) for k in keys], dtype=torch.float64, device=_dist_device())
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    t /= d.get_world_size()
+    return {k: float(v) for k, v in zip(keys, t.cpu().tolist())}
+
+
+def sync_decisions(state: "FitState"):
+    """After the callbacks: rank 0's stop flag and learning rate are everybody's (they were computed from identical logs,
+    this makes the agreement unconditional - e.g. against a callback with rank-local state)."""
+    d = _dist()
+    if d is None:
+        return
+    import torch
+    t = torch.tensor([1.0 if state.stop_training else 0.0, float(state.model.lr)], dtype=torch.float64, device=_dist_device())
+    d.broadcast(t, src=0)
+    state.stop_training = bool(t[0].item() != 0.0)
+    state.model.lr = float(t[1].item())
 
 
 def _as_batch(model, x, targets):
@@ -164,7 +220,7 @@ def fit(model, train_batches, epochs: int, val_batches=None,
     state = FitState(model)
     ms = _metric_set(model)
     for epoch in range(int(epochs)):
-        tot, n = 0.0, 0
+        tot, n, skipped = 0.0, 0, 0
         if ms is not None:
             ms.reset()
         for x, targets in _batches(train_batches):
@@ -173,6 +229,13 @@ def fit(model, train_batches, epochs: int, val_batches=None,
             if ms is not None:                  # Keras updates the metrics from the training-mode predictions of the step
                 ms.update(targets)
             n += 1
+            if hasattr(model, "nonfinite_updates"):
+                # fp16 backward overflow: the optimiser skipped (and counted) the affected elements; back the loss scale
+                # off like dynamic loss scaling does and report it - Keras would have put NaNs into the weights instead
+                bad = model.nonfinite_updates(reset=True)
+                if bad:
+                    skipped += bad
+                    model.grad_target = max(model.grad_target / 2.0, 1.0)
         if hasattr(train_batches, "on_epoch_end"):
             train_batches.on_epoch_end()
         logs = {"loss": tot / max(n, 1)}
@@ -180,8 +243,11 @@ def fit(model, train_batches, epochs: int, val_batches=None,
             logs.update(ms.result())
         if val_batches is not None:
             logs.update({"val_" + k: v for k, v in evaluate(model, val_batches, return_dict=True).items()})
+        logs["nonfinite_grads"] = float(skipped)
+        logs = sync_logs(logs)                   # data parallel: every rank's callbacks see the mean over the shards
         for cb in callbacks:
             cb.on_epoch_end(epoch, logs, state)
+        sync_decisions(state)
         for k, v in logs.items():
             hist.setdefault(k, []).append(v)
         if verbose:

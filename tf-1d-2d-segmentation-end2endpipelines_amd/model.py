@@ -497,6 +497,8 @@ class ParamStore:
         self.V = torch.zeros(n, dtype=torch.float32, device=_dev())
         self.P16 = torch.zeros(n, dtype=torch.float16, device=_dev())
         self.S = torch.zeros(max(self.n_state, self.ALIGN), dtype=torch.float32, device=_dev())
+        self.G16 = None           # bf16 image of G for the data-parallel exchange (allocated by dp.DataParallel(grad_dtype="bf16"))
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=_dev())      # elements whose update was skipped (NaN / Inf gradient)
 
     def view(self, name, which="P") -> torch.Tensor:
         s = self.slots[name]
@@ -1048,7 +1050,7 @@ class BNOp(Op):
         self.acc = self.x.claim() if (self.live and self.x.needs_grad) else None
 
     def backward(self):
-        if not self.live or self.acc is None:
+        if not self.live:
             return
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
         dA = self.out.grad
@@ -1056,6 +1058,8 @@ class BNOp(Op):
              _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha), _p(self.bpart), BN_PARTS_BWD, s)
         call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.C, x.npix, st.ptr(bn + "/gamma", "G"),
              st.ptr(bn + "/beta", "G"), 1.0, C.c_void_p(self.m.gs.data_ptr() + 4), _p(self.c1), _p(self.c2), s)
+        if self.acc is None:          # the input needs no gradient (a BN placed on the network input): gamma / beta are done
+            return
         call("seg_bn_act_bwd_apply", _p(dA), self.out.cs, 0, _p(x.buf), x.cs, 0, _p(x.grad), x.cs, 0, x.npix, self.C,
              _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1), _p(self.c2), ACT[self.act],
              float(self.alpha), self.acc, s)
@@ -1208,6 +1212,8 @@ class SegModel:
         self.metric_names: List[str] = []   # compile(metrics=[...]): names of utils/tf_metrics.py, evaluated by harness.fit
         self._label_flag = None
         self.world_size = 1
+        self.grad_dtype = "f32"        # what the data-parallel exchange moves: "f32" (the flat buffer itself) or "bf16" (store.G16)
+        self.grad_target = GRAD_TARGET  # max |dLoss/dOut| is scaled into [target/2, target) before the fp16 backward pass
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
         self.bucket_waits = None       # ... and fn() -> [(lo, hi, work)] handing the pending all-reduces to the optimiser
@@ -1251,6 +1257,11 @@ class SegModel:
             self.adam_t += 1
             self._alpha_dev.fill_(self.lr * math.sqrt(1.0 - self.beta_2 ** self.adam_t) / (1.0 - self.beta_1 ** self.adam_t))
 
+        # the warm-up below is a real optimiser step on the example batch (PyTorch's capture protocol needs one eager run):
+        # weights, optimiser state, BN moving statistics and the step count are put back afterwards, so that capturing
+        # does not train the model
+        st = self.store
+        snap = (st.P.clone(), st.M.clone(), st.V.clone(), st.S.clone(), self.adam_t, self._u_product)
         self._graph_mode = True
         try:
             warm = torch.cuda.Stream()
@@ -1265,10 +1276,21 @@ class SegModel:
                 lv = self.train_step(sx, st_, loss)
         finally:
             self._graph_mode = False
-        self._g_clean = False
+        st.P.copy_(snap[0]); st.M.copy_(snap[1]); st.V.copy_(snap[2]); st.S.copy_(snap[3])
+        self.adam_t, self._u_product = snap[4], snap[5]
+        del snap
+        self._refresh_copies()
+        st.G.zero_()
+        self._g_clean = True          # what the captured step expects on entry (it ends by clearing the buffer itself)
+        torch.cuda.synchronize()
 
         def step(xn, tn):
             tn = list(tn) if isinstance(tn, (list, tuple)) else [tn]
+            # an eager step before this replay may have left Adam slices / the operand rebuild running on the side stream,
+            # or a backward pass without an optimiser step may have left gradients in the buffer
+            self._join_side()
+            if not self._g_clean:
+                st.G.zero_()
             sx.copy_(self._check_x(xn))
             for d, t in zip(st_, tn):
                 d.copy_(t)
@@ -1626,6 +1648,17 @@ class SegModel:
         return {name: np.asarray(s.from_engine(host[s.off:s.off + s.numel]), np.float32).reshape(s.spec.shape)
                 for name, s in st.slots.items() if s.trainable}
 
+    def nonfinite_updates(self, reset: bool = False) -> int:
+        """Parameter elements whose update the optimiser skipped since the last reset because their gradient was NaN or
+        +-Inf (an overflow of the fp16 backward pass; Keras would have propagated the NaN into the weights).  Reading it
+        synchronises with the device - harness.fit reads it once per step next to the loss and halves `grad_target` (the
+        fp16 loss scale) when it is non-zero, the way dynamic loss scaling backs off."""
+        self._join_side()
+        n = int(self.store.nonfinite.cpu())
+        if reset and n:
+            self.store.nonfinite.zero_()
+        return n
+
     def _refresh_copies(self):
         st = self.store
         self._enter()
@@ -1768,7 +1801,7 @@ class SegModel:
         self.amax.zero_()
         for h in self.out_heads:
             call("seg_absmax", _p(h.dy), h.dy.numel(), _p(self.amax), s)
-        call("seg_grad_scale", _p(self.amax), GRAD_TARGET, _p(self.gs), s)
+        call("seg_grad_scale", _p(self.amax), float(self.grad_target), _p(self.gs), s)
         if not self._g_clean:
             self.store.G.zero_()          # (after an optimiser step the side stream has already cleared it)
         self._g_clean = False
@@ -1866,17 +1899,21 @@ class SegModel:
                 raise NotImplementedError("a captured training step supports the Adam optimiser only")
             other = (OPTIMIZER[self.optimizer], self._optimizer_scalars())
 
-        def adam(lo, hi):
+        def adam(lo, hi, exchanged=False):
             off = lambda t: C.c_void_p(t.data_ptr() + lo * t.element_size())
-            if other is not None:        # the rest of the registry: same slices, same streams, another update rule
-                call("seg_optimizer_step", other[0], off(st.P), off(st.G), off(st.M), off(st.V), off(st.P16) if self.dtype == "f16" else None,
-                     hi - lo, other[1], 1.0 / self.world_size, _stream())
-            elif self._graph_mode:       # the step size comes from device memory (refreshed before every replay)
-                call("seg_adam_step_dev", off(st.P), off(st.G), off(st.M), off(st.V), off(st.P16) if self.dtype == "f16" else None, hi - lo,
-                     _p(self._alpha_dev), self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _stream())
+            p16 = off(st.P16) if self.dtype == "f16" else None
+            # a slice that went through the bf16 exchange is read from there (the sum over the ranks), everything else from G
+            if exchanged and self.grad_dtype == "bf16":
+                g, gdt = off(st.G16), _ffi.GRAD_BF16
             else:
-                call("seg_adam_step", off(st.P), off(st.G), off(st.M), off(st.V), off(st.P16) if self.dtype == "f16" else None, hi - lo, a_t,
-                     self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _stream())
+                g, gdt = off(st.G), _ffi.GRAD_F32
+            if other is not None:        # the rest of the registry: same slices, same streams, another update rule
+                call("seg_optimizer_step_ex", other[0], off(st.P), g, gdt, off(st.M), off(st.V), p16, hi - lo, other[1], 1.0 / self.world_size,
+                     _p(st.nonfinite), _stream())
+            else:                        # (a captured step reads its step size from device memory, refreshed before every replay)
+                dev = self._graph_mode
+                call("seg_adam_step_ex", off(st.P), g, gdt, off(st.M), off(st.V), p16, hi - lo, 1.0 if dev else a_t,
+                     _p(self._alpha_dev) if dev else None, self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _p(st.nonfinite), _stream())
 
         n = st.P.numel()
         if self.bucket_waits is not None and DP_ASYNC and self.side_stream is not None and not self._graph_mode:
@@ -1893,7 +1930,7 @@ class SegModel:
                     work.wait()                    # stream-side for RCCL: the side stream waits for this collective
                     if lo > pos:
                         adam(pos, lo)
-                    adam(lo, hi)
+                    adam(lo, hi, True)
                     pos = hi
                     e = torch.cuda.Event()
                     e.record(side)
@@ -1910,7 +1947,7 @@ class SegModel:
             done = []
             for lo, hi, work in self.bucket_waits():
                 work.wait()
-                adam(lo, hi)
+                adam(lo, hi, True)
                 done.append((lo, hi))
             done.sort()
             pos = 0
