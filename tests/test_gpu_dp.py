@@ -109,4 +109,5 @@ def test_two_ranks_equal_hand_averaged_replicas(overlap, grad_dtype):
     want = a.store.P.cpu().numpy()
     # (Adam normalises the step: a gradient element whose bf16 sum rounds the other way moves its weight by up to ~lr)
     assert np.abs(res[0][1] - want).max() < (1e-6 if grad_dtype == "f32" else 2e-3), np.abs(res[0][1] - want).max()
-    assert res[0][2] == pytest.approx(ref_losses[0::2], rel=1e-5) and res[1][2] == pytest.approx(ref_losses[1::2], rel=1e-5)
+    rel = 1e-5 if grad_dtype == "f32" else 1e-3
+    assert res[0][2] == pytest.approx(ref_losses[0::2], rel=rel) and res[1][2] == pytest.approx(ref_losses[1::2], rel=rel)

@@ -150,3 +150,4 @@ def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg):
     losses = [float(model.train_step(x, targets).cpu()) for _ in range(4)]
     assert all(np.isfinite(losses)), losses
     assert losses[3] < losses[0], (cfg, losses)
+    assert model.nonfinite_updates() == 0              # no fp16 overflow anywhere in the backward pass at this depth / width

@@ -42,6 +42,16 @@ def one_hot(shape, ncls):
     return F.one_hot(torch.randint(0, ncls, shape), ncls).float()
 
 
+def _with_targets(model, x, loss):
+    """Random targets shaped like the model's outputs ([out, level1, ...]; 1D outputs without the H = 1 axis)."""
+    g = model.graph
+    tg = []
+    for o in g.outputs:
+        H, W, C = g.nodes[o].shape
+        tg.append(torch.rand(x.shape[0], W, C) if g.ndim == 1 else torch.rand(x.shape[0], H, W, C))
+    return model, x, tg, loss
+
+
 CASES = {
     "unet_softmax_cce": lambda: (B("UNet", 32, 32, 16, 2, num_channels=3, output_nums=4, final_activation="softmax"),
                                  torch.rand(2, 32, 32, 3), [one_hot((2, 32, 32), 4)], "cce"),
@@ -74,6 +84,12 @@ CASES = {
                                    torch.rand(4, 256, 1), [one_hot((4, 256), 2)], "cce"),
     "unetpp1d_ds_mse": lambda: (segamd.UNet1D(128, 2, 1, 16, 3, ds=1).UNetPP(), torch.rand(4, 128, 1),
                                 [torch.rand(4, 128, 1), torch.rand(4, 128, 1), torch.rand(4, 128, 1)], "mse"),
+    # the remaining same-kernel variants (2DCNN unet_variants.py:217-274; 1DCNN BCDUNet.py:111-174)
+    "unetp_bce": lambda: (B("UNetP", 32, 32, 16, 2, num_channels=3), torch.rand(2, 32, 32, 3),
+                          [(torch.rand(2, 32, 32, 1) > 0.5).float()], "bce"),
+    "unetp_ag_ds_mse": lambda: _with_targets(B("UNetP", 32, 32, 16, 2, num_channels=3, ag=1, ds=1), torch.rand(2, 32, 32, 3), "mse"),
+    "bcdunet1d_lstm_dense2_mse": lambda: _with_targets(segamd.BCDUNet(128, 2, 1, 16, 3, lstm=1, dense_loop=2, ds=1).BCDUNet(),
+                                                      torch.rand(4, 128, 1), "mse"),
 }
 
 
@@ -120,6 +136,7 @@ def test_masks_match_reference_rule(name):
     model.build(x.shape[0])
     for _ in range(2):                                       # make the moving statistics non-trivial
         model.train_step(x, targets, loss)
+    assert model.nonfinite_updates() == 0                    # the optimiser skipped nothing (no fp16 overflow in the backward pass)
     w = {k: torch.from_numpy(v) for k, v in model.get_weights().items()}
     from ir_interp import run_graph
     ref = run_graph(model.graph, x, w, training=False)[0]

@@ -950,6 +950,42 @@ def test_adam_matches_keras_adam_three_steps():
     assert torch.equal(p16.cpu(), p.cpu().half())
 
 
+def test_bf16_gradient_operand_nonfinite_counter_and_pack():
+    """seg_cast_f32_bf16 == torch's round-to-nearest-even (NaN / Inf kept); seg_adam_step_ex with a bf16 gradient equals the
+    fp32 form on the widened values; NaN / Inf gradients are skipped AND counted."""
+    n = 10007
+    g = torch.randn(n) * (10.0 ** torch.randint(-8, 3, (n,)).float())
+    g[5], g[77], g[1234] = float("nan"), float("inf"), float("-inf")
+    gd = g.cuda()
+    g16 = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    ffi.call("seg_cast_f32_bf16", P(gd), P(g16), n, stream())
+    torch.cuda.synchronize()
+    want = g.bfloat16()
+    ok = torch.isfinite(g)
+    assert torch.equal(g16.cpu()[ok].view(torch.int16), want[ok].view(torch.int16))
+    assert bool(torch.isnan(g16.cpu()[5])) and float(g16.cpu()[77]) == float("inf") and float(g16.cpu()[1234]) == float("-inf")
+    p0 = torch.randn(n)
+    outs = []
+    for gbuf, gdt in ((g16, ffi.GRAD_BF16), (g16.float(), ffi.GRAD_F32)):
+        p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        p16 = torch.zeros(n, dtype=torch.float16, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ffi.call("seg_adam_step_ex", P(p), P(gbuf), gdt, P(m), P(v), P(p16), n, 1e-3, None, 0.9, 0.999, 1e-7, 0.5, P(cnt), stream())
+        torch.cuda.synchronize()
+        assert int(cnt.cpu()) == 3                                   # the three non-finite elements, counted once each
+        assert torch.equal(p.cpu()[~ok], p0[~ok]) and float(m.cpu()[~ok].abs().max()) == 0.0      # ... and left alone
+        outs.append((p.cpu(), m.cpu(), v.cpu(), p16.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    import ctypes as C
+    cs = (C.c_float * 5)(1e-2, 0, 0, 0, 0)
+    p, s1, s2 = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ffi.call("seg_optimizer_step_ex", ffi.OPTIMIZER["SGD"], P(p), P(g16), ffi.GRAD_BF16, P(s1), P(s2), None, n, cs, 1.0, P(cnt), stream())
+    torch.cuda.synchronize()
+    assert int(cnt.cpu()) == 3 and torch.allclose(p.cpu()[ok], (p0 - 1e-2 * want.float())[ok], rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("name", ["SGD", "RMSprop", "Adagrad", "Adadelta", "Adamax", "Nadam", "FTRL"])
 def test_registry_optimizers_match_the_oracle_four_steps(name):
     """seg_optimizer_step driven the way SegModel drives it (per-step host scalars, state initialisation) against the
