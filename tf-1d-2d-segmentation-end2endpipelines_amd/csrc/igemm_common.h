@@ -1,0 +1,358 @@
+// Shared pieces of the implicit-GEMM translation units (igemm_fwd.hip: register-staged and LDS-DMA per-tap kernels;
+// igemm_halo.hip: halo-tile forward / data gradient; igemm_wgrad.hip: weight gradients): MFMA K steps, the XCD-aware block
+// order, the forward epilogue (bias, BN partial statistics, activation, split outputs) and the host-side argument checks.
+// Everything lives in an unnamed namespace: each translation unit gets its own copy.
+#pragma once
+#include "seg_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int ROW_BYTES = 64;     // one LDS tile row = one K step = 4 chunks of 16 B (32 halves or 16 floats)
+template <typename T> struct ET;
+template <> struct ET<half_t> { static constexpr int EPC = 8; };   // elements per 16-B chunk
+template <> struct ET<float> { static constexpr int EPC = 4; };
+
+// One K step (64 B per row) of MFMAs for a (TM x TN) grid of 32x32 tiles.  A/B point at the rows of this wave's
+// tiles; lane (fr = lane & 31, fh = lane >> 5) reads row fr.  fp16: two v_mfma_f32_32x32x16_f16 (k = 8 fh + j);
+// fp32: eight v_mfma_f32_32x32x2_f32 - lane half fh owns k = 8 fh .. 8 fh + 7 of the 16-deep step and MFMA j
+// contracts the pair {j, 8 + j} (the sum over k is order-free as long as A and B use the same assignment).
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_step(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
+                                         f16v (&acc)[TM][TN]) {
+  const int fswz = (fr >> 2) & 3;
+  if constexpr (sizeof(T) == 2) {
+    // all eight fragment reads of the 32-deep step are issued before the first MFMA: the LDS latency is paid once
+    h8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ((ks * 2 + fh) ^ fswz) << 4;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[ks][a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * ROW_BYTES + ch);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[ks][b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * ROW_BYTES + ch);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+  } else {
+    const int c0 = ((2 * fh) ^ fswz) << 4, c1 = ((2 * fh + 1) ^ fswz) << 4;
+    f4 a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const unsigned char* r = A + (a_row0 + a * 32 + fr) * ROW_BYTES;
+      a0[a] = *reinterpret_cast<const f4*>(r + c0);
+      a1[a] = *reinterpret_cast<const f4*>(r + c1);
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const unsigned char* r = B + (b_row0 + b * 32 + fr) * ROW_BYTES;
+      b0[b] = *reinterpret_cast<const f4*>(r + c0);
+      b1[b] = *reinterpret_cast<const f4*>(r + c1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a][j], b0[b][j], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a][j], b1[b][j], acc[a][b], 0, 0, 0);
+        }
+  }
+}
+constexpr int STG_LD = 36;        // floats per staging row (32 + 4 pad, keeps 16-B alignment)
+constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;   // 4 waves
+
+// XCD-aware block order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin over them): physical
+// block b runs on XCD b % 8; give each XCD one contiguous range of logical tiles so that neighbouring tiles (which
+// share halo rows / the dz tile / weight panels) meet in the same L2.  Bijective for any block count.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// 64-deep K step on 128-B LDS rows (fp16): 8 chunks per row, chunk index XOR (row >> 1) & 7, so that the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.  4 x (TM x TN) MFMAs.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_step64(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
+                                           f16v (&acc)[TM][TN]) {
+  const int fswz = (fr >> 1) & 7;      // tile rows start at multiples of 32, so (row >> 1) & 7 depends on fr only
+#pragma unroll
+  for (int kp = 0; kp < 2; ++kp) {     // two pairs of 16-deep MFMA steps; fragment reads of a pair issued together
+    h8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = (((kp * 2 + ks) * 2 + fh) ^ fswz) << 4;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[ks][a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * 128 + ch);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[ks][b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * 128 + ch);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+  }
+}
+
+// eight stored elements kept in their memory format (16 B of fp16 / 32 B of fp32) until they are needed
+template <typename T> struct Raw8;
+template <> struct Raw8<half_t> {
+  typedef u4 type;
+  static __device__ __forceinline__ void zero(type& r) { r = u4{0u, 0u, 0u, 0u}; }
+  static __device__ __forceinline__ void load(const half_t* p, type& r) { r = ld16(p); }
+  static __device__ __forceinline__ void add(const type& r, float* f) {
+    float o[8];
+    unpack8(r, o);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) f[t] += o[t];
+  }
+};
+template <> struct Raw8<float> {
+  struct type { f4 a, b; };
+  static __device__ __forceinline__ void zero(type& r) { r.a = f4{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+  static __device__ __forceinline__ void load(const float* p, type& r) {
+    r.a = *reinterpret_cast<const f4*>(p);
+    r.b = *reinterpret_cast<const f4*>(p + 4);
+  }
+  static __device__ __forceinline__ void add(const type& r, float* f) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { f[t] += r.a[t]; f[4 + t] += r.b[t]; }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// shared epilogue of the forward kernels: bias, BN partial statistics, activation, channel-padding mask, then each
+// 32x32 accumulator tile goes through a per-wave LDS slab so that global stores are 8 channels (16 / 32 B) per lane.
+// row0 = first logical pixel of this wave's rows, col0 = first column of this wave inside the block's BN columns.
+// ---------------------------------------------------------------------------------------------------------
+// PWE = 0: this wave's rows are the logical pixels row0 .. ; PWE = 32 / 16: the rows are a 256-pixel patch of width
+// PWE at (image pn, row py0, column px0) and row0 is the wave's first patch row (the halo-tile kernel).
+template <typename T, int TM, int TN, int NWM, int BN, int PWE = 0>
+__device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v (&acc)[TM][TN], unsigned char* smem, int tid, int row0,
+                                              int col0, int n0, int wm, int cls, int mblocks, int mb, int M, int HW,
+                                              int pn = 0, int py0 = 0, int px0 = 0) {
+  const seg_geom& g = p.g;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
+  float* sst = reinterpret_cast<float*>(smem + STG_BYTES);   // [NWM][BN][2]
+  const float* bias = p.bias;
+  T* out = (T*)p.out;
+  const bool do_stats = p.stats != nullptr;
+  float s_sum[TN], s_sq[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) { s_sum[b] = 0.f; s_sq[b] = 0.f; }
+  // rows this lane stores: (lane >> 2) + 16 * pass within each 32-row tile, 8 channels (lane & 3) * 8 ..
+  const int st_row = lane >> 2, st_ch = lane & 3;
+  // destination of each 32-column tile: the single output, or one span of the split output (wave-uniform)
+  T* obase[TN];
+  const T* ybase[TN];            // output of the layer whose activation derivative multiplies this span (or null)
+  int ocs[TN], ocol[TN], olim[TN], oacc[TN], dact[TN];
+  float dalpha[TN];
+  bool any_acc = false, any_y = false;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int nbase = n0 + col0 + b * 32;
+    obase[b] = out;
+    ybase[b] = nullptr;
+    dact[b] = SEG_ACT_NONE;
+    dalpha[b] = 0.f;
+    ocs[b] = p.out_cs; ocol[b] = p.out_coff + nbase; olim[b] = p.n_rows - nbase; oacc[b] = p.accumulate;
+    if (p.nout > 0) {
+      int start = 0;
+      obase[b] = nullptr;
+      olim[b] = 0;
+      for (int o = 0; o < p.nout; ++o) {
+        if (nbase >= start && nbase < start + p.out_span[o]) {
+          obase[b] = (T*)p.out_ptr[o];
+          ocs[b] = p.out_cs_o[o];
+          ocol[b] = nbase - start;
+          olim[b] = p.out_cs_o[o] - ocol[b];
+          oacc[b] = p.out_acc[o];
+          ybase[b] = (const T*)p.out_y[o];
+          dact[b] = p.out_dact[o];
+          dalpha[b] = p.out_dalpha[o];
+        }
+        start += p.out_span[o];
+      }
+    }
+    any_acc |= oacc[b] != 0;
+    any_y |= ybase[b] != nullptr;
+  }
+  long opix[TM][2];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      if constexpr (PWE > 0) {
+        const int r = st_row + 16 * ps;
+        const int yy = row0 + (PWE == 32 ? a : 2 * a + (r >> 4)), xx = PWE == 32 ? r : (r & 15);
+        opix[a][ps] = ((long)pn * g.Hout + ((py0 + yy) * g.osy + g.oy[cls])) * g.Wout + ((px0 + xx) * g.osx + g.ox[cls]);
+      } else {
+        int m = row0 + a * 32 + st_row + 16 * ps;
+        if (m < M) {
+          int n = m / HW;
+          int rem = m - n * HW;
+          int i = rem / g.Wl;
+          int j = rem - i * g.Wl;
+          opix[a][ps] = ((long)n * g.Hout + (i * g.osy + g.oy[cls])) * g.Wout + (j * g.osx + g.ox[cls]);
+        } else {
+          opix[a][ps] = -1;
+        }
+      }
+    }
+  // accumulating outputs (data gradients summed over the consumers of a tensor): fetch every old value up front, so
+  // the read-modify-write costs one memory latency per block instead of one per 32x32 tile and row pass
+  // (in groups of two 32-row tiles: 16 registers per tile row)
+  constexpr int AG = TM > 2 ? 2 : TM;
+  typename Raw8<T>::type oldv[AG][TN][2], yv[AG][TN][2];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    if ((any_acc || any_y) && a % AG == 0) {
+#pragma unroll
+      for (int a2 = 0; a2 < AG; ++a2)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            Raw8<T>::zero(oldv[a2][b][ps]);
+            Raw8<T>::zero(yv[a2][b][ps]);
+            if (opix[a + a2][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b]) {
+              const size_t eo = (size_t)opix[a + a2][ps] * ocs[b] + ocol[b] + st_ch * 8;
+              if (oacc[b]) Raw8<T>::load(obase[b] + eo, oldv[a2][b][ps]);
+              if (ybase[b] != nullptr) Raw8<T>::load(ybase[b] + eo, yv[a2][b][ps]);
+            }
+          }
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int nbase = n0 + col0 + b * 32;
+      const int ncol = nbase + fr;
+      float bv = 0.f;
+      if (bias != nullptr && ncol < p.n_rows) bv = bias[ncol];
+      const bool nzero = ncol >= p.n_valid;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rt = (q & 3) + 8 * (q >> 2) + 4 * fh;
+        float v = acc[a][b][q] + bv;
+        if (do_stats) {
+          const int m = row0 + a * 32 + rt;
+          if (PWE > 0 || m < M) { s_sum[b] += v; s_sq[b] += v * v; }
+        }
+        v = seg_act(v, p.act, p.alpha);
+        if (nzero) v = 0.f;
+        stg[rt * STG_LD + fr] = v;
+      }
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int rt = st_row + 16 * ps;
+        f4 v0 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8]);
+        f4 v1 = *reinterpret_cast<const f4*>(&stg[rt * STG_LD + st_ch * 8 + 4]);
+        if (opix[a][ps] >= 0 && obase[b] != nullptr && st_ch * 8 < olim[b]) {
+          T* dst = obase[b] + (size_t)opix[a][ps] * ocs[b] + ocol[b] + st_ch * 8;
+          float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if (any_y && ybase[b] != nullptr) {
+            float yf[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) yf[t] = 0.f;
+            Raw8<T>::add(yv[a % AG][b][ps], yf);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) f[t] *= seg_act_grad_from_out(yf[t], dact[b], dalpha[b]);
+          }
+          if (any_acc) Raw8<T>::add(oldv[a % AG][b][ps], f);
+          store8(dst, f);
+        }
+      }
+    }
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      float s = s_sum[b] + __shfl_xor(s_sum[b], 32);
+      float q = s_sq[b] + __shfl_xor(s_sq[b], 32);
+      if (fh == 0) {
+        int col = col0 + b * 32 + fr;
+        sst[(wm * BN + col) * 2 + 0] = s;
+        sst[(wm * BN + col) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      int ncol = n0 + tid;
+      if (ncol < p.n_rows) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) { s += sst[(w * BN + tid) * 2 + 0]; q += sst[(w * BN + tid) * 2 + 1]; }
+        size_t part = (size_t)cls * mblocks + mb;
+        p.stats[(part * 2 + 0) * p.n_rows + ncol] = s;
+        p.stats[(part * 2 + 1) * p.n_rows + ncol] = q;
+      }
+    }
+  }
+}
+
+constexpr unsigned OOB_OFF = 0x60000000u;   // beyond any legal byte offset (operands are checked to be < 1 GiB)
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+bool check_geom(const seg_geom& g, const char* who) {
+  if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Hl <= 0 || g.Wl <= 0 || g.Hout <= 0 || g.Wout <= 0) {
+    seg_set_error("%s: non-positive dimension", who);
+    return false;
+  }
+  if (g.ncls < 1 || g.ncls > SEG_MAX_CLS || g.ntaps < 1 || g.ncls * g.ntaps > SEG_MAX_TAPS) {
+    seg_set_error("%s: ncls=%d ntaps=%d out of range", who, g.ncls, g.ntaps);
+    return false;
+  }
+  for (int c = 0; c < g.ncls; ++c) {
+    long ymax = (long)(g.Hl - 1) * g.osy + g.oy[c], xmax = (long)(g.Wl - 1) * g.osx + g.ox[c];
+    if (g.oy[c] < 0 || g.ox[c] < 0 || ymax >= g.Hout || xmax >= g.Wout) {
+      seg_set_error("%s: class %d output coordinates leave the output tensor", who, c);
+      return false;
+    }
+  }
+  for (int e = 0; e < g.ncls * g.ntaps; ++e)
+    if (g.tap_w[e] < 0 || g.tap_w[e] >= g.T_total) {
+      seg_set_error("%s: tap %d weight index %d outside T_total=%d", who, e, g.tap_w[e], g.T_total);
+      return false;
+    }
+  if ((long)g.N * g.Hl * g.Wl >= (1L << 31) || (long)g.N * g.Hin * g.Win >= (1L << 31)) {
+    seg_set_error("%s: pixel count overflows int32", who);
+    return false;
+  }
+  return true;
+}
+
+template <typename Args>
+bool check_segs(const Args& a, const char* who) {
+  if (a.nseg < 1 || a.nseg > SEG_MAX_SEG) { seg_set_error("%s: nseg=%d", who, a.nseg); return false; }
+  for (int s = 0; s < a.nseg; ++s) {
+    if (a.seg_ptr[s] == nullptr || a.seg_c[s] <= 0 || (a.seg_c[s] & 7) || (a.seg_cs[s] & 7) || a.seg_c[s] > a.seg_cs[s] ||
+        (a.seg_woff[s] & 31) || a.seg_woff[s] + ((a.seg_c[s] + 31) & ~31) > a.Kpad) {
+      seg_set_error("%s: bad segment %d (c=%d cs=%d woff=%d Kpad=%d)", who, s, a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.Kpad);
+      return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+// halo-tile (variant 3) forward launcher, igemm_halo.hip
+int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st);
