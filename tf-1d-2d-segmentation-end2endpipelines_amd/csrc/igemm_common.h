@@ -356,3 +356,5 @@ bool check_segs(const Args& a, const char* who) {
 
 // halo-tile (variant 3) forward launcher, igemm_halo.hip
 int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st);
+// its software-pipelined generation (igemm_halo2.hip); called by seg_launch_fwd3 after the argument checks
+int seg_launch_fwd4(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st);

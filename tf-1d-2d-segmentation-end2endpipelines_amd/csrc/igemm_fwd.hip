@@ -467,9 +467,9 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
                     "seg_igemm_fwd: span %d: fused activation backward needs an output tensor and act in RELU..SIGMOID (got %d)", o, a->out_dact[o]);
   }
   SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_fwd: Kpad=%d not a multiple of 32", a->Kpad);
-  SEG_CHECK_ARG(a->variant == 0 || a->variant == 3, "seg_igemm_fwd: variant=%d", a->variant);
+  SEG_CHECK_ARG((a->variant & 255) == 0 || (a->variant & 255) == 3, "seg_igemm_fwd: variant=%d", a->variant);
   SEG_CHECK_ARG(a->act >= SEG_ACT_NONE && a->act <= SEG_ACT_SIGMOID, "seg_igemm_fwd: act=%d", a->act);
-  if (a->variant == 3) {
+  if ((a->variant & 255) == 3) {      // (bits 8.. : timing-experiment switches of the pipelined halo kernel, igemm_halo2.hip)
     SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_fwd: variant 3 (halo tiles) is fp16 only");
     if constexpr (sizeof(T) == 2) return seg_launch_fwd3(*a, (hipStream_t)stream);
   }

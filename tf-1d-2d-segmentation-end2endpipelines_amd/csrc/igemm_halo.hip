@@ -346,6 +346,18 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   const int npatch = (int)((long)a.g.N * a.g.Hl * a.g.Wl / 256);
   const int nblocks = (a.n_rows + a.tile_n - 1) / a.tile_n;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)a.g.ncls, 1);
+  // the software-pipelined generation (igemm_halo2.hip).  Measured on MI355X (tools/op_bench.py, same box, C3 layers):
+  // transposed conv forward 4-6 % faster (its blocks run class-fastest, so the four classes of a patch share the halo tile
+  // in L2) and its data gradient 0-3 %; the 3x3 layers 1-3 % SLOWER on the 128-channel tile and equal on the 64-channel
+  // tile - reading fragments ahead does not pay there: the in-order issue stream (LDS-DMA, ds_read, address VALU) is what
+  // bounds the kernel, not the exposed ds_read latency (ablations in DESIGN.md section 4).  SEG_FWD_PIPE=0 / 1 forces one.
+  static const char* pipe_env = std::getenv("SEG_FWD_PIPE");
+  const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : (a.g.ntaps != 9);
+  if (pipe || (a.variant >> 8) != 0) {
+    seg_launch_fwd4(a, pw, grid, st);
+    SEG_CHECK_LAUNCH("seg_igemm_fwd (halo tiles, pipelined)");
+    return SEG_OK;
+  }
   if (a.g.ntaps == 16) launch_fwd3_nt<4, 1, 2, 4>(a, pw, grid, st);
   else if (a.g.ntaps == 9) launch_fwd3_nt<9, 1, 3>(a, pw, grid, st);
   else launch_fwd3_nt<4, 1, 2>(a, pw, grid, st);

@@ -243,7 +243,8 @@ def fit(model, train_batches, epochs: int, val_batches=None,
             logs.update(ms.result())
         if val_batches is not None:
             logs.update({"val_" + k: v for k, v in evaluate(model, val_batches, return_dict=True).items()})
-        logs["nonfinite_grads"] = float(skipped)
+        if skipped or _dist() is not None:       # (every rank must bring the same keys to the reduction)
+            logs["nonfinite_grads"] = float(skipped)
         logs = sync_logs(logs)                   # data parallel: every rank's callbacks see the mean over the shards
         for cb in callbacks:
             cb.on_epoch_end(epoch, logs, state)

@@ -340,6 +340,8 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
         if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
             return 256, tn, 3
     tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
+    if not f16 and tm == 256:          # the 256-row tile exists on the fp16 LDS-DMA kernels only
+        tm, tn = 128, 64
     return tm, tn, 0
 
 

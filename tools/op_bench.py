@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--bk", default="")
     ap.add_argument("--splitk", default="")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dbg", default="", help="comma list of timing-experiment bit masks for the pipelined halo kernel (fwd / dgrad phases; results are wrong)")
     args = ap.parse_args()
     pkg = importlib.import_module(PKG)
     M = importlib.import_module(PKG + ".model")
@@ -72,6 +73,13 @@ def main():
                 fn = lambda: M.call("seg_igemm_wgrad", C.byref(a), s)
             t0 = (a.tile_m, a.tile_n)
             sk0 = a.splitk if ph == "wgrad" else None
+            if args.dbg and ph != "wgrad" and (a.variant & 255) == 3:
+                for d in [int(v) for v in args.dbg.split(",")]:
+                    a.variant = 3 | (d << 8)
+                    us = timeit(fn)
+                    print(f"{name:16s} {ph:6s} tile {a.tile_m}x{a.tile_n} dbg {d:2d}: {us:8.1f} us  {fl / us / 1e6:7.0f} TF", flush=True)
+                a.variant = 3
+                continue
             for tile in tiles:
                 for bk in (bks if ph != "wgrad" else [None]):
                     for sk in (sks if ph == "wgrad" else [None]):
