@@ -65,6 +65,63 @@ __device__ __forceinline__ void mma_step(const unsigned char* A, const unsigned 
         }
   }
 }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// ---- fp32 operands contracted on the fp16 MFMA ("split" form of the exact mode, 3 MFMAs per product instead of the
+// 1/16-rate v_mfma_f32_32x32x2_f32): x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048) - the residual is
+// exact in fp32 and scaled into fp16's normal range, so hi + lo / 2048 carries ~22 significant bits of x.  Products of fp16
+// values are exact in the fp32 accumulator: a b ~= ah bh + (al bh + ah bl) / 2048 (the al bl term, 2^-22 relative, is
+// dropped); the two sums live in separate accumulators and are combined once at the end.  An LDS row (one K step of 16
+// fp32 values) holds [16 hi | 16 lo] halves = the same 64 B as the 16 floats.
+constexpr float SPLIT_SCALE = 2048.f;
+__device__ __forceinline__ void split4(const u4& raw, h4& hi, h4& lo) {
+  const f4 x = __builtin_bit_cast(f4, raw);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (half_t)x[i];
+    lo[i] = (half_t)((x[i] - (float)hi[i]) * SPLIT_SCALE);
+  }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void mma_step_split(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
+                                               f16v (&acc)[TM][TN], f16v (&accl)[TM][TN]) {
+  const int fswz = (fr >> 2) & 3;
+  const int ch = (fh ^ fswz) << 4, cl = ((2 + fh) ^ fswz) << 4;       // chunks 0,1: hi (k = 8 fh ..), chunks 2,3: lo
+  h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const unsigned char* r = A + (a_row0 + a * 32 + fr) * ROW_BYTES;
+    ah[a] = *reinterpret_cast<const h8*>(r + ch);
+    al[a] = *reinterpret_cast<const h8*>(r + cl);
+  }
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const unsigned char* r = B + (b_row0 + b * 32 + fr) * ROW_BYTES;
+    bh[b] = *reinterpret_cast<const h8*>(r + ch);
+    bl[b] = *reinterpret_cast<const h8*>(r + cl);
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+      accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], accl[a][b], 0, 0, 0);
+      accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
+    }
+}
+// LDS store of 4 consecutive fp32 K values (16-B chunk `chunk` of a row) in the split row format
+__device__ __forceinline__ void split_store(unsigned char* tile, int row, int chunk, const u4& raw) {
+  h4 hi, lo;
+  split4(raw, hi, lo);
+  const int sub = (chunk & 1) * 8;
+  *reinterpret_cast<h4*>(tile + lds_off(row, chunk >> 1) + sub) = hi;
+  *reinterpret_cast<h4*>(tile + lds_off(row, 2 + (chunk >> 1)) + sub) = lo;
+}
+inline bool f32_split_enabled() {
+  static const bool exact = std::getenv("SEG_F32_EXACT") != nullptr && std::atoi(std::getenv("SEG_F32_EXACT")) != 0;
+  return !exact;
+}
+
 constexpr int STG_LD = 36;        // floats per staging row (32 + 4 pad, keeps 16-B alignment)
 constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;   // 4 waves
 
@@ -76,7 +133,6 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 // 64-deep K step on 128-B LDS rows (fp16): 8 chunks per row, chunk index XOR (row >> 1) & 7, so that the 16 rows a
 // ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.  4 x (TM x TN) MFMAs.

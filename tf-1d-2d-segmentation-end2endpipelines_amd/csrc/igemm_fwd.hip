@@ -16,8 +16,9 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args p) {
+  static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 contraction is the fp32 mode's");
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int EPC = ET<T>::EPC, BK = 4 * EPC;      // elements per 16-B chunk / per K step
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
@@ -68,6 +69,15 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  f16v accl[SPLIT ? TM : 1][SPLIT ? TN : 1];      // split mode: the (lo x hi + hi x lo) sums, scaled by 2048
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accl[a][b][q] = 0.f;
+  }
 
   int niter = 0;
   for (int s = 0; s < p.nseg; ++s) niter += ((p.seg_c[s] + BK - 1) / BK) * g.ntaps;
@@ -103,15 +113,23 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
   auto lstore = [&](int buf) {
     unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* B = A + A_BYTES;
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int r = 0; r < TM; ++r) st16(A + lds_off(ld_row + 64 * r, ld_ch), ra[r]);
+      for (int r = 0; r < TM; ++r) split_store(A, ld_row + 64 * r, ld_ch, ra[r]);
 #pragma unroll
-    for (int r = 0; r < TN; ++r) st16(B + lds_off(ld_row + 64 * r, ld_ch), rb[r]);
+      for (int r = 0; r < TN; ++r) split_store(B, ld_row + 64 * r, ld_ch, rb[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < TM; ++r) st16(A + lds_off(ld_row + 64 * r, ld_ch), ra[r]);
+#pragma unroll
+      for (int r = 0; r < TN; ++r) st16(B + lds_off(ld_row + 64 * r, ld_ch), rb[r]);
+    }
   };
   const int fr = lane & 31, fh = lane >> 5;
   auto compute = [&](int buf) {
     const unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
-    mma_step<T, TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
+    if constexpr (SPLIT) mma_step_split<TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc, accl);
+    else mma_step<T, TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
   };
 
   // ---- main loop: iteration order (segment, channel chunk, tap) with taps innermost
@@ -135,6 +153,14 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
     __syncthreads();
   }
 
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][b][q] += accl[a][b][q] * (1.f / SPLIT_SCALE);
+  }
   conv_epilogue<T, TM, TN, 2, BN>(p, acc, smem, tid, m0 + wm * (BM / 2), wn * (BN / 2), n0, wm, cls, mblocks, mb, M, HW);
 }
 
@@ -488,6 +514,16 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
     if (fwd2_eligible(*a)) return launch_fwd2(*a, mblocks, nblocks, st);
   }
   SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (fp16, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
+  if constexpr (sizeof(T) == 4) {
+    if (f32_split_enabled()) {      // exact mode on the fp16 MFMA: 3 split products per fp32 product (SEG_F32_EXACT=1: the fp32 fma-chain MFMA)
+      if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 128, true>), grid, block, lds, st, *a);
+      else if (a->tile_m == 128 && a->tile_n == 64) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 64, true>), grid, block, lds, st, *a);
+      else if (a->tile_m == 64 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 128, true>), grid, block, lds, st, *a);
+      else hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 64, true>), grid, block, lds, st, *a);
+      SEG_CHECK_LAUNCH("seg_igemm_fwd (split fp16)");
+      return SEG_OK;
+    }
+  }
   if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 128>), grid, block, lds, st, *a);
   else if (a->tile_m == 128 && a->tile_n == 64) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 64>), grid, block, lds, st, *a);
   else if (a->tile_m == 64 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 128>), grid, block, lds, st, *a);

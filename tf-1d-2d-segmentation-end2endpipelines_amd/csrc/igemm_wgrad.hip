@@ -9,8 +9,9 @@ namespace {
 // Both operands are "reduction-major" in memory, so their MFMA fragments are read with the hardware
 // transposing LDS read ds_read_b64_tr_b16 (VARIANT 0) or transposed while being stored to LDS (VARIANT 1).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int VARIANT>
+template <typename T, int BM, int BN, int VARIANT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
+  static_assert(!SPLIT || (sizeof(T) == 4 && VARIANT == 1), "the split-fp16 contraction is the fp32 mode's (transposing-store form)");
   static_assert(sizeof(T) == 2 || VARIANT == 1, "the transposing LDS read exists for 16-bit elements only");
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int EPC = ET<T>::EPC;
@@ -86,6 +87,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  f16v accl[SPLIT ? TM : 1][SPLIT ? TN : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accl[a][b][q] = 0.f;
+  }
 
   u4 rz[ZPT], ra[APT];
   auto gload = [&](int pb) {
@@ -133,7 +143,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
 #pragma unroll
         for (int t = 0; t < EPC; ++t) {
           int row = z_c[r] * EPC + t;
-          *reinterpret_cast<T*>(Z + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
+          if constexpr (SPLIT) {      // row = [16 hi | 16 lo] halves over the step's 16 pixels
+            const half_t hi = (half_t)v[t];
+            *reinterpret_cast<half_t*>(Z + lds_off(row, pp >> 3) + (pp & 7) * 2) = hi;
+            *reinterpret_cast<half_t*>(Z + lds_off(row, 2 + (pp >> 3)) + (pp & 7) * 2) = (half_t)(((float)v[t] - (float)hi) * SPLIT_SCALE);
+          } else {
+            *reinterpret_cast<T*>(Z + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
+          }
         }
       }
 #pragma unroll
@@ -143,7 +159,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
 #pragma unroll
         for (int t = 0; t < EPC; ++t) {
           int row = a_c[r] * EPC + t;
-          *reinterpret_cast<T*>(A + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
+          if constexpr (SPLIT) {
+            const half_t hi = (half_t)v[t];
+            *reinterpret_cast<half_t*>(A + lds_off(row, pp >> 3) + (pp & 7) * 2) = hi;
+            *reinterpret_cast<half_t*>(A + lds_off(row, 2 + (pp >> 3)) + (pp & 7) * 2) = (half_t)(((float)v[t] - (float)hi) * SPLIT_SCALE);
+          } else {
+            *reinterpret_cast<T*>(A + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
+          }
         }
       }
     }
@@ -185,7 +207,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
           for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
     } else {
-      mma_step<T, TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
+      if constexpr (SPLIT) mma_step_split<TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc, accl);
+      else mma_step<T, TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
     }
   };
 
@@ -201,6 +224,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
     __syncthreads();
   }
 
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][b][q] += accl[a][b][q] * (1.f / SPLIT_SCALE);
+  }
   // ---- epilogue: fp32 atomics, lanes 0..31 hit 32 consecutive K columns of one weight row
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
@@ -978,7 +1009,8 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
       if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 0>), grid, block, lds, st, *a);        \
       else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
     } else {                                                                                                      \
-      hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                          \
+      if (f32_split_enabled()) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1, true>), grid, block, lds, st, *a);   \
+      else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
     }                                                                                                             \
   } while (0)
   if (bm == 128 && bn == 128) SEG_WG(128, 128);
