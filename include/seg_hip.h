@@ -138,6 +138,11 @@ typedef struct seg_igemm_wgrad_args {
                                     engine clears the gradient buffer once per step), so the single writer of each tile
                                     stores instead of read-modify-writing - deep layers (8x8 / 16x16 images, 2048-channel
                                     kernels) are otherwise bound by that epilogue.  0: always accumulate                  */
+  float* partial;                /* optional workspace for a DETERMINISTIC pixel split, fp32 [splitk][n_rows * T_total * Kpad],
+                                    zero-filled once by the caller and owned by this layer: with splitk > 1 every block stores
+                                    its partial tile there (plain stores, no atomics) and a second launch inside this call adds
+                                    scale * sum_z partial[z] to dw in a fixed order - two runs give bit-identical gradients.
+                                    NULL: split blocks add into dw with float atomics (order-dependent last bits).            */
 } seg_igemm_wgrad_args;
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
 /* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */

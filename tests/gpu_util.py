@@ -99,7 +99,7 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
 
 
 def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=None, tile=None, f32=False, bias_parts=False,
-                overwrite=0, prefill=0.0):
+                overwrite=0, prefill=0.0, partial=False, raw=False):
     """Returns dW in Keras layout (numpy).  prefill: what dw holds before the launch (the launch accumulates unless overwrite)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kshape[:2]
@@ -132,12 +132,18 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
     a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)
     a.scale, a.scale_ptr, a.variant = 1.0, None, variant
     a.overwrite = overwrite
+    ws = None
+    if partial:                    # deterministic pixel split: per-layer workspace, zero-filled once
+        ws = torch.zeros(a.splitk * n_rows * T * Kpad, dtype=torch.float32, device="cuda")
+        a.partial = ws.data_ptr()
     bp = None
     if bias_parts:
         bp = torch.full((2 * a.splitk, 2, n_rows), 1e30, dtype=torch.float32, device="cuda")
         a.bias_part = bp.data_ptr()
     ffi.call("seg_igemm_wgrad_f32" if f32 else "seg_igemm_wgrad", C.byref(a), stream())
     torch.cuda.synchronize()
+    if raw:
+        return dw.cpu()
     w = M.unpack_gemm_weight(dw.cpu().numpy(), kshape, cin_l, woff, n_rows, Kpad, transposed)
     if bias_parts:
         assert float(bp[:, 1].abs().max()) == 0.0

@@ -165,3 +165,22 @@ def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg):
     assert all(np.isfinite(losses)), losses
     assert losses[3] < losses[0], (cfg, losses)
     assert model.nonfinite_updates() == 0              # no fp16 overflow anywhere in the backward pass at this depth / width
+
+
+def test_training_is_bit_reproducible_at_the_headline_config():
+    """Two runs of three optimiser steps of C3 at its BASELINE batch leave bit-identical parameters: the pixel-split weight
+    gradients go through per-layer partial tiles and an ordered reduce instead of float atomics (SEG_WGRAD_DETERMINISTIC)."""
+    def run():
+        torch.manual_seed(5)
+        model, x, targets, loss = CONFIGS["C3"](16)
+        model.build(16, dtype="f16")
+        model.compile(loss=loss, lr=2e-4)
+        assert any(op.wg_partial is not None for op in model.ops if hasattr(op, "wg_partial"))
+        for _ in range(3):
+            model.train_step(x, targets)
+        model._join_side()
+        torch.cuda.synchronize()
+        return model.store.P.clone(), model.store.S.clone()
+    p0, s0 = run()
+    p1, s1 = run()
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)

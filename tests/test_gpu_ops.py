@@ -950,6 +950,28 @@ def test_adam_matches_keras_adam_three_steps():
     assert torch.equal(p16.cpu(), p.cpu().half())
 
 
+@pytest.mark.parametrize("kind,variant,f32", [("conv", 2, False), ("convT", 2, False), ("conv", 0, False), ("conv", 1, True)])
+def test_deterministic_pixel_split_of_the_weight_gradient(kind, variant, f32):
+    """splitk > 1 with a partial-tile workspace: same gradient as the atomic form (to summation-order rounding), identical
+    bits on every run, and it accumulates into what dw already holds."""
+    torch.manual_seed(3)
+    N, H, W, cin, cout = 4, 32, 32, 72, 40
+    xs = [torch.randn(N, H, W, cin)]
+    if kind == "convT":
+        kshape, st = (4, 4, cout, cin), (2, 2)
+        dz = torch.randn(N, 2 * H, 2 * W, cout)
+    else:
+        kshape, st = (3, 3, cin, cout), (1, 1)
+        dz = torch.randn(N, H, W, cout)
+    kw = dict(kind=kind, strides=st, variant=variant, splitk=4, f32=f32)
+    atomic = U.igemm_wgrad(xs, dz, kshape, prefill=0.5, **kw)
+    runs = [U.igemm_wgrad(xs, dz, kshape, prefill=0.5, partial=True, raw=True, **kw) for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])                 # bit-identical run to run
+    det = U.igemm_wgrad(xs, dz, kshape, prefill=0.5, partial=True, **kw)
+    scale = float(np.abs(atomic).max())
+    assert float(np.abs(det - atomic).max()) < 2e-5 * scale
+
+
 def test_bf16_gradient_operand_nonfinite_counter_and_pack():
     """seg_cast_f32_bf16 == torch's round-to-nearest-even (NaN / Inf kept); seg_adam_step_ex with a bf16 gradient equals the
     fp32 form on the widened values; NaN / Inf gradients are skipped AND counted."""

@@ -52,7 +52,7 @@ class IgemmWgradArgs(C.Structure):
                 ("dz_cs", C.c_int32), ("dz_coff", C.c_int32), ("dw", C.c_void_p), ("Kpad", C.c_int32),
                 ("n_rows", C.c_int32), ("splitk", C.c_int32), ("scale", C.c_float), ("scale_ptr", C.c_void_p),
                 ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("variant", C.c_int32), ("bias_part", C.c_void_p),
-                ("overwrite", C.c_int32)]
+                ("overwrite", C.c_int32), ("partial", C.c_void_p)]
 
 
 class TransposeDesc(C.Structure):

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
   float* dw = p.dw;
+  float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
           const int row = r0 + wm * (BM / 2) + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
           if (row < p.n_rows) {
             size_t off = ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol;
-            atomicAdd(dw + off, acc[a][b][q] * sc_mul);
+            if (part != nullptr) part[off] = acc[a][b][q];          // deterministic split: reduced in order by wgrad_reduce_kernel
+            else atomicAdd(dw + off, acc[a][b][q] * sc_mul);
           }
         }
       }
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_mt_kernel(const seg_igemm_
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
   float* dw = p.dw;
+  float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NTB; ++t)
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_mt_kernel(const seg_igemm_
           const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
           if (row < p.n_rows) {
             size_t off = ((size_t)row * g.T_total + t_w[t]) * p.Kpad + p.seg_woff[seg] + kcol;
-            atomicAdd(dw + off, acc[t][b][q] * sc_mul);
+            if (part != nullptr) part[off] = acc[t][b][q];
+            else atomicAdd(dw + off, acc[t][b][q] * sc_mul);
           }
         }
       }
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
   float* dw = p.dw;
+  float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
   const int fr = lane & 31, fh = lane >> 5;
   const int kcol = c0 + wn * 32 + fr;
   if (kcol < sc) {
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
             if (p.overwrite) *d = acc[t][q] * sc_mul;          // when the caller vouches that dw holds zeros
             else *d += acc[t][q] * sc_mul;
           }
+          else if (part != nullptr) part[d - dw] = acc[t][q];   // deterministic split: reduced in order by wgrad_reduce_kernel
           else atomicAdd(d, acc[t][q] * sc_mul);
         }
       }
@@ -826,6 +832,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
   float* dw = p.dw;
+  float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
   const int fr = lane & 31, fh = lane >> 5;
   if (do_bias && fr == 0) {          // every column of accb holds the same sums: lanes of column 0 write the partial row
     float* rowp = p.bias_part + ((size_t)(py * p.splitk + bz) * 2) * p.n_rows;
@@ -852,6 +859,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
             if (p.overwrite) *d = acc[t][q] * sc_mul;          // when the caller vouches that dw holds zeros
             else *d += acc[t][q] * sc_mul;
           }
+          else if (part != nullptr) part[d - dw] = acc[t][q];   // deterministic split: reduced in order by wgrad_reduce_kernel
           else atomicAdd(d, acc[t][q] * sc_mul);
         }
       }
@@ -869,6 +877,54 @@ template __global__ void igemm_wgrad_halo_kernel<32, true>(const seg_igemm_wgrad
 template __global__ void igemm_wgrad_halo_kernel<16, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<8, false>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_kernel<8, true>(const seg_igemm_wgrad_args);
+
+// second pass of the deterministic pixel split: dw[i] += scale * sum_z partial[z][i], summed in a FIXED order: G lanes
+// share a float4 position (lane g adds z = g, g + G, ... in ascending order), then a butterfly over the G lanes - the same
+// tree on every run.  G > 1 keeps layers with few weights and many splits (first layer: 18 K weights x 256 splits) parallel.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int splitk, long numel, float* dw, float scale, const float* scale_ptr) {
+  if (scale_ptr != nullptr) scale *= *scale_ptr;
+  const long n4 = numel >> 2;
+  const int g = threadIdx.x % G;
+  const long stride = (long)gridDim.x * (256 / G);
+  const long iters = (n4 + stride - 1) / stride;                  // every lane runs the same trip count (the shuffles need all G lanes)
+  long i = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  for (long it = 0; it < iters; ++it, i += stride) {
+    const bool ok = i < n4;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      for (int z = g; z < splitk; z += G) {
+        const f4 v = *reinterpret_cast<const f4*>(partial + (size_t)z * numel + 4 * i);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+      }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+      s[0] += __shfl_xor(s[0], o); s[1] += __shfl_xor(s[1], o); s[2] += __shfl_xor(s[2], o); s[3] += __shfl_xor(s[3], o);
+    }
+    if (ok && g == 0) {
+      f4 d = *reinterpret_cast<const f4*>(dw + 4 * i);
+      d[0] += s[0] * scale; d[1] += s[1] * scale; d[2] += s[2] * scale; d[3] += s[3] * scale;
+      *reinterpret_cast<f4*>(dw + 4 * i) = d;
+    }
+  }
+}
+
+int launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st) {
+  if (a.partial == nullptr || a.splitk <= 1) return SEG_OK;
+  const long numel = (long)a.n_rows * a.g.T_total * a.Kpad;          // Kpad is a multiple of 32: whole float4 groups
+  if (a.splitk >= 32) {
+    long blocks = (numel / 4 + 31) / 32;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a.partial, a.splitk, numel, a.dw, a.scale, a.scale_ptr);
+  } else {
+    long blocks = (numel / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, a.partial, a.splitk, numel, a.dw, a.scale, a.scale_ptr);
+  }
+  SEG_CHECK_LAUNCH("seg_igemm_wgrad (split reduce)");
+  return SEG_OK;
+}
 
 }  // namespace
 
@@ -939,6 +995,7 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
                     a->dz_coff + a->n_rows <= a->dz_cs,
                 "seg_igemm_wgrad: n_rows=%d dz_cs=%d dz_coff=%d", a->n_rows, a->dz_cs, a->dz_coff);
   SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_wgrad: Kpad=%d", a->Kpad);
+  SEG_CHECK_ARG(a->partial == nullptr || (((uintptr_t)a->partial | (uintptr_t)a->dw) & 15) == 0, "seg_igemm_wgrad: partial / dw must be 16-byte aligned for the split reduce");
   SEG_CHECK_ARG((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64),
                 "seg_igemm_wgrad: tile %dx%d", a->tile_m, a->tile_n);
   SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "seg_igemm_wgrad: splitk=%d", a->splitk);
@@ -978,7 +1035,7 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
 #undef SEG_HALO_PC
     }
     SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
-    return SEG_OK;
+    return launch_wgrad_reduce(*a, (hipStream_t)stream);
   }
   const int variant = (sizeof(T) == 4) ? 1 : a->variant;      // fp32: transposing-store form only
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
@@ -996,7 +1053,7 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
       else if (a->tile_n == 128 && ntb == 4) hipLaunchKernelGGL((igemm_wgrad_mt_kernel<128, 4>), gridm, dim3(256), ldsm, stm, *a);
       else hipLaunchKernelGGL((igemm_wgrad_mt_kernel<128, 3>), gridm, dim3(256), ldsm, stm, *a);
       SEG_CHECK_LAUNCH("seg_igemm_wgrad (multi-tap)");
-      return SEG_OK;
+      return launch_wgrad_reduce(*a, (hipStream_t)stream);
     }
   }
   dim3 grid((unsigned)(rtiles * ktiles), (unsigned)(a->g.ncls * a->g.ntaps), (unsigned)a->splitk), block(256, 1, 1);
@@ -1019,7 +1076,7 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   else SEG_WG(64, 64);
 #undef SEG_WG
   SEG_CHECK_LAUNCH("seg_igemm_wgrad");
-  return SEG_OK;
+  return launch_wgrad_reduce(*a, st);
 }
 extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream) { return igemm_wgrad_launch<half_t>(a, stream); }
 extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream) { return igemm_wgrad_launch<float>(a, stream); }

@@ -43,6 +43,7 @@ GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before t
 WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
 WGRAD_OVERWRITE = os.environ.get("SEG_WGRAD_OVERWRITE", "1") != "0"   # single-writer weight-gradient tiles store into the cleared buffer
 WGRAD_HALO = os.environ.get("SEG_WGRAD_HALO", "1") != "0"      # variant 2 (LDS-DMA halo tiles) for the 3x3 stride-1 layers
+WGRAD_DETERMINISTIC = os.environ.get("SEG_WGRAD_DETERMINISTIC", "1") != "0"   # pixel-split weight gradients through per-layer partial tiles + an ordered reduce (no float atomics)
 
 
 def _r8(v):
@@ -668,6 +669,12 @@ class ConvOp(Op):
         # the gradient buffer is cleared once per step (backward() / the side stream after the optimiser), and with
         # splitk == 1 every tile has one writer: it may store instead of read-modify-write
         wg.overwrite = 1 if (WGRAD_OVERWRITE and variant == 2 and sk == 1) else 0
+        # deterministic pixel split: the split blocks store partial tiles into this layer's own workspace (zero-filled once;
+        # positions no block writes stay zero) and a second launch inside seg_igemm_wgrad adds them up in a fixed order
+        self.wg_partial = None
+        if WGRAD_DETERMINISTIC and sk > 1:
+            self.wg_partial = torch.zeros(sk * self.n_rows * self.T * self.Kpad, dtype=torch.float32, device=_dev())
+            wg.partial = self.wg_partial.data_ptr()
         # transposed convs on the class-pair kernel: the bias gradient (column sums of dz) comes out of the weight-gradient
         # launch as per-block partial rows instead of a separate pass over dz
         self.bias_from_wgrad = (BIAS_FROM_WGRAD and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
