@@ -12,6 +12,7 @@ from .builders1d import BCDUNet
 from .builders1d import UNet as UNet1D
 from . import harness
 from . import data
+from . import keras_map
 from .data import CustomDataGenerator, prepare_train_dict, create_patches, patchify, unpatchify
 from .harness import (EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, fit, masks_from_predictions, mask_grey_levels,
                       predict_directory)
@@ -19,5 +20,5 @@ from .harness import (EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, fit, ma
 __all__ = ["Graph", "Node", "ParamSpec", "Sym", "unet_model_builder", "model_selector", "ENCODER_METHODS",
            "SUPPORTED_DECODERS", "builders1d", "BCDUNet", "UNet1D", "harness", "EarlyStopping", "ModelCheckpoint",
            "ReduceLROnPlateau", "fit", "masks_from_predictions", "mask_grey_levels", "predict_directory", "data",
-           "CustomDataGenerator", "prepare_train_dict", "create_patches", "patchify", "unpatchify"]
+           "CustomDataGenerator", "prepare_train_dict", "create_patches", "patchify", "unpatchify", "keras_map"]
 __version__ = "0.1.0"
