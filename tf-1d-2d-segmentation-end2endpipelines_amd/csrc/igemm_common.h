@@ -414,3 +414,5 @@ bool check_segs(const Args& a, const char* who) {
 int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st);
 // its software-pipelined generation (igemm_halo2.hip); called by seg_launch_fwd3 after the argument checks
 int seg_launch_fwd4(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st);
+// wave-specialised halo-tile weight gradient (igemm_wgrad2.hip); called by seg_igemm_wgrad after the argument checks
+int seg_launch_wgrad_halo_ws(const seg_igemm_wgrad_args& a, int pc, dim3 grid, hipStream_t st);

@@ -463,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   const int wm = wave >> 1, wn = wave & 1;
   const seg_geom& g = p.g;
   const int H = g.Hin, W = g.Win;
+  // timing experiments (tools/op_bench.py --dbg on the wgrad phase; results are WRONG): 1 no LDS-DMA, 4 no barrier, 8 no MFMA, 16 no epilogue
+  const int dbg = __builtin_amdgcn_readfirstlane(p.variant >> 8);
 
   // ---- which (64-row tile, 64-channel plane, patch range) is this block
   // logical order: patch range (z) slowest, then sub-pixel class (y), then (row tile, plane): every block that reads
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   int py_ = (q0 - pn_ * (PH * PW)) / PW;
   int px_ = q0 - pn_ * (PH * PW) - py_ * PW;
   auto issue = [&](int /*q*/, int stage) {
+    if (dbg & 1) return;
     const int n = pn_, y0 = py_ * R, x0 = px_ * C;
     if (++px_ == PW) {
       px_ = 0;
@@ -606,6 +609,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
         if (TC && !((tmask >> t) & 1u)) continue;                   // wave-uniform
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
         const h8 bf = trfrag(Is + hb * 128 + offB[hb & 3]);
+        if (dbg & 8) { asm volatile("" ::"v"(af), "v"(bf)); continue; }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
       }
     }
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   issue(q0, 0);
   for (int q = q0; q < q1; ++q) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (q + 1 < q1) issue(q + 1, stage ^ 1);
     compute(stage);
@@ -628,6 +632,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
   const int fr = lane & 31, fh = lane >> 5;
   const int kcol = c0 + wn * 32 + fr;
+  if (dbg & 16) {
+    float keep = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) keep += acc[t][0] + acc[t][15];
+    if (keep != 12345.678f) return;
+  }
   if (kcol < sc) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -999,10 +1009,10 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   SEG_CHECK_ARG((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64),
                 "seg_igemm_wgrad: tile %dx%d", a->tile_m, a->tile_n);
   SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "seg_igemm_wgrad: splitk=%d", a->splitk);
-  SEG_CHECK_ARG(a->variant >= 0 && a->variant <= 2, "seg_igemm_wgrad: variant=%d", a->variant);
-  SEG_CHECK_ARG(a->bias_part == nullptr || (a->variant == 2 && seg_wgrad_halo_class_groups(&a->g) == 2),
+  SEG_CHECK_ARG((a->variant & 255) >= 0 && (a->variant & 255) <= 2, "seg_igemm_wgrad: variant=%d", a->variant);
+  SEG_CHECK_ARG(a->bias_part == nullptr || ((a->variant & 255) == 2 && seg_wgrad_halo_class_groups(&a->g) == 2),
                 "seg_igemm_wgrad: bias_part needs variant 2 on a transposed conv of the class-pair kernel");
-  if (a->variant == 2) {
+  if ((a->variant & 255) == 2) {      // (bits 8.. : timing-experiment switches of the halo kernel)
     SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_wgrad: variant 2 (LDS-DMA halo tiles) is fp16 only");
     const int pc = seg_wgrad_halo_patch(&a->g);
     SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 32 == 0 and H %% 2 == 0, W %% 16 == 0 and H %% 4 == 0, or W and H %% 8 == 0");
@@ -1024,7 +1034,17 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
     else if (pc == 16) hipLaunchKernelGGL((KERNEL<16 __VA_ARGS__>), GRID, dim3(256), LDS, sth, *a);              \
     else hipLaunchKernelGGL((KERNEL<8 __VA_ARGS__>), GRID, dim3(256), LDS, sth, *a);                             \
   } while (0)
-      if (a->g.ncls == 1) {
+      // wave-specialised generation (igemm_wgrad2.hip: 4 loader waves + 4 compute waves, 4-stage ring, one block per CU).
+      // Measured (tools/op_bench.py, C3 layers, same box): when the grid has at most ~1 block per CU anyway (deep layers:
+      // few patches, many weight tiles) it is 25-45 % faster than the round-1 kernel (X23 488 -> 352 us, X32 474 -> 339 us,
+      // enc3 92 -> 73 us); when the round-1 kernel can keep two blocks per CU it is 0-12 % slower (X14, X05).
+      // SEG_WGRAD_WS=0 / 1 forces one.
+      static const char* ws_env = std::getenv("SEG_WGRAD_WS");
+      const long nblk = (long)gridh.x * gridh.y * gridh.z;
+      const bool ws = ws_env != nullptr ? std::atoi(ws_env) != 0 : nblk <= 320;
+      if (a->g.ncls == 1 && (ws || (a->variant >> 8) == 0x40)) {
+        seg_launch_wgrad_halo_ws(*a, pc, gridh, sth);
+      } else if (a->g.ncls == 1) {
         SEG_HALO_PC(igemm_wgrad_halo_kernel, gridh, lds1, , false);
       } else if (seg_wgrad_halo_class_groups(&a->g) == 2) {
         dim3 grid2(gridh.x, 2, gridh.z);
@@ -1037,7 +1057,7 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
     SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
     return launch_wgrad_reduce(*a, (hipStream_t)stream);
   }
-  const int variant = (sizeof(T) == 4) ? 1 : a->variant;      // fp32: transposing-store form only
+  const int variant = (sizeof(T) == 4) ? 1 : (a->variant & 255);      // fp32: transposing-store form only
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
   int ktiles = 0;
   for (int s = 0; s < a->nseg; ++s) ktiles += (a->seg_c[s] + a->tile_n - 1) / a->tile_n;

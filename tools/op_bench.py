@@ -73,12 +73,19 @@ def main():
                 fn = lambda: M.call("seg_igemm_wgrad", C.byref(a), s)
             t0 = (a.tile_m, a.tile_n)
             sk0 = a.splitk if ph == "wgrad" else None
-            if args.dbg and ph != "wgrad" and (a.variant & 255) == 3:
-                for d in [int(v) for v in args.dbg.split(",")]:
-                    a.variant = 3 | (d << 8)
-                    us = timeit(fn)
-                    print(f"{name:16s} {ph:6s} tile {a.tile_m}x{a.tile_n} dbg {d:2d}: {us:8.1f} us  {fl / us / 1e6:7.0f} TF", flush=True)
-                a.variant = 3
+            part0 = a.partial if ph == "wgrad" else None
+            if args.dbg and (a.variant & 255) == (2 if ph == "wgrad" else 3):
+                v0 = a.variant & 255
+                for sk in (sks if ph == "wgrad" else [None]):
+                    if sk is not None:
+                        a.splitk, a.partial = sk, None        # (the layer's own partial workspace is sized for its planned split)
+                    for d in [int(v) for v in args.dbg.split(",")]:
+                        a.variant = v0 | (d << 8)
+                        us = timeit(fn)
+                        print(f"{name:16s} {ph:6s} tile {a.tile_m}x{a.tile_n} splitk {a.splitk if ph == 'wgrad' else '-'} dbg {d:2d}: {us:8.1f} us  {fl / us / 1e6:7.0f} TF", flush=True)
+                a.variant = v0
+                if sk0 is not None:
+                    a.splitk, a.partial = sk0, part0
                 continue
             for tile in tiles:
                 for bk in (bks if ph != "wgrad" else [None]):
@@ -89,6 +96,8 @@ def main():
                                 a.stats = None          # the BN partial-sum buffer is sized for the planned tile
                         if sk is not None:
                             a.splitk = sk
+                            if ph == "wgrad":
+                                a.partial = None          # (the layer's partial workspace is sized for its planned split)
                         if bk is None:
                             os.environ.pop("SEG_V2_BK", None)
                         else:
@@ -101,7 +110,7 @@ def main():
                             print(f"{name:16s} {ph:6s} tile {tile} bk {bk}: {e}", flush=True)
             a.tile_m, a.tile_n = t0
             if sk0 is not None:
-                a.splitk = sk0
+                a.splitk, a.partial = sk0, part0
             os.environ.pop("SEG_V2_BK", None)
 
 
