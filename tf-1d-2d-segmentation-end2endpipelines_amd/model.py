@@ -35,7 +35,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs
+from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs, HeadInject
 from .graph import Graph, Node, ParamSpec
 
 BN_PARTS_BWD = int(os.environ.get("SEG_BN_PARTS_BWD", "1024"))
@@ -396,6 +396,11 @@ def wgrad_halo_class_groups(g: Geom) -> int:
 
 WGRAD_FORK_EARLY = os.environ.get("SEG_WGRAD_FORK_EARLY", "1") != "0"   # side stream forks when dz is final, before the op's data gradients are enqueued
 HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
+# output heads on a conv+BN tensor: data gradient folded into that layer's BN backward (seg_bn_act_bwd_*_inj).  Measured on C3
+# (same box A/B, gpurun_out/r2i): seg_head_bwd 0.70 -> 0.32 ms per step, but the two BN passes of the six level-0 tensors
+# grow by 0.39 ms (two extra 4-byte gathers per pixel in kernels that sit on the HBM roofline): step-neutral, so it is OFF
+# by default and kept as a tested option (SEG_HEAD_INJECT=1)
+HEAD_INJECT = os.environ.get("SEG_HEAD_INJECT", "0") != "0"
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = int(os.environ.get("SEG_HALO_BLOCKS_TC", os.environ.get("SEG_HALO_BLOCKS", "256")))   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
@@ -625,6 +630,7 @@ class ConvOp(Op):
         self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
         self.wt = torch.zeros(Kpad * self.T * self.rows_pad, dtype=DevTensor.dtype, device=dev) if any(self.need_dgrad) else None
         self.fwd_args = None
+        self.head_inject: Optional["HeadOp"] = None       # output head whose data gradient this layer's BN backward adds on the fly
         self.gathered: Dict[int, "GatherDgrad"] = {}      # segment index -> gathered data gradient that covers it
         self.gather_launch: List["GatherDgrad"] = []      # gathered data gradients launched at the end of this op's backward
         self.dz_ptr = None
@@ -789,15 +795,24 @@ class ConvOp(Op):
         gs_inv = C.c_void_p(self.m.gs.data_ptr() + 4)
         if self.has_bn:
             bn = self.bn_name
-            dA = self.out.grad
-            call("seg_bn_act_bwd_reduce", _p(dA), self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
+            dA = self.out.ensure_grad()
+            inj, sfx = None, ""
+            src = _p(dA)
+            if self.head_inject is not None:
+                # the head's data gradient (a rank-Cout update per pixel) is added by both passes instead of having been
+                # read-modify-written into dA by seg_head_bwd; with no other consumer nothing was written into dA at all
+                inj, sfx = C.byref(self.head_inject.inject_args()), "_inj"
+                if not self.out.claimers:
+                    src = None
+            extra = (inj,) if inj is not None else ()
+            call("seg_bn_act_bwd_reduce" + sfx, src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
                  _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
-                 _p(self.bpart), BN_PARTS_BWD, s)
+                 _p(self.bpart), BN_PARTS_BWD, *extra, s)
             call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
                  st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
-            call("seg_bn_act_bwd_apply", _p(dA), self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
+            call("seg_bn_act_bwd_apply" + sfx, src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
                  self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
-                 _p(self.c2), ACT[self.act], float(self.alpha), 0, s)
+                 _p(self.c2), ACT[self.act], float(self.alpha), 0, *extra, s)
             dz = dA
         elif self.kind == "convlstm":
             dz = self.z.ensure_grad()
@@ -944,7 +959,27 @@ class HeadOp(Op):
         call("seg_head_fwd", _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W, self.sy, self.sx,
              st.ptr(self.wname), self.w_ld, st.ptr(self.bname), self.cout, self.act, _p(self.y), _stream())
 
+    def inject_args(self) -> HeadInject:
+        if self._inj is None:
+            st = self.m.store
+            h = HeadInject()
+            h.dy, h.y, h.w = self.dy.data_ptr(), self.y.data_ptr(), st.ptr(self.wname).value
+            h.w_ld, h.cout, h.act, h.gs = self.w_ld, self.cout, self.act, self.m.gs.data_ptr()
+            self._inj = h
+        return self._inj
+
     def plan_backward(self):
+        self._inj = None
+        self.injected = False
+        prod = self.m.producer_of.get(id(self.x)) if hasattr(self.m, "producer_of") else None
+        if (HEAD_INJECT and not isinstance(self, WideHeadOp) and prod is not None and prod.has_bn and prod.head_inject is None
+                and prod.out is self.x and (self.sy, self.sx) == (1, 1) and self.cout <= 4 and self.x.needs_grad):
+            # the producing layer's BN backward adds this head's data gradient on the fly: no pass over x.grad here
+            prod.head_inject = self
+            self.injected = True
+            self.x.gw = True                   # the tensor does receive a gradient (the producer must run its backward)
+            self.acc = None
+            return
         self.acc = self.x.claim() if self.x.needs_grad else None
 
     def backward(self):
@@ -1558,6 +1593,7 @@ class SegModel:
         self._build_transpose_table()
         self.set_weights({p.name: init_param(p, self.seed) for p in g.param_specs()})
         # ---- static backward schedule (accumulate flags)
+        self.producer_of = {id(op.out): op for op in self.ops if isinstance(op, ConvOp)}
         for op in reversed(self.ops):
             op.plan_backward()
         DevTensor.registry = None
