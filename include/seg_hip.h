@@ -108,6 +108,9 @@ typedef struct seg_igemm_fwd_args {
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
 /* patch width (32: 8x32 pixels, 16: 16x16 pixels) the variant-3 kernel uses for this geometry; 0: not eligible   */
 int seg_fwd_halo_patch(const seg_geom* g);
+/* the same for the 512 x 64 tile of the wave-specialised kernel (tile_m = 512, n_rows <= 64): 32 = 16 x 32-pixel patches,
+ * 16 = 32 x 16, 0 = not eligible (then use the 256-row tiles)                                                       */
+int seg_fwd_halo_patch512(const seg_geom* g);
 
 /* ---- implicit-GEMM weight gradient of the same layers:
  *   dw[n][tap_w][woff_seg + c] += scale * (*scale_ptr) * sum_pix dz[outpix][n] * in_seg[pix+tap][c]

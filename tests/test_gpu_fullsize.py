@@ -142,9 +142,10 @@ def test_baseline_config_at_its_own_size(cfg):
     for e, m, q in zip(r["outs"], r["out_mag"], r["out_rms"]):
         assert e < tol * max(1.0, m), (cfg, r["outs"], r["out_mag"])
         assert q < F16_RMS[cfg] * max(1.0, m), (cfg, r["out_rms"])
-    for got, ref in r["out_tensors"]:
+    for (got, ref), m in zip(r["out_tensors"], r["out_mag"]):
         same = masks(got) == masks(ref)
-        assert bool(same[margin(ref) > tol].all()), f"{cfg}: a mask pixel outside the near-tie band differs"
+        band = tol * max(1.0, m)                     # the bound the output error was just held to (linear DS heads: |ref| > 1)
+        assert bool(same[margin(ref) > band].all()), f"{cfg}: a mask pixel outside the near-tie band differs"
         assert float(same.float().mean()) >= 0.99
     assert worst_deep[0] < 10 * tol, worst_deep          # the 8x8 / 16x16 level (K up to 18 432) stays in line with the rest
     for k, (cos, ratio, mag) in r["gcos"].items():

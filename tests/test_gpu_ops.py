@@ -328,6 +328,11 @@ def test_wgrad_matches_autograd(case, variant):
     dict(shape=(1, 32, 32), cins=[40], cout=200, tile=(256, 128)),                 # two N tiles, the second ragged
     dict(shape=(3, 16, 16), cins=[128, 24], cout=136, tile=(256, 128)),            # 16x16 patches, 128-wide tile
     dict(shape=(1, 8, 32), cins=[8], cout=8, tile=(256, 64)),                      # smallest: one chunk of 8 channels
+    # wave-specialised 512 x 64 tile (8 compute + 4 loader waves): 16 x 32 and 32 x 16 patches, virtual concat, padded channels
+    dict(shape=(2, 16, 32), cins=[64], cout=64, tile=(512, 64)),
+    dict(shape=(1, 32, 64), cins=[64, 32, 8], cout=40, tile=(512, 64)),
+    dict(shape=(2, 32, 16), cins=[96], cout=64, tile=(512, 64)),
+    dict(shape=(1, 64, 48), cins=[72, 8], cout=24, tile=(512, 64)),
 ], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-{c['tile']}")
 @pytest.mark.parametrize("mode", ["plain", "bias_relu_stats", "accumulate"])
 def test_conv_fwd_halo_kernel(case, mode):
@@ -356,6 +361,8 @@ def test_conv_fwd_halo_kernel(case, mode):
     dict(shape=(1, 16, 16), cin=72, cout=24, tile=(256, 64)),
     dict(shape=(2, 8, 64), cin=64, cout=128, tile=(256, 128)),
     dict(shape=(1, 16, 16), cin=160, cout=136, tile=(256, 128)),
+    dict(shape=(2, 16, 32), cin=128, cout=64, tile=(512, 64)),                      # wave-specialised tile
+    dict(shape=(1, 32, 16), cin=72, cout=24, tile=(512, 64)),
 ], ids=lambda c: f"{c['shape']}-{c['cin']}->{c['cout']}-{c['tile']}")
 def test_conv_transpose_fwd_halo_kernel(case):
     """variant 3 on Conv2DTranspose(4x4, stride 2): four sub-pixel classes of 2x2 taps from the same halo tile."""

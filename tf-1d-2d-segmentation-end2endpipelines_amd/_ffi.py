@@ -76,6 +76,7 @@ _PROTOS = {
     "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_wgrad_halo_class_groups": ([C.POINTER(Geom)], C.c_int),
     "seg_fwd_halo_patch": ([C.POINTER(Geom)], C.c_int),
+    "seg_fwd_halo_patch512": ([C.POINTER(Geom)], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),

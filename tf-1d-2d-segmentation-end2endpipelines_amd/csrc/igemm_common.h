@@ -193,7 +193,7 @@ template <> struct Raw8<float> {
 // ---------------------------------------------------------------------------------------------------------
 // PWE = 0: this wave's rows are the logical pixels row0 .. ; PWE = 32 / 16: the rows are a 256-pixel patch of width
 // PWE at (image pn, row py0, column px0) and row0 is the wave's first patch row (the halo-tile kernel).
-template <typename T, int TM, int TN, int NWM, int BN, int PWE = 0>
+template <typename T, int TM, int TN, int NWM, int BN, int PWE = 0, int NWV = 4>
 __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v (&acc)[TM][TN], unsigned char* smem, int tid, int row0,
                                               int col0, int n0, int wm, int cls, int mblocks, int mb, int M, int HW,
                                               int pn = 0, int py0 = 0, int px0 = 0) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
-  float* sst = reinterpret_cast<float*>(smem + STG_BYTES);   // [NWM][BN][2]
+  float* sst = reinterpret_cast<float*>(smem + (STG_BYTES / 4) * NWV);   // [NWM][BN][2], behind the NWV staging slabs
   const float* bias = p.bias;
   T* out = (T*)p.out;
   const bool do_stats = p.stats != nullptr;
@@ -414,5 +414,7 @@ bool check_segs(const Args& a, const char* who) {
 int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st);
 // its software-pipelined generation (igemm_halo2.hip); called by seg_launch_fwd3 after the argument checks
 int seg_launch_fwd4(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st);
+// wave-specialised 512 x 64 halo-tile forward (igemm_halo3.hip); called by seg_launch_fwd3 for tile_m == 512
+int seg_launch_fwd5(const seg_igemm_fwd_args& a, hipStream_t st);
 // wave-specialised halo-tile weight gradient (igemm_wgrad2.hip); called by seg_igemm_wgrad after the argument checks
 int seg_launch_wgrad_halo_ws(const seg_igemm_wgrad_args& a, int pc, dim3 grid, hipStream_t st);

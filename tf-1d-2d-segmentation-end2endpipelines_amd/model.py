@@ -321,6 +321,24 @@ def fwd_halo_patch(g: Geom) -> int:
     return 0
 
 
+def fwd_halo_patch512(g: Geom) -> int:
+    """Mirror of seg_fwd_halo_patch512(): 512-pixel patches (16 x 32 or 32 x 16) of the wave-specialised 512 x 64 tile."""
+    if not fwd_halo_patch(g) or g.isy != 1:
+        return 0
+    if g.Wl % 32 == 0 and g.Hl % 16 == 0:
+        return 32
+    if g.Wl % 16 == 0 and g.Hl % 32 == 0:
+        return 16
+    return 0
+
+
+# wave-specialised 512 x 64 halo tile for layers with <= 64 output channels (igemm_halo3.hip).  Faster alone (see pick_fwd), but in
+# the training step - next to the weight gradients of the side stream - C3 is 0.3-0.5 ms SLOWER with it (same-box A/B,
+# gpurun_out/r2k): a 768-thread one-block-per-CU kernel leaves the side stream less room than two 256-thread blocks.  OFF by
+# default; SEG_FWD_WS=1 enables it (forward-only / inference workloads profit).
+FWD_WS = os.environ.get("SEG_FWD_WS", "0") != "0"
+FWD_WS_MIN_BLOCKS = int(os.environ.get("SEG_FWD_WS_MIN_BLOCKS", "512"))
+FWD_WS_MIN_K = int(os.environ.get("SEG_FWD_WS_MIN_K", "2048"))       # taps x K channels from which the 512 x 64 tile pays
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
@@ -336,6 +354,13 @@ FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     """(tile_m, tile_n, variant) of a forward / data-gradient launch."""
+    # wave-specialised 512 x 64 tile: measured (tools/op_bench.py, C3, same box) +4 .. +8 % on the long-K 64-channel layers
+    # (X03 .. X05 forward, gathered data gradients), +14 % on the transposed-conv forward (class-fastest blocks share the halo
+    # tile in L2), but -2 .. -13 % on short reductions (K = 576 data gradients, the first layer) where the longer prologue /
+    # epilogue of a one-block-per-CU kernel is not amortised
+    if (f16 and FWD_HALO and FWD_WS and n_rows <= 64 and fwd_halo_patch512(g) and g.ncls * (M // 512) >= FWD_WS_MIN_BLOCKS
+            and (g.ncls == 4 or ktot >= FWD_WS_MIN_K)):
+        return 512, 64, 3
     if f16 and FWD_HALO and fwd_halo_patch(g):
         tn = 64 if n_rows <= 64 else 128
         if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
