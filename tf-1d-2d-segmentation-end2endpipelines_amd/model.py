@@ -1710,6 +1710,17 @@ class SegModel:
         from .harness import load_weights_npz
         self.set_weights(load_weights_npz(path))
 
+    def load_keras_model(self, keras_model):
+        """Take over the weights of a tf.keras model built by the reference for the same constructor call: every Keras layer
+        is matched to its structural name by walking `inbound_nodes` (keras_map.py), never by list position or auto-name."""
+        from .keras_map import keras_weights_by_structural_name
+        self.set_weights(keras_weights_by_structural_name(keras_model, self.graph))
+
+    def export_to_keras_model(self, keras_model):
+        """The other direction: write this model's weights into the matching layers of a tf.keras model."""
+        from .keras_map import export_to_keras
+        export_to_keras(self.get_weights(), keras_model, self.graph)
+
     def get_grads(self) -> Dict[str, np.ndarray]:
         """Gradients of the last backward pass, Keras layout (already divided by the internal gradient scale).  Valid
         between backward() and optimizer_step(): the optimiser step clears the buffer for the next backward pass."""
