@@ -349,6 +349,10 @@ DP_BUSBW_GBS = float(os.environ.get("SEG_DP_BUSBW_GBS", "300"))                 
 ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
 ADAM_URGENT_FIRST = os.environ.get("SEG_ADAM_URGENT_FIRST", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
+# forward pass: deep (small-image) ops on a second stream.  Measured step-neutral on C3 (24.71 / 24.51 against 24.59 / 24.55 ms,
+# same box, gpurun_out/r2m): the full-resolution kernels already occupy every CU's LDS, so the deep kernels' blocks queue
+# behind them instead of running beside them.  OFF by default (SEG_FWD_TWO_STREAMS=1); parity-tested with it on.
+FWD_TWO_STREAMS = os.environ.get("SEG_FWD_TWO_STREAMS", "0") != "0"
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
 
@@ -549,6 +553,14 @@ class Op:
     def forward(self, training: bool):
         raise NotImplementedError
 
+    def reads(self) -> list:
+        """Activation tensors the forward pass of this op reads / writes (the two-stream forward schedule orders ops that run
+        on different streams through these)."""
+        return []
+
+    def writes(self) -> list:
+        return []
+
     def plan_backward(self):
         """Called once, in reverse order, to fix accumulate flags."""
 
@@ -563,6 +575,12 @@ class InputOp(Op):
     def __init__(self, m, t: DevTensor, Cin):
         self.m, self.t, self.Cin = m, t, Cin
         t.needs_grad = False
+
+    def reads(self):
+        return []
+
+    def writes(self):
+        return [self.t]
 
     def forward(self, training):
         x = self.m._x
@@ -722,6 +740,12 @@ class ConvOp(Op):
             return []
         return [(self.m.store.ptr(self.wname, self.m.src_buf).value, self.wt.data_ptr(), self.n_rows, self.T, self.Kpad, 0, self.Kpad,
                  self.rows_pad, self.rows_pad, 0)]
+
+    def reads(self):
+        return [t for t, _c in self.segs]
+
+    def writes(self):
+        return [t for t in (self.out, self.z, self.pooled) if t is not None]
 
     def forward(self, training):
         st, s = self.m.store, _stream()
@@ -979,6 +1003,12 @@ class HeadOp(Op):
         m.store.add(bspec, cout, lambda b: np.asarray(b, np.float32), lambda f: f[:cout].copy())
         self.wname, self.bname = kspec.name, bspec.name
 
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return []
+
     def forward(self, training):
         st = self.m.store
         call("seg_head_fwd", _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W, self.sy, self.sx,
@@ -1041,6 +1071,12 @@ class WideHeadOp(HeadOp):
         self.y = torch.zeros((logits.N, logits.H, logits.W, self.cout), dtype=torch.float32, device=_dev())
         self.dy = torch.zeros_like(self.y)
 
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return []
+
     def forward(self, training):
         x = self.x
         call("seg_head_act_fwd", _p(x.buf), x.cs, x.npix, self.cout, self.act, _p(self.y), _stream())
@@ -1074,6 +1110,12 @@ class ReshapeOp(Op):
         else:
             call("seg_copy_channels", _p(src), img.C, 0, _p(dst), img.cs, 0, img.C, img.npix, accumulate, _stream())
 
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return [self.out]
+
     def forward(self, training):
         self._copy(self.to_flat, self.x.buf, self.out.buf, 0)
 
@@ -1102,6 +1144,12 @@ class BNOp(Op):
         self.bpart = torch.zeros(BN_PARTS_BWD * 2 * self.C, dtype=torch.float32, device=dev)
         self.mean, self.invstd, self.scale, self.shift, self.c1, self.c2 = (
             torch.zeros(self.C, dtype=torch.float32, device=dev) for _ in range(6))
+
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return [self.out]
 
     def forward(self, training):
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
@@ -1141,6 +1189,12 @@ class ConcatOp(Op):
     def __init__(self, m, segs: List[Tuple[DevTensor, int]], out: DevTensor):
         self.m, self.segs, self.out = m, segs, out
 
+    def reads(self):
+        return [t for t, _c in self.segs]
+
+    def writes(self):
+        return [self.out]
+
     def forward(self, training):
         off = 0
         for t, c in self.segs:
@@ -1172,6 +1226,12 @@ class AddOp(Op):
             raise NotImplementedError("add of more than 4 tensors")
         self.ptrs = (C.c_void_p * 4)(*[x.buf.data_ptr() for x in xs])
 
+    def reads(self):
+        return list(self.xs)
+
+    def writes(self):
+        return [self.out]
+
     def forward(self, training):
         call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
              float(self.alpha), _stream())
@@ -1202,6 +1262,12 @@ class MulOp(Op):
         if r.C != 1:
             raise NotImplementedError("mul: the second operand must be a 1-channel map (Attention_Block)")
 
+    def reads(self):
+        return [self.a, self.r]
+
+    def writes(self):
+        return [self.out]
+
     def forward(self, training):
         call("seg_mul_bcast_fwd", _p(self.a.buf), _p(self.r.buf), _p(self.out.buf), self.a.npix, self.a.cs, self.r.cs, _stream())
 
@@ -1222,6 +1288,12 @@ class UpsampleOp(Op):
     def __init__(self, m, x: DevTensor, size, bilinear, out: DevTensor):
         self.m, self.x, self.size, self.bilinear, self.out = m, x, size, 1 if bilinear else 0, out
 
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return [self.out]
+
     def forward(self, training):
         x = self.x
         call("seg_upsample_fwd", _p(x.buf), _p(self.out.buf), x.N, x.H, x.W, x.cs, self.size[0], self.size[1], self.bilinear, _stream())
@@ -1241,6 +1313,12 @@ class UpsampleOp(Op):
 class PoolOp(Op):
     def __init__(self, m, x: DevTensor, size, out: DevTensor):
         self.m, self.x, self.size, self.out = m, x, size, out
+
+    def reads(self):
+        return [self.x]
+
+    def writes(self):
+        return [self.out]
 
     def forward(self, training):
         x = self.x
@@ -1617,6 +1695,7 @@ class SegModel:
         self.gathers = [] if _DryRun.on else plan_gathers(self, self.ops)
         self._build_transpose_table()
         self.set_weights({p.name: init_param(p, self.seed) for p in g.param_specs()})
+        self._plan_forward_streams()
         # ---- static backward schedule (accumulate flags)
         self.producer_of = {id(op.out): op for op in self.ops if isinstance(op, ConvOp)}
         for op in reversed(self.ops):
@@ -1628,6 +1707,35 @@ class SegModel:
         self.built = True
         self._init_optimizer_state()
         return self
+
+    def _plan_forward_streams(self):
+        """Two-stream forward schedule.  The deep levels of a UNet (images of 32 x 32 and smaller at 256 x 256 input: 1024-2048
+        channels, 128-256 blocks per launch) cannot fill 256 CUs - measured 350-660 TFLOP/s against 900-1100 on the large
+        levels - and in the UNet++ / UNet decoders they are independent of most full-resolution nodes: X01, X11, X02 ... only
+        need the encoder.  Ops whose output image has at most 1/64 of the input's pixels run on a second stream, ordered
+        against the main stream by one event per cross-stream tensor dependency (computed here from reads() / writes())."""
+        g = self.graph
+        H0, W0, _ = g.nodes[g.inputs[0]].shape
+        limit = (H0 * W0) // 64
+        self.fstream = [0] * len(self.ops)
+        if FWD_TWO_STREAMS and not _DryRun.on and limit >= 64:
+            for i, op in enumerate(self.ops):
+                w = op.writes()
+                if w and not isinstance(op, InputOp) and w[0].H * w[0].W <= limit:
+                    self.fstream[i] = 1
+        producer = {}
+        self.fwait: List[List[int]] = [[] for _ in self.ops]      # producers on the other stream this op has to wait for
+        self.frecord = [False] * len(self.ops)
+        for i, op in enumerate(self.ops):
+            for t in op.reads():
+                j = producer.get(id(t))
+                if j is not None and self.fstream[j] != self.fstream[i] and j not in self.fwait[i]:
+                    self.fwait[i].append(j)
+                    self.frecord[j] = True
+            for t in op.writes():
+                producer[id(t)] = i
+        self._fev: Dict[int, object] = {}
+        self.aux_stream = None
 
     def _build_transpose_table(self):
         """Device table of every derived (transposed) weight operand: refreshed by ONE launch after each optimiser step."""
@@ -1767,13 +1875,42 @@ class SegModel:
         self._x = self._check_x(x)
         self._enter()
         ev, k = self._param_events, 0          # optimiser slices still being updated on the side stream (forward order)
+        main = None if _DryRun.on else torch.cuda.current_stream()
+        two = (not _DryRun.on) and any(self.fstream) and self.side_stream is not None
+        if two:
+            if self.aux_stream is None:
+                self.aux_stream = torch.cuda.Stream()
+            self.aux_stream.wait_stream(main)          # everything before this forward pass (previous step, the packed input)
         for i, op in enumerate(self.ops):
             while k < len(ev) and ev[k][0] <= i:
-                torch.cuda.current_stream().wait_event(ev[k][1])
+                main.wait_event(ev[k][1])
+                if two:
+                    self.aux_stream.wait_event(ev[k][1])
                 k += 1
-            op.forward(training)
+            if two and self.fstream[i]:
+                for j in self.fwait[i]:
+                    self.aux_stream.wait_event(self._fev[j])
+                with torch.cuda.stream(self.aux_stream):
+                    op.forward(training)
+                    if self.frecord[i]:
+                        e = self._fev.get(i)
+                        if e is None:
+                            e = self._fev[i] = torch.cuda.Event()
+                        e.record(self.aux_stream)
+            else:
+                if two:
+                    for j in self.fwait[i]:
+                        main.wait_event(self._fev[j])
+                op.forward(training)
+                if two and self.frecord[i]:
+                    e = self._fev.get(i)
+                    if e is None:
+                        e = self._fev[i] = torch.cuda.Event()
+                    e.record(main)
         for _first, e in ev[k:]:
-            torch.cuda.current_stream().wait_event(e)
+            main.wait_event(e)
+        if two:
+            main.wait_stream(self.aux_stream)
         self._param_events = []
         outs = [h.y for h in self.out_heads]
         return [o.squeeze(1) for o in outs] if self.graph.ndim == 1 else outs
