@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_
       b_tap[j] = __builtin_amdgcn_readfirstlane(tt);
       const int gch = lch ^ ((row >> 2) & 3);
       b_voff[j] = (n0 + row < p.n_rows) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
+      if (dbg & 64) b_voff[j] = (unsigned)(((j * 4 + wave) * 64 + lane) * 16);      // timing experiment: one contiguous KiB per weight LDS-DMA
     }
   }
   auto uniform_ptr = [](const void* q) -> void* {

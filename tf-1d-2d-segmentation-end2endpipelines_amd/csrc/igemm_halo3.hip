@@ -18,7 +18,7 @@
 
 namespace {
 
-template <int PW, int NT, int TG>
+template <int PW, int NT, int TG, int NSLOT>
 __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BN = 64, NCW = 8, PIX = 64 * NCW;          // compute waves along the pixels, one block of 64 output channels
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_
   constexpr int NA_HI = (NI_A + 3) / 4, NA_REM = NI_A % 4;  // per loader wave: NA_HI for waves < NA_REM (all when NA_REM == 0), else NA_HI - 1
   constexpr int A_BYTES = NI_A * 1024;
   constexpr int B_BYTES = TG * BN * 64, NB_W = B_BYTES / 4096;     // weight stage; LDS-DMA instructions per loader wave and stage
-  constexpr int NSTEP = NT / TG, NSLOT = 3;
+  constexpr int NSTEP = NT / TG;                           // NSLOT weight stages in the LDS ring: NSLOT - 1 issued ahead
   static_assert(TG * NSTEP == NT && NSTEP >= 2 && NB_W * 4096 == B_BYTES, "tap groups / weight stage");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -87,6 +87,9 @@ __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_
         b_tap[j] = __builtin_amdgcn_readfirstlane(tt);
         const int gch = lch ^ ((row >> 2) & 3);
         b_voff[j] = (row < p.n_rows) ? (unsigned)((row * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
+        // timing experiment (dbg & 64, wrong data): every weight LDS-DMA instruction reads ONE contiguous KiB (eight whole
+        // cache lines) instead of 16 rows x 64 B, as a [chunk][tap][row][32] weight layout would allow
+        if (dbg & 64) b_voff[j] = (unsigned)(((j * 4 + wave) * 64 + lane) * 16);
       }
     }
     auto uniform_ptr = [](const void* q) -> void* {
@@ -135,38 +138,41 @@ __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_
     };
     issueA(cA, 0);
     advance(cA);
-    issueB(cB, tgB, 0);
-    nextB();
-    if (nsteps > 1) issueB(cB, tgB, 1);
-    nextB();
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) {
+      if (i < nsteps) issueB(cB, tgB, i);
+      nextB();
+    }
     int s = 0, slot = 0, abuf = 0;
     for (int ck = 0; ck < nchunks; ++ck) {
       static_for<0, NSTEP>([&](auto tgc) {
         constexpr int tg = decltype(tgc)::value;
-        // retire everything older than the newest weight stage - and, while it may still fly, than the next chunk's halo tile
-        // (issued right behind the weight stage of this chunk's first step; it must have landed by the next chunk's first barrier)
-        if (s + 1 < nsteps) {
-          if (tg >= 1 && tg <= 2 && ck + 1 < nchunks) {
-            if (NA_REM == 0 || wave < NA_REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_W + NA_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_W + NA_HI - 1) : "memory");
+        // Before barrier s stage s must have landed; the NSLOT - 2 younger stages may still fly, and so may the next chunk's
+        // halo tile while it sits among them in issue order (it is issued at a chunk's first step, BEFORE that step's weight
+        // stage, and has to be complete at the next chunk's first barrier - where it is older than every stage still allowed)
+        constexpr int FLY = NSLOT - 2;
+        if (s + FLY < nsteps) {
+          if (tg >= 1 && tg <= FLY && ck + 1 < nchunks) {
+            if (NA_REM == 0 || wave < NA_REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLY * NB_W + NA_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLY * NB_W + NA_HI - 1) : "memory");
           } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_W) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLY * NB_W) : "memory");
           }
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 2 < nsteps) {
-          int s2 = slot + 2;
-          if (s2 >= NSLOT) s2 -= NSLOT;
-          issueB(cB, tgB, s2);
-        }
-        nextB();
         if (tg == 0 && ck + 1 < nchunks) {
           issueA(cA, abuf ^ 1);
           advance(cA);
         }
+        if (s + (NSLOT - 1) < nsteps) {
+          int s2 = slot + (NSLOT - 1);
+          if (s2 >= NSLOT) s2 -= NSLOT;
+          issueB(cB, tgB, s2);
+        }
+        nextB();
         slot = slot == NSLOT - 1 ? 0 : slot + 1;
         ++s;
       });
@@ -247,10 +253,12 @@ __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_
 #endif
 }
 
-template __global__ void igemm_fwd5_kernel<32, 9, 3>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd5_kernel<16, 9, 3>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd5_kernel<32, 4, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd5_kernel<16, 4, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd5_kernel<32, 9, 3, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd5_kernel<16, 9, 3, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd5_kernel<32, 9, 3, 5>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd5_kernel<16, 9, 3, 5>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd5_kernel<32, 4, 2, 3>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd5_kernel<16, 4, 2, 3>(const seg_igemm_fwd_args);
 
 }  // namespace
 
@@ -271,14 +279,19 @@ int seg_launch_fwd5(const seg_igemm_fwd_args& a, hipStream_t st) {
   const int npatch = (int)((long)a.g.N * a.g.Hl * a.g.Wl / 512);
   dim3 grid((unsigned)npatch, (unsigned)a.g.ncls, 1);
   const int ni_a = pw == 32 ? 39 : 39;                 // (16 + 2) x 34 = 612 rows, (32 + 2) x 18 = 612 rows
-  if (a.g.ntaps == 9) {
+  static const int nslot = std::getenv("SEG_FWD5_NSLOT") ? std::atoi(std::getenv("SEG_FWD5_NSLOT")) : 5;
+  if (a.g.ntaps == 9 && nslot == 5) {         // four weight stages issued ahead: 2 x 39 + 5 x 12 = 138 KB of LDS
+    const size_t lds = (size_t)2 * ni_a * 1024 + 5 * (3 * 4096);
+    if (pw == 32) hipLaunchKernelGGL((igemm_fwd5_kernel<32, 9, 3, 5>), grid, dim3(768), lds, st, a);
+    else hipLaunchKernelGGL((igemm_fwd5_kernel<16, 9, 3, 5>), grid, dim3(768), lds, st, a);
+  } else if (a.g.ntaps == 9) {
     const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (3 * 4096);
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd5_kernel<32, 9, 3>), grid, dim3(768), lds, st, a);
-    else hipLaunchKernelGGL((igemm_fwd5_kernel<16, 9, 3>), grid, dim3(768), lds, st, a);
+    if (pw == 32) hipLaunchKernelGGL((igemm_fwd5_kernel<32, 9, 3, 3>), grid, dim3(768), lds, st, a);
+    else hipLaunchKernelGGL((igemm_fwd5_kernel<16, 9, 3, 3>), grid, dim3(768), lds, st, a);
   } else {
     const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (2 * 4096);
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd5_kernel<32, 4, 2>), grid, dim3(768), lds, st, a);
-    else hipLaunchKernelGGL((igemm_fwd5_kernel<16, 4, 2>), grid, dim3(768), lds, st, a);
+    if (pw == 32) hipLaunchKernelGGL((igemm_fwd5_kernel<32, 4, 2, 3>), grid, dim3(768), lds, st, a);
+    else hipLaunchKernelGGL((igemm_fwd5_kernel<16, 4, 2, 3>), grid, dim3(768), lds, st, a);
   }
   SEG_CHECK_LAUNCH("seg_igemm_fwd (halo tiles, wave-specialised)");
   return SEG_OK;
