@@ -1,5 +1,6 @@
-"""GPU parity tests in the exact-fp32 mode (dtype='f32': fp32 activations, v_mfma_f32_32x32x2_f32 - an fp32 fma
-chain): the north star's tolerance, asserted as written - every model output within 1e-3 of the oracle (fp32
+"""GPU parity tests in the parity mode (dtype='f32': fp32 activations; the contractions run split fp16 operands on the fp16
+MFMA - x = hi + lo / 2048, three MFMAs per product, ~22 significant bits - or, with SEG_F32_EXACT=1, the fp32 fma-chain
+v_mfma_f32_32x32x2_f32): the north star's tolerance, asserted as written - every model output within 1e-3 of the oracle (fp32
 torch-CPU restatement of the reference) and masks (threshold 0.5 / channel arg-max, 2DCNN/Test.py:176) identical;
 measured errors are around 1e-6, so the tests hold a tighter 1e-4 as well.  Gradients: per parameter tensor the
 relative L2 error is below 5e-3 (a ReLU input within 1e-7 of zero can still flip with the summation order, which

@@ -119,7 +119,8 @@ def test_baseline_config_at_its_own_size(cfg):
     assert abs(r["loss"][0] - r["loss"][1]) < 1e-5 * max(1.0, abs(r["loss"][1]))
     gn = max(nrm for _e, nrm in r["gl2"].values())
     for k, (e, nrm) in r["gl2"].items():
-        assert e < GRAD_L2.get(cfg, 2e-2) * (nrm + 1e-3 * gn), (cfg, k, e, nrm)
+        # (a conv bias in front of BatchNormalization has an exactly-zero gradient: both sides hold summation noise ~1e-4 x gn there)
+        assert e < GRAD_L2.get(cfg, 2e-2) * (nrm + 5e-3 * gn), (cfg, k, e, nrm)
     _record(cfg, "f32_ties", {"near_tie_pixels": ties})
     assert pads_are_zero(model32) is None
     del model32, r

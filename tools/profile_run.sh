@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+B="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- $B > $O/stats.log 2>&1
 # the same with every kernel alone on one stream (no weight-gradient side stream): the per-kernel durations bench.py's
 # roofline object is computed from (its profiled step also runs single-stream)
