@@ -126,7 +126,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
     a.dz, a.dz_cs, a.dz_coff = dzd.data_ptr(), dzd.shape[3], 0
     a.dw, a.Kpad, a.n_rows = dw.data_ptr(), Kpad, n_rows
     Mtot = N * g.Hl * g.Wl
-    tm, tn, sk = M.pick_tile_wgrad(Mtot, n_rows, [d.shape[3] for d in devs], g.ncls, g.ntaps, variant)
+    tm, tn, sk = M.pick_tile_wgrad(Mtot, n_rows, [d.shape[3] for d in devs], g.ncls, g.ntaps, variant & 255)
     if tile:
         tm, tn = tile
     a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)

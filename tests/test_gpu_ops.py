@@ -395,8 +395,12 @@ def test_conv_fwd_halo_kernel_refuses_other_geometries():
     dict(shape=(3, 8, 8), cins=[128, 40], cout=72, sk=2),                 # 8x8 patches: a 16-pixel K block spans two image rows
     dict(shape=(2, 16, 24), cins=[64], cout=64, sk=3),                    # W = 24 -> 8-wide patches, several per row
 ], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
-def test_wgrad_halo_kernel_matches_autograd(case):
-    """variant 2: LDS-DMA halo tiles + transposed LDS reads, 3x3 stride-1 'same' convs."""
+@pytest.mark.parametrize("gen", ["auto", "ts", "ts16", "ws", "r1"])
+def test_wgrad_halo_kernel_matches_autograd(case, gen):
+    """variant 2: LDS-DMA halo tiles + transposed LDS reads, 3x3 stride-1 'same' convs.  Three generations of the kernel
+    behind the same entry point (bits 8.. of `variant` force one): tap-split (default for larger grids; ts16 = its
+    16x16x32-MFMA form), wave-specialised (default for small grids), round 1."""
+    variant = 2 | ({"auto": 0, "ws": 0x40, "r1": 0x80, "ts": 0x100, "ts16": 0x300}[gen] << 8)
     N, H, W = case["shape"]
     xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]
     cin = sum(case["cins"])
@@ -405,7 +409,9 @@ def test_wgrad_halo_kernel_matches_autograd(case):
     y = K.conv2d_same(torch.cat(xs, -1), kern, None, (1, 1))
     dz = h16(torch.randn_like(y))
     (y * dz).sum().backward()
-    got = U.igemm_wgrad(xs, dz, kshape, "conv", (1, 1), 2, case["sk"], None)
+    got = U.igemm_wgrad(xs, dz, kshape, "conv", (1, 1), variant, case["sk"], None)
+    assert rel(torch.from_numpy(got), kern.grad) < 1e-4
+    got = U.igemm_wgrad(xs, dz, kshape, "conv", (1, 1), variant, case["sk"], None, partial=True)      # deterministic split
     assert rel(torch.from_numpy(got), kern.grad) < 1e-4
 
 

@@ -128,6 +128,25 @@ constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;   // 4 waves
 // XCD-aware block order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin over them): physical
 // block b runs on XCD b % 8; give each XCD one contiguous range of logical tiles so that neighbouring tiles (which
 // share halo rows / the dz tile / weight panels) meet in the same L2.  Bijective for any block count.
+// ---- LDS-DMA issued from inline assembly.  The compiler models ds_read_b64_tr_b16 as a possible LDS WRITE and orders it
+// behind every LDS-DMA it knows to be in flight with an s_waitcnt vmcnt(0) of its own - which makes the loads of the
+// weight-gradient kernels synchronous (issue next patch, wait for it, only then contract the current one).  Loads the
+// compiler cannot see are waited for where the kernel says so (counted vmcnt + s_barrier).
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i4v make_rsrc(const void* base, int bytes) {       // raw buffer, bounds-checked against `bytes`
+  const unsigned long long v = (unsigned long long)base;
+  i4v r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) & 0xffff;
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// 64 lanes x 16 bytes -> 1 KiB of LDS at lds_addr (wave-uniform); lane i fetches rsrc[voff + soff]
+__device__ __forceinline__ void lds_dma16(i4v rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+
 __device__ __forceinline__ int xcd_remap(int b, int n) {
   const int q = n >> 3, r = n & 7, x = b & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -418,3 +437,4 @@ int seg_launch_fwd4(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t 
 int seg_launch_fwd5(const seg_igemm_fwd_args& a, hipStream_t st);
 // wave-specialised halo-tile weight gradient (igemm_wgrad2.hip); called by seg_igemm_wgrad after the argument checks
 int seg_launch_wgrad_halo_ws(const seg_igemm_wgrad_args& a, int pc, dim3 grid, hipStream_t st);
+int seg_launch_wgrad_halo_ts(const seg_igemm_wgrad_args& a, int pc, dim3 grid, hipStream_t st);   // igemm_wgrad3.hip

@@ -341,12 +341,18 @@ SEG_FWD4_INST(4, 1, 4, 4)      // ... and its data gradient (four parity planes)
 // the round-1 tap grouping of the 64-channel tile (3 taps per barrier, 3-stage ring) with read-ahead inside the step
 template __global__ void igemm_fwd4_kernel<32, 64, 9, 3, 1, 3>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd4_kernel<16, 64, 9, 3, 1, 3>(const seg_igemm_fwd_args);
+// the 64-channel tile of the transposed conv and of its data gradient: two taps per barrier (16 instead of 8 MFMAs per wave between barriers)
+template __global__ void igemm_fwd4_kernel<32, 64, 4, 2, 1, 4>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd4_kernel<16, 64, 4, 2, 1, 4>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd4_kernel<32, 64, 4, 2, 4, 4>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd4_kernel<16, 64, 4, 2, 4, 4>(const seg_igemm_fwd_args);
 #undef SEG_FWD4_INST
 
 template <int NT, int NPL>
 void launch_fwd4_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st) {
   const int ni_a = pw == 32 ? 22 : 21;
   static const bool tg3 = std::getenv("SEG_FWD4_TG3") != nullptr;       // A/B switch: 64-channel tile with 3 taps per barrier
+  static const bool tg2 = std::getenv("SEG_FWD4_TG2") != nullptr;       // A/B switch: transposed conv, 64-channel tile, 2 taps per barrier
   if (a.tile_n == 128) {
     const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 8192;
     if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 128, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
@@ -355,6 +361,12 @@ void launch_fwd4_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t 
     const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (3 * 4096);
     if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, 9, 3, 1, 3>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 64, 9, 3, 1, 3>), grid, dim3(256), lds, st, a);
+  } else if (NT == 4 && tg2) {
+    if constexpr (NT == 4) {
+      const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 8192;
+      if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, 4, 2, NPL, 4>), grid, dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 64, 4, 2, NPL, 4>), grid, dim3(256), lds, st, a);
+    }
   } else {
     const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 4096;
     if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   const int wm = wave >> 1, wn = wave & 1;
   const seg_geom& g = p.g;
   const int H = g.Hin, W = g.Win;
-  // timing experiments (tools/op_bench.py --dbg on the wgrad phase; results are WRONG): 1 no LDS-DMA, 4 no barrier, 8 no MFMA, 16 no epilogue
+  // timing experiments (tools/op_bench.py --dbg on the wgrad phase; results are WRONG): 1 no LDS-DMA, 4 no barrier, 16 no epilogue
   const int dbg = __builtin_amdgcn_readfirstlane(p.variant >> 8);
 
   // ---- which (64-row tile, 64-channel plane, patch range) is this block
@@ -511,15 +511,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   }
   const int Ho = g.Hout, Wo = g.Wout, osy = g.osy, osx = g.osx;
 
-  // wave-uniform descriptors (readfirstlane returns int: keep the halves unsigned, or a low word with bit 31 set
-  // sign-extends into the high word of the base address)
-  auto uniform_ptr = [](const void* q) -> void* {
-    const unsigned long long v = (unsigned long long)q;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (void*)(((unsigned long long)hi << 32) | lo);
-  };
-  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.seg_ptr[seg]), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * cs2), 0x00020000);
-  const auto rsrc_dz = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.dz), 0, __builtin_amdgcn_readfirstlane(g.N * Ho * Wo * dzcs2), 0x00020000);
+  const i4v rsrc_in = make_rsrc(p.seg_ptr[seg], g.N * H * W * cs2);
+  const i4v rsrc_dz = make_rsrc(p.dz, g.N * Ho * Wo * dzcs2);
+  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
   // ---- LDS-DMA lane constants.  A wave instruction fills 8 LDS rows (lane >> 3) x 8 chunks (lane & 7); the chunk a
   // lane fetches from memory is its LDS chunk XOR the row's swizzle
@@ -545,9 +539,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   }
   // patch coordinates of the next issue, advanced incrementally (two scalar divisions per patch were 10 % of the
   // wave's issue cycles)
-  int pn_ = q0 / (PH * PW);
-  int py_ = (q0 - pn_ * (PH * PW)) / PW;
-  int px_ = q0 - pn_ * (PH * PW) - py_ * PW;
+  int pn_ = __builtin_amdgcn_readfirstlane(q0 / (PH * PW));
+  int py_ = __builtin_amdgcn_readfirstlane((q0 - pn_ * (PH * PW)) / PW);
+  int px_ = __builtin_amdgcn_readfirstlane(q0 - pn_ * (PH * PW) - py_ * PW);
   auto issue = [&](int /*q*/, int stage) {
     if (dbg & 1) return;
     const int n = pn_, y0 = py_ * R, x0 = px_ * C;
@@ -555,18 +549,17 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
       px_ = 0;
       if (++py_ == PH) { py_ = 0; ++pn_; }
     }
-    unsigned char* sb = smem + stage * STAGE;
-    const int zs = ((n * Ho + y0 * osy + g.oy[cls]) * Wo + x0 * osx + g.ox[cls]) * dzcs2;
+    const unsigned sb = lds_base + (unsigned)(stage * STAGE);
+    const int zs = __builtin_amdgcn_readfirstlane(((n * Ho + y0 * osy + g.oy[cls]) * Wo + x0 * osx + g.ox[cls]) * dzcs2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dz, (lds_ptr_t)(sb + (wave * 2 + i) * 1024), 16, z_voff[i], zs, 0, 0);
+    for (int i = 0; i < 2; ++i) lds_dma16(rsrc_dz, sb + (wave * 2 + i) * 1024, z_voff[i], zs);
 #pragma unroll
     for (int k = 0; k < NI_W; ++k) {
       if (wave + 4 * k < NI_IN) {
         const int y = y0 + in_dy[k], x = x0 + in_dx[k];
         const bool ok = in_cb[k] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         const unsigned voff = ok ? (unsigned)(((n * H + y) * W + x) * cs2 + in_cb[k]) : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(sb + Z_BYTES + (wave + 4 * k) * 1024), 16, voff, 0, 0, 0);
+        lds_dma16(rsrc_in, sb + Z_BYTES + (wave + 4 * k) * 1024, voff, 0);
       }
     }
   };
@@ -609,7 +602,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
         if (TC && !((tmask >> t) & 1u)) continue;                   // wave-uniform
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
         const h8 bf = trfrag(Is + hb * 128 + offB[hb & 3]);
-        if (dbg & 8) { asm volatile("" ::"v"(af), "v"(bf)); continue; }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
       }
     }
@@ -713,13 +705,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
     return;
   }
 
-  auto uniform_ptr = [](const void* q) -> void* {
-    const unsigned long long v = (unsigned long long)q;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (void*)(((unsigned long long)hi << 32) | lo);
-  };
-  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.seg_ptr[seg]), 0, __builtin_amdgcn_readfirstlane(g.N * H * W * cs2), 0x00020000);
-  const auto rsrc_dz = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.dz), 0, __builtin_amdgcn_readfirstlane(g.N * Ho * Wo * dzcs2), 0x00020000);
+  const i4v rsrc_in = make_rsrc(p.seg_ptr[seg], g.N * H * W * cs2);
+  const i4v rsrc_dz = make_rsrc(p.dz, g.N * Ho * Wo * dzcs2);
+  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
   const int lrow = lane >> 3, lch = lane & 7;
   unsigned z_voff[2];
@@ -741,29 +729,28 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
     in_dx[k] = xx - 1;
     in_cb[k] = (i < NI_IN && row < HROWS && c0 + gch * 8 < sc) ? (c0 + gch * 8) * 2 : -1;
   }
-  int pn_ = q0 / (PH * PW);
-  int py_ = (q0 - pn_ * (PH * PW)) / PW;
-  int px_ = q0 - pn_ * (PH * PW) - py_ * PW;
+  int pn_ = __builtin_amdgcn_readfirstlane(q0 / (PH * PW));
+  int py_ = __builtin_amdgcn_readfirstlane((q0 - pn_ * (PH * PW)) / PW);
+  int px_ = __builtin_amdgcn_readfirstlane(q0 - pn_ * (PH * PW) - py_ * PW);
   auto issue = [&](int stage) {
     const int n = pn_, y0 = py_ * R, x0 = px_ * C;
     if (++px_ == PW) {
       px_ = 0;
       if (++py_ == PH) { py_ = 0; ++pn_; }
     }
-    unsigned char* sb = smem + stage * STAGE;
-    const int zs = ((n * Ho + y0 * 2 + py) * Wo + x0 * 2) * dzcs2;          // class (py, 0); (py, 1) is the next pixel
+    const unsigned sb = lds_base + (unsigned)(stage * STAGE);
+    const int zs = __builtin_amdgcn_readfirstlane(((n * Ho + y0 * 2 + py) * Wo + x0 * 2) * dzcs2);          // class (py, 0); (py, 1) is the next pixel
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dz, (lds_ptr_t)(sb + c2 * Z_BYTES + (wave * 2 + i) * 1024), 16, z_voff[i], zs + c2 * dzcs2, 0, 0);
+      for (int i = 0; i < 2; ++i) lds_dma16(rsrc_dz, sb + c2 * Z_BYTES + (wave * 2 + i) * 1024, z_voff[i], zs + c2 * dzcs2);
 #pragma unroll
     for (int k = 0; k < NI_W; ++k) {
       if (wave + 4 * k < NI_IN) {
         const int y = y0 + in_dy[k], x = x0 + in_dx[k];
         const bool ok = in_cb[k] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         const unsigned voff = ok ? (unsigned)(((n * H + y) * W + x) * cs2 + in_cb[k]) : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(sb + 2 * Z_BYTES + (wave + 4 * k) * 1024), 16, voff, 0, 0, 0);
+        lds_dma16(rsrc_in, sb + 2 * Z_BYTES + (wave + 4 * k) * 1024, voff, 0);
       }
     }
   };
@@ -1042,8 +1029,15 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
       static const char* ws_env = std::getenv("SEG_WGRAD_WS");
       const long nblk = (long)gridh.x * gridh.y * gridh.z;
       const bool ws = ws_env != nullptr ? std::atoi(ws_env) != 0 : nblk <= 320;
-      if (a->g.ncls == 1 && (ws || (a->variant >> 8) == 0x40)) {
+      // larger grids: tap-split generation (igemm_wgrad3.hip: an input fragment feeds two MFMAs, -30 % LDS reads);
+      // SEG_WGRAD_TS=0 keeps the round-1 kernel
+      static const char* ts_env = std::getenv("SEG_WGRAD_TS");
+      const bool ts = ts_env == nullptr || std::atoi(ts_env) != 0;
+      const int force = a->variant >> 8;                            // tests: 0x40 wave-specialised, 0x80 round 1, 0x100 tap-split
+      if (a->g.ncls == 1 && (force == 0x40 || (ws && force != 0x80 && !(force & 0x100)))) {
         seg_launch_wgrad_halo_ws(*a, pc, gridh, sth);
+      } else if (a->g.ncls == 1 && ((force & 0x100) || (ts && force != 0x80))) {
+        seg_launch_wgrad_halo_ts(*a, pc, gridh, sth);
       } else if (a->g.ncls == 1) {
         SEG_HALO_PC(igemm_wgrad_halo_kernel, gridh, lds1, , false);
       } else if (seg_wgrad_halo_class_groups(&a->g) == 2) {

@@ -182,7 +182,6 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_halo_ws_kernel(const seg_i
         if (TC && !((tmask >> t) & 1u)) continue;                   // wave-uniform
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
         const h8 bf = trfrag(Is + hb * 128 + offB[hb & 3]);
-        if (dbg & 8) { asm volatile("" ::"v"(af), "v"(bf)); continue; }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
       }
     }
