@@ -224,6 +224,7 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   const float* bias = p.bias;
   T* out = (T*)p.out;
   const bool do_stats = p.stats != nullptr;
+  const float act_slope = p.act == SEG_ACT_LEAKY ? p.alpha : 0.f;      // ReLU / LeakyReLU: v > 0 ? v : v * slope
   float s_sum[TN], s_sq[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) { s_sum[b] = 0.f; s_sq[b] = 0.f; }
@@ -316,18 +317,33 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
       float bv = 0.f;
       if (bias != nullptr && ncol < p.n_rows) bv = bias[ncol];
       const bool nzero = ncol >= p.n_valid;
+      // (block-uniform choices - statistics, kind of activation - are taken once per tile, not once per element: the
+      // element loop used to carry ~14 scalar branches, a third of the run time of the short-K layers' blocks)
+      float vv[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int rt = (q & 3) + 8 * (q >> 2) + 4 * fh;
-        float v = acc[a][b][q] + bv;
-        if (do_stats) {
-          const int m = row0 + a * 32 + rt;
-          if (PWE > 0 || m < M) { s_sum[b] += v; s_sq[b] += v * v; }
+      for (int q = 0; q < 16; ++q) vv[q] = acc[a][b][q] + bv;
+      if (do_stats) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = row0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+          const float v = (PWE > 0 || m < M) ? vv[q] : 0.f;
+          s_sum[b] += v;
+          s_sq[b] += v * v;
         }
-        v = seg_act(v, p.act, p.alpha);
-        if (nzero) v = 0.f;
-        stg[rt * STG_LD + fr] = v;
       }
+      if (p.act == SEG_ACT_SIGMOID) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vv[q] = 1.f / (1.f + __expf(-vv[q]));
+      } else if (p.act != SEG_ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vv[q] = vv[q] > 0.f ? vv[q] : vv[q] * act_slope;
+      }
+      if (nzero) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vv[q] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) stg[((q & 3) + 8 * (q >> 2) + 4 * fh) * STG_LD + fr] = vv[q];
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const int rt = st_row + 16 * ps;
@@ -341,8 +357,14 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
 #pragma unroll
             for (int t = 0; t < 8; ++t) yf[t] = 0.f;
             Raw8<T>::add(yv[a % AG][b][ps], yf);
+            if (dact[b] == SEG_ACT_SIGMOID) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) f[t] *= seg_act_grad_from_out(yf[t], dact[b], dalpha[b]);
+              for (int t = 0; t < 8; ++t) f[t] *= yf[t] * (1.f - yf[t]);
+            } else if (dact[b] != SEG_ACT_NONE) {
+              const float lo = dact[b] == SEG_ACT_LEAKY ? dalpha[b] : 0.f;
+#pragma unroll
+              for (int t = 0; t < 8; ++t) f[t] *= yf[t] > 0.f ? 1.f : lo;
+            }
           }
           if (any_acc) Raw8<T>::add(oldv[a % AG][b][ps], f);
           store8(dst, f);
