@@ -402,6 +402,41 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   }
 }
 
+// ---- epilogue of the weight-gradient kernels: one 32 x 32 fp32 accumulator tile -> dw (or the split's partial buffer).
+// How the tile is written is a block-uniform choice: made once (wgrad_mode), not per element; the element address is
+// a tile base plus a scalar multiple of the row stride.
+//   0 store (only writer, dw known to be zero)   1 read-add-store (only writer)   2 store into the partial buffer of this
+//   patch range (deterministic split, reduced in order by wgrad_reduce_kernel)    3 atomicAdd
+__device__ __forceinline__ int wgrad_mode(const seg_igemm_wgrad_args& p) {
+  return p.splitk == 1 ? (p.overwrite ? 0 : 1) : ((p.partial != nullptr) ? 2 : 3);
+}
+// d0: element (first row of the tile + 4 (lane >> 5), this lane's column); rows_left = n_rows - first row of the tile (n_rows
+// is a multiple of 8, so each group of eight rows is inside or outside as a whole); stride = floats between consecutive rows
+template <int MODE>
+__device__ __forceinline__ void wgrad_store_tile(float* d0, const f16v& acc, int rows_left, int stride, float sc_mul) {
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    if (8 * gq < rows_left) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = d0 + (8 * gq + j) * stride;
+        const float v = acc[4 * gq + j];
+        if constexpr (MODE == 0) *d = v * sc_mul;
+        else if constexpr (MODE == 1) *d += v * sc_mul;
+        else if constexpr (MODE == 2) *d = v;
+        else atomicAdd(d, v * sc_mul);
+      }
+    }
+  }
+}
+template <typename F>
+__device__ __forceinline__ void wgrad_mode_dispatch(int mode, F&& f) {
+  if (mode == 0) f(std::integral_constant<int, 0>{});
+  else if (mode == 1) f(std::integral_constant<int, 1>{});
+  else if (mode == 2) f(std::integral_constant<int, 2>{});
+  else f(std::integral_constant<int, 3>{});
+}
+
 constexpr unsigned OOB_OFF = 0x60000000u;   // beyond any legal byte offset (operands are checked to be < 1 GiB)
 
 template <int I, int N, typename F>

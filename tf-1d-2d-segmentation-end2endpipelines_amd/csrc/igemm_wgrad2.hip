@@ -236,24 +236,15 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_halo_ws_kernel(const seg_i
     if (keep != 12345.678f) return;
   }
   if (kcol < sc) {
+    const int stride = g.T_total * p.Kpad, row0 = r0 + wm * 32;
+    float* const wbase = (part != nullptr ? part : dw) + (size_t)(row0 + 4 * fh) * stride + p.seg_woff[seg] + kcol;
+    wgrad_mode_dispatch(wgrad_mode(p), [&](auto mc) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (TC && !((tmask >> t) & 1u)) continue;
-      const int widx = wmap[t];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-        if (row < p.n_rows) {
-          float* d = dw + ((size_t)row * g.T_total + widx) * p.Kpad + p.seg_woff[seg] + kcol;
-          if (p.splitk == 1) {       // this block is the only writer of its tile: no atomic needed, and no read either
-            if (p.overwrite) *d = acc[t][q] * sc_mul;          // when the caller vouches that dw holds zeros
-            else *d += acc[t][q] * sc_mul;
-          }
-          else if (part != nullptr) part[d - dw] = acc[t][q];   // deterministic split: reduced in order by wgrad_reduce_kernel
-          else atomicAdd(d, acc[t][q] * sc_mul);
-        }
+      for (int t = 0; t < 9; ++t) {
+        if (TC && !((tmask >> t) & 1u)) continue;
+        wgrad_store_tile<decltype(mc)::value>(wbase + wmap[t] * p.Kpad, acc[t], p.n_rows - row0, stride, sc_mul);
       }
-    }
+    });
   }
 #endif
 }

@@ -239,41 +239,47 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_ts_kernel(const seg_i
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
   float* dw = p.dw;
   float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
-  auto store = [&](int row, int t, int kcol, float v) {
-    if (row < p.n_rows && kcol < sc) {
-      float* d = dw + ((size_t)row * g.T_total + g.tap_w[t]) * p.Kpad + p.seg_woff[seg] + kcol;
-      if (p.splitk == 1) {       // this block is the only writer of its tile: no atomic needed, and no read either
-        if (p.overwrite) *d = v * sc_mul;                         // when the caller vouches that dw holds zeros
-        else *d += v * sc_mul;
-      }
-      else if (part != nullptr) part[d - dw] = v;                 // deterministic split: reduced in order by wgrad_reduce_kernel
-      else atomicAdd(d, v * sc_mul);
-    }
-  };
   if (dbg & 16) {
     float keep = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) keep += acc[t][0] + acc[t][15] + acc16[S16 ? 4 * t : 0][0];
     if (keep != 12345.678f) return;
   }
+  const int stride = g.T_total * p.Kpad;
+  float* const wroot = (part != nullptr ? part : dw) + p.seg_woff[seg];
+  wgrad_mode_dispatch(wgrad_mode(p), [&](auto mc) {
+    constexpr int MODE = decltype(mc)::value;
 #pragma unroll
-  for (int s = 0; s < 9; ++s) {
-    const int t = s < 8 ? tgrp * 5 + (s >> 1) : 4;               // tap and row tile of accumulator s
-    const int a = s < 8 ? (s & 1) : tgrp;
-    if constexpr (S16) {
+    for (int s = 0; s < 9; ++s) {
+      const int t = s < 8 ? tgrp * 5 + (s >> 1) : 4;               // tap and row tile of accumulator s
+      const int a = s < 8 ? (s & 1) : tgrp;
+      const int row0 = r0 + a * 32;
+      float* const tbase = wroot + (size_t)row0 * stride + g.tap_w[t] * p.Kpad;
+      if constexpr (S16) {
+        // 16x16 tiles: row = 4 (lane >> 4) + reg, column = lane & 15
 #pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2)
+        for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < 2; ++b) {
+            const int kcol = c0 + wn * 32 + b * 16 + (lane & 15);
+            if (kcol < sc && row0 + a2 * 16 + 4 * (lane >> 4) < p.n_rows) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            store(r0 + a * 32 + a2 * 16 + 4 * (lane >> 4) + q, t, c0 + wn * 32 + b * 16 + (lane & 15), acc16[s * 4 + 2 * a2 + b][q]);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-        store(r0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), t, c0 + wn * 32 + (lane & 31), acc[s][q]);
+              for (int q = 0; q < 4; ++q) {
+                float* d = tbase + (size_t)(a2 * 16 + 4 * (lane >> 4) + q) * stride + kcol;
+                const float v = acc16[s * 4 + 2 * a2 + b][q];
+                if constexpr (MODE == 0) *d = v * sc_mul;
+                else if constexpr (MODE == 1) *d += v * sc_mul;
+                else if constexpr (MODE == 2) *d = v;
+                else atomicAdd(d, v * sc_mul);
+              }
+            }
+          }
+      } else {
+        const int kcol = c0 + wn * 32 + (lane & 31);
+        if (kcol < sc) wgrad_store_tile<MODE>(tbase + (size_t)(4 * (lane >> 5)) * stride + kcol, acc[s], p.n_rows - row0, stride, sc_mul);
+      }
     }
-  }
+  });
 #endif
 }
 
