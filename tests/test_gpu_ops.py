@@ -385,6 +385,27 @@ def test_conv_fwd_halo_kernel_refuses_other_geometries():
         U.igemm_conv([h16(torch.randn(2, 16, 32, 64))], kern, None, "conv", (2, 2), None, 0.0, False, (256, 64), variant=3)     # stride
 
 
+def test_conv_statistics_at_full_size_are_exact_and_repeatable():
+    """The BatchNormalization sums the conv epilogue takes (sum, sum of squares per channel) at a level-0 size of the headline
+    configuration: 4 096 blocks, several rounds of co-resident blocks.  Guards a defect the reduced-size tests did not see:
+    with the statistics accumulated through compiler-formed packed-fp32 instructions the sum of squares came out up to 0.4 %
+    off in a few blocks per launch, differently from launch to launch (tools/stats_probe.py)."""
+    N, H, W = 8, 256, 256
+    x = [h16(torch.randn(N, H, W, 64))]
+    kern = (rng.standard_normal((3, 3, 64, 64)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    pre = K.conv2d_same(x[0], torch.from_numpy(kern.astype(np.float16).astype(np.float32)), torch.from_numpy(b)).double()
+    ref = torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])
+    first = None
+    for _ in range(4):
+        _out, st, _pad = U.igemm_conv(x, kern, b, "conv", (1, 1), None, 0.0, True, (256, 64), variant=3)
+        err = (st[:, :64].double() - ref).abs() / ref.abs().clamp_min(1.0)
+        assert float(err.max()) < 2e-6, err.max(1)
+        if first is None:
+            first = st
+        assert torch.equal(st, first)
+
+
 @pytest.mark.parametrize("case", [
     dict(shape=(2, 8, 32), cins=[64], cout=64, sk=1),                     # 32-wide patches, 2 rows
     dict(shape=(3, 6, 64), cins=[64, 64, 8], cout=64, sk=5),              # several planes, a ragged one, uneven split

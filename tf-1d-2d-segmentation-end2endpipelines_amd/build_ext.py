@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_build")
 OUT = os.path.join(HERE, "libseg_hip.so")
 STAMP = OUT + ".srchash"          # fingerprint of the sources the shipped .so was built from
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 
 
 def sources():

@@ -144,7 +144,12 @@ __device__ __forceinline__ i4v make_rsrc(const void* base, int bytes) {       //
 }
 // 64 lanes x 16 bytes -> 1 KiB of LDS at lds_addr (wave-uniform); lane i fetches rsrc[voff + soff]
 __device__ __forceinline__ void lds_dma16(i4v rsrc, unsigned lds_addr, unsigned voff, int soff) {
+#if defined(SEG_DMA_BUILTIN)      // bisecting aid: the compiler-visible form (synchronous in the kernels with transposing reads)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(unsigned)rsrc.y << 32) | (unsigned)rsrc.x), 0, rsrc.z, rsrc.w), (lds_ptr_t)(size_t)lds_addr, 16, voff, soff, 0, 0);
+#else
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+#endif
 }
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {
@@ -219,6 +224,9 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   const seg_geom& g = p.g;
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
+  // the last MFMAs of the K loop retire before anything below reads an accumulator (the statistics are accumulated by
+  // inline assembly, which the compiler's hazard tracking does not look into)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
   float* sst = reinterpret_cast<float*>(smem + (STG_BYTES / 4) * NWV);   // [NWM][BN][2], behind the NWV staging slabs
   const float* bias = p.bias;
@@ -331,8 +339,11 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
         for (int q = 0; q < 16; ++q) {
           const int m = row0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
           const float v = (PWE > 0 || m < M) ? vv[q] : 0.f;
-          s_sum[b] += v;
-          s_sq[b] += v * v;
+          // written out: left to the compiler this pair becomes v_pk_mul_f32 / v_pk_add_f32 on (v, v * v) register pairs, and
+          // with those the SUM OF SQUARES came out up to 0.4 % off in lanes 16-31 / 48-63 of a few blocks per launch,
+          // differently from run to run (the sums stayed exact) - tools/stats_probe.py
+          asm("v_add_f32 %0, %0, %1" : "+v"(s_sum[b]) : "v"(v));
+          asm("v_fmac_f32 %0, %1, %1" : "+v"(s_sq[b]) : "v"(v));
         }
       }
       if (p.act == SEG_ACT_SIGMOID) {

@@ -19,7 +19,7 @@
 
 namespace {
 
-template <int PW, int BN, int NT, int TG, int NPL, int NSLOT>
+template <int PW, int BN, int NT, int TG, int NPL, int NSLOT, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PH = 256 / PW, HC = PW + 2, HROWS = (PH + 2) * HC;
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_
   const seg_geom& g = p.g;
   // timing experiments (tools/op_bench.py --dbg; results are WRONG with any bit set): 1 no weight DMA, 2 no halo DMA,
   // 4 no barrier, 8 no MFMA, 16 no epilogue
-  const int dbg = __builtin_amdgcn_readfirstlane(p.variant >> 8);
+  // (a separate instantiation: in the production kernel dbg is the constant 0 and none of the switches leaves a branch behind)
+  const int dbg = DBG ? __builtin_amdgcn_readfirstlane(p.variant >> 8) : 0;
   const int H = g.Hl, W = g.Wl, IS = NPL == 4 ? 2 : 1;
   const int PWn = W / PW, PHn = H / PH;
   const int npatch = g.N * PHn * PWn;
@@ -330,11 +331,13 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_
 #endif
 }
 
-#define SEG_FWD4_INST(NT, TG, NPL, NSLOT)                                                              \
-  template __global__ void igemm_fwd4_kernel<32, 128, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);   \
-  template __global__ void igemm_fwd4_kernel<16, 128, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);   \
-  template __global__ void igemm_fwd4_kernel<32, 64, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);    \
-  template __global__ void igemm_fwd4_kernel<16, 64, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);
+#define SEG_FWD4_INST(NT, TG, NPL, NSLOT)                                                                     \
+  template __global__ void igemm_fwd4_kernel<32, 128, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);          \
+  template __global__ void igemm_fwd4_kernel<16, 128, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);          \
+  template __global__ void igemm_fwd4_kernel<32, 64, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);           \
+  template __global__ void igemm_fwd4_kernel<16, 64, NT, TG, NPL, NSLOT>(const seg_igemm_fwd_args);           \
+  template __global__ void igemm_fwd4_kernel<32, 128, NT, TG, NPL, NSLOT, true>(const seg_igemm_fwd_args);    \
+  template __global__ void igemm_fwd4_kernel<32, 64, NT, TG, NPL, NSLOT, true>(const seg_igemm_fwd_args);
 SEG_FWD4_INST(9, 1, 1, 4)      // 3x3 conv and its data gradient
 SEG_FWD4_INST(4, 1, 1, 4)      // one sub-pixel class of the 4x4 / stride-2 transposed conv
 SEG_FWD4_INST(4, 1, 4, 4)      // ... and its data gradient (four parity planes)
@@ -353,9 +356,11 @@ void launch_fwd4_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t 
   const int ni_a = pw == 32 ? 22 : 21;
   static const bool tg3 = std::getenv("SEG_FWD4_TG3") != nullptr;       // A/B switch: 64-channel tile with 3 taps per barrier
   static const bool tg2 = std::getenv("SEG_FWD4_TG2") != nullptr;       // A/B switch: transposed conv, 64-channel tile, 2 taps per barrier
+  const bool dbgk = (a.variant >> 8) != 0 && pw == 32;     // timing experiments: the instantiation that keeps the switches
   if (a.tile_n == 128) {
     const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 8192;
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 128, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
+    if (dbgk) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 128, NT, 1, NPL, 4, true>), grid, dim3(256), lds, st, a);
+    else if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 128, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 128, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
   } else if (NT == 9 && NPL == 1 && tg3) {
     const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (3 * 4096);
@@ -369,7 +374,8 @@ void launch_fwd4_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t 
     }
   } else {
     const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 4096;
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
+    if (dbgk) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, NT, 1, NPL, 4, true>), grid, dim3(256), lds, st, a);
+    else if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 64, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
   }
 }
