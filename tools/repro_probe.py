@@ -39,6 +39,7 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
         torch.cuda.empty_cache()
         continue
     order = [getattr(getattr(op, "node", None), "name", type(op).__name__) for op in m0.ops]
+    print("   parameter gradients: relative L2 difference %.3e, max abs %.3e of max %.3e" % (float((g0.double() - g1.double()).norm() / g0.double().norm()), float((g0 - g1).abs().max()), float(g0.abs().max())))
     print("   master weights / fp16 weights / BN state differ:", "P" in bad_a, "P16" in bad_a, "S" in bad_a, " enc1/conv:z differs:", "enc1/conv:z" in bad_a)
     print("   first differing activations in forward order:", [n for n in order if n in bad_a or (n + ":z") in bad_a][:5])
     print("   differing activation grads, backward order:", [n for n in reversed(order) if n in bad_d or (n + ":z") in bad_d][:8])
