@@ -42,6 +42,22 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     print("   parameter gradients: relative L2 difference %.3e, max abs %.3e of max %.3e" % (float((g0.double() - g1.double()).norm() / g0.double().norm()), float((g0 - g1).abs().max()), float(g0.abs().max())))
     print("   master weights / fp16 weights / BN state differ:", "P" in bad_a, "P16" in bad_a, "S" in bad_a, " enc1/conv:z differs:", "enc1/conv:z" in bad_a)
     print("   first differing activations in forward order:", [n for n in order if n in bad_a or (n + ":z") in bad_a][:5])
+    for n in bad_d:
+        dd = (d0[n].float() - d1[n].float()).abs()
+        print(f"      d/{n:20s} ndiff {int((dd > 0).sum()):9d} of {dd.numel():9d}  max {float(dd.max()):.3e}  ref max {float(d0[n].float().abs().max()):.3e}")
+    if "X41/relu" in bad_d:
+        dd = (d0["X41/relu"].float() - d1["X41/relu"].float()).abs()          # (N, H, W, C)
+        chs = torch.nonzero(dd.sum((0, 1, 2)) > 0).flatten().tolist()
+        pix = dd.sum(3) > 0
+        print("      X41/relu: channels with differences", len(chs), chs[:40], "| pixels with differences", int(pix.sum()), "of", pix.numel(),
+              "| images", torch.nonzero(pix.sum((1, 2)) > 0).flatten().tolist())
+        for opx in m0.ops:
+            if getattr(getattr(opx, "node", None), "name", "") == "X41/conv":
+                opy = [o for o in m1.ops if getattr(getattr(o, "node", None), "name", "") == "X41/conv"][0]
+                for nm in ("bpart", "c1", "c2"):
+                    t0, t1 = getattr(opx, nm), getattr(opy, nm)
+                    dv = (t0 - t1).abs()
+                    print("      X41/conv", nm, "equal", torch.equal(t0, t1), "ndiff", int((dv > 0).sum()), "of", dv.numel(), "max", float(dv.max()))
     print("   differing activation grads, backward order:", [n for n in reversed(order) if n in bad_d or (n + ":z") in bad_d][:8])
     print(f"trial {trial}: activations differing {len(bad_a)} {bad_a[:4]}; activation grads differing {len(bad_d)} {bad_d[:6]}; "
           f"param grads differing {len(bad_g)} {bad_g[-6:]}", flush=True)

@@ -9,7 +9,7 @@ def dev_f32(a):
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(3)
 M = U.M
-def setup(N, H, W, cin, cout, tile):
+def setup(N, H, W, cin, cout, tile, variant=3):
     kshape = (4, 4, cout, cin)
     kern = (rng.standard_normal(kshape).astype(np.float32) * 0.05).astype(np.float16).astype(np.float32)
     dz = h16(torch.randn(N, 2 * H, 2 * W, cout))
@@ -28,7 +28,7 @@ def setup(N, H, W, cin, cout, tile):
     a.seg_c[0], a.seg_cs[0], a.seg_woff[0], a.seg_ptr[0] = n_rows, dzd.shape[3], 0, dzd.data_ptr()
     a.w, a.Kpad, a.n_rows, a.n_valid = wt.data_ptr(), rows_pad, cs_in, cs_in
     a.out, a.out_cs, a.out_coff = dx.data_ptr(), cs_in, 0
-    a.tile_m, a.tile_n, a.variant = tile[0], tile[1], 3
+    a.tile_m, a.tile_n, a.variant = tile[0], tile[1], variant
     return a, dx, (wt, dzd, Ed)
 def stress(name, a, dx, beside):
     side = torch.cuda.Stream()
@@ -58,3 +58,10 @@ stress("tconv dgrad 16x16 1024<-512, alone", a, dx, None)
 # beside: another copy of a heavy forward-type launch on the second stream
 a2, dx2, keep2 = setup(16, 32, 32, 512, 256, (256, 128))
 stress("tconv dgrad 16x16 1024<-512, a 32x32 launch beside", a, dx, lambda s: ffi.call("seg_igemm_fwd", C.byref(a2), C.c_void_p(s)))
+
+for tile in ((128, 128), (128, 64)):
+    a3, dx3, keep3 = setup(16, 16, 16, 1024, 512, tile, 0)
+    stress(f"16-tap v2 kernel {tile[0]}x{tile[1]}, 16x16 1024<-512, alone", a3, dx3, None)
+    stress(f"16-tap v2 kernel {tile[0]}x{tile[1]}, 16x16 1024<-512, launch beside", a3, dx3, lambda s: ffi.call("seg_igemm_fwd", C.byref(a2), C.c_void_p(s)))
+a4, dx4, keep4 = setup(16, 8, 8, 2048, 1024, (128, 64), 0)
+stress("16-tap v2 kernel 128x64, 8x8 2048<-1024, launch beside", a4, dx4, lambda s: ffi.call("seg_igemm_fwd", C.byref(a2), C.c_void_p(s)))
