@@ -181,13 +181,10 @@ def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg):
 def test_training_is_bit_reproducible_at_the_headline_config():
     """Two runs of three optimiser steps of C3 at its BASELINE batch leave bit-identical parameters: the pixel-split weight
     gradients go through per-layer partial tiles and an ordered reduce instead of float atomics (SEG_WGRAD_DETERMINISTIC).
-    Held bit for bit on the single-stream schedule (`use_side_stream = False`, what SEG_WGRAD_STREAM=0 selects).  On the
-    default two-stream schedule 95-99 % of the runs are bit-identical as well; in the rest the gradients from the deepest
-    decoder node upstream differ in their low-order bits (found at the end of round 2 with tools/repro_probe.py; the build of
-    the start of the round shows it at the same rate; cause not found - neither the optimiser overlap, nor the early fork, nor
-    any one weight-gradient kernel generation removes it, only running the weight gradients on the main stream does).  That
-    schedule is therefore held to agreement of the parameter gradients of one pass to 1e-5 (relative L2; measured 5e-7 when it
-    happens), and the outcome is printed."""
+    Checked on the single-stream schedule (`use_side_stream = False`, what SEG_WGRAD_STREAM=0 selects) and on the default
+    two-stream one.  History: until the end of round 2 1-10 % of the two-stream runs differed in one
+    32 x 32 tile of a deep-level data gradient; the launches involved were the 64-deep, two-stage-ring form of the LDS-DMA
+    per-tap kernel, which is opt-in since (0 differing runs in 240 with the three-stage rings, tools/repro_probe.py)."""
     def run(side_stream, steps, grads_only=False):
         torch.manual_seed(5)
         model, x, targets, loss = CONFIGS["C3"](16)
@@ -204,13 +201,11 @@ def test_training_is_bit_reproducible_at_the_headline_config():
         model._join_side()
         torch.cuda.synchronize()
         return model.store.P.clone(), model.store.S.clone(), model.store.G.clone()
-    p0, s0, _ = run(False, 3)
-    p1, s1, _ = run(False, 3)
-    assert torch.equal(p0, p1) and torch.equal(s0, s1)
-    del p0, p1, s0, s1
+    for side in (False, True):
+        p0, s0, _ = run(side, 3)
+        p1, s1, _ = run(side, 3)
+        assert torch.equal(p0, p1) and torch.equal(s0, s1), f"parameters differ between two identical runs (side stream: {side})"
+        del p0, p1, s0, s1
     _, _, g0 = run(True, 0, grads_only=True)          # from identical weights: one forward / backward pass
     _, _, g1 = run(True, 0, grads_only=True)
-    same = torch.equal(g0, g1)
-    d = float((g0.double() - g1.double()).norm() / g0.double().norm().clamp_min(1e-30))
-    print(f"two-stream schedule: gradients bit-identical = {same}, relative L2 difference = {d:.3e}")
-    assert d < 1e-5
+    assert torch.equal(g0, g1)
