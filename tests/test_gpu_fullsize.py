@@ -183,8 +183,9 @@ def test_training_is_bit_reproducible_at_the_headline_config():
     gradients go through per-layer partial tiles and an ordered reduce instead of float atomics (SEG_WGRAD_DETERMINISTIC).
     Checked on the single-stream schedule (`use_side_stream = False`, what SEG_WGRAD_STREAM=0 selects) and on the default
     two-stream one.  History: until the end of round 2 1-10 % of the two-stream runs differed in one
-    32 x 32 tile of a deep-level data gradient; the launches involved were the 64-deep, two-stage-ring form of the LDS-DMA
-    per-tap kernel, which is opt-in since (0 differing runs in 240 with the three-stage rings, tools/repro_probe.py)."""
+    32 x 32 tile of a deep-level data gradient - a write-after-read hazard on an LDS ring slot across s_barrier (fragment reads
+    issued but not returned when the slot was refilled), visible only with the other stream's kernels backing up the LDS; every
+    ring kernel now waits for its own LDS reads in front of the slot-releasing barrier (tools/repro_probe.py)."""
     def run(side_stream, steps, grads_only=False):
         torch.manual_seed(5)
         model, x, targets, loss = CONFIGS["C3"](16)

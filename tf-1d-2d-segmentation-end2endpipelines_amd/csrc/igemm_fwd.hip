@@ -332,6 +332,12 @@ __global__ __launch_bounds__(256, ((BM == 128 && (BKE == 32 || BN == 64)) ? 3 : 
       constexpr int t2 = (t + DIST) % NT, k2 = (t + DIST) / NT;
       if (DIST == 2 && it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // two-stage ring: the stage the loads issued below go into is the one this wave read LAST step.  The compiler may
+      // leave the final MFMAs of that step - and the wait for their fragment reads - behind this barrier (gfx950 puts no
+      // implicit wait in front of s_barrier), so the reads must have RETURNED, not just been issued, before any wave may
+      // start overwriting the stage: with the LDS backed up by a co-resident kernel a queued read otherwise returns the next
+      // step's bytes (one 32 x 32 tile a K step off in 1-10 % of the training steps, tools/repro_probe.py)
+      if (DIST == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       int st2 = stage + DIST;
@@ -431,13 +437,9 @@ static void launch_fwd2_nt(const seg_igemm_fwd_args& a, dim3 grid, size_t lds, h
 static int fwd2_bk(const seg_igemm_fwd_args& a, long nblocks) {
   const char* env = std::getenv("SEG_V2_BK");     // read per call: tools/op_bench.py flips it between launches
   if (env != nullptr) return std::atoi(env) == 64 ? 64 : 32;
-  // The 64-deep step runs a TWO-stage ring (the loads of step s + 1 are issued when step s starts and consumed one barrier
-  // later).  In the training step - never in thousands of repeated launches on its own - one 32 x 32 output tile of such a
-  // launch came out a K step off in 1-10 % of the runs, depending on how hard the weight-gradient stream pressed on the same
-  // CUs (tools/repro_probe.py: 8 / 80 runs with two weight-gradient blocks per CU, 0 / 80 with the three-stage rings only).
-  // The protocol (own vmcnt(0), s_barrier, then other waves' reads) is the documented one and the three-stage kernels use it
-  // with one more step of slack; until the two-stage form is understood it is opt-in (SEG_V2_TWO_STAGE=1).
-  static const bool two_stage = std::getenv("SEG_V2_TWO_STAGE") != nullptr;
+  // (the 64-deep step runs a two-stage ring; SEG_V2_TWO_STAGE=0 keeps every launch on the 32-deep three-stage form - the
+  // bisecting switch of the LDS write-after-read hazard described at the barrier of igemm_fwd2_kernel)
+  static const bool two_stage = std::getenv("SEG_V2_TWO_STAGE") == nullptr || std::atoi(std::getenv("SEG_V2_TWO_STAGE")) != 0;
   if (!two_stage) return 32;
   if (a.Kpad & 63) return 32;
   int cmin = 1 << 30;

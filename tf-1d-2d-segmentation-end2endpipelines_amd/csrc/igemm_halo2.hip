@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (fragment reads of the step before must have RETURNED before their ring slot is refilled: igemm_fwd.hip, two-stage ring)
         if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + (NSLOT - 1) < nsteps) {

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_
   for (int ck = 0; ck < nchunks; ++ck) {
     static_for<0, NSTEP>([&](auto tgc) {
       constexpr int tg = decltype(tgc)::value;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the loaders refill the slot of the step before right behind this barrier: its fragment reads must have returned)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (dbg & 8) { slot = slot == NSLOT - 1 ? 0 : slot + 1; return; }

@@ -216,6 +216,9 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_halo_ws_kernel(const seg_i
   {
     int stage = 0;
     for (int q = q0; q < q1; ++q) {
+      // the loaders refill the slot of patch q - 1 right behind this barrier: its transposing reads must have returned
+      // (not just been issued) - see the two-stage ring of igemm_fwd.hip
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       compute(stage);
