@@ -277,7 +277,7 @@ def pick_tile_fwd(M, n_rows, ncls, ktot=1 << 30):
 
 
 def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
-    """Mirror of seg_wgrad_taps_per_block() (csrc/igemm.hip); tests/test_cabi.py keeps the two in step."""
+    """Mirror of seg_wgrad_taps_per_block() (csrc/igemm_wgrad.hip); tests/test_cabi.py keeps the two in step."""
     if variant != 0 or tile_m != 64:
         return 1
     if tile_n == 64:
@@ -288,7 +288,7 @@ def wgrad_taps_per_block(tile_m, tile_n, ntaps, variant=0):
 
 
 def fwd_halo_patch(g: Geom) -> int:
-    """Mirror of seg_fwd_halo_patch() (csrc/igemm.hip): patch width of the halo-tile forward / data-gradient kernel
+    """Mirror of seg_fwd_halo_patch() (csrc/igemm_halo.hip): patch width of the halo-tile forward / data-gradient kernel
     (variant 3; 32 = 8x32-pixel patches, 16 = 16x16), 0 when the geometry is neither a stride-1 'same' convolution with
     the nine tap offsets {-1,0,1}^2 (in any order) nor a 4x4 / stride-2 transposed convolution (four sub-pixel classes
     of 2x2 taps), or the image is not tiled by those patches."""
@@ -376,7 +376,7 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
 
 
 def wgrad_halo_patch(g: Geom) -> int:
-    """Mirror of seg_wgrad_halo_patch() (csrc/igemm.hip): patch width of the LDS-DMA halo-tile weight-gradient kernel
+    """Mirror of seg_wgrad_halo_patch() (csrc/igemm_wgrad.hip): patch width of the LDS-DMA halo-tile weight-gradient kernel
     (variant 2) for this geometry, 0 when it is neither a 3x3 / stride-1 / 'same' convolution nor a 4x4 / stride-2
     transposed convolution the kernel can tile."""
     if (g.isy, g.isx) != (1, 1) or (g.Hl, g.Wl) != (g.Hin, g.Win):
