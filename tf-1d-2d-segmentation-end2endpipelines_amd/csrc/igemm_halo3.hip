@@ -161,7 +161,7 @@ __global__ __launch_bounds__(768, 3) void igemm_fwd5_kernel(const seg_igemm_fwd_
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();          // loader waves: no LDS reads of their own
         asm volatile("" ::: "memory");
         if (tg == 0 && ck + 1 < nchunks) {
           issueA(cA, abuf ^ 1);

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_halo_ws_kernel(const seg_i
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();          // loader waves: no LDS reads of their own
       asm volatile("" ::: "memory");
       if (q + NSTAGE - 1 < q1) issue(q + NSTAGE - 1, slot_next);
       slot_next = slot_next == NSTAGE - 1 ? 0 : slot_next + 1;
