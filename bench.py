@@ -128,6 +128,21 @@ def profiled_step(model, x, targets, rank0=True):
     return KP
 
 
+def profiled_steps(model, x, targets, rank0=True, passes=3):
+    """`passes` profiled steps; KP.records is left holding the pass whose GEMM launches took the MEDIAN total time, so that one
+    interrupted launch (a clock ramp, a context switch: seen in about 1 run of 30) cannot distort the roofline figure.  Returns
+    KP and the GEMM seconds of every pass (reported beside the figure)."""
+    runs = []
+    for _ in range(passes):
+        KP = profiled_step(model, x, targets, rank0)
+        recs = list(KP.records)
+        tot = sum(e0.elapsed_time(e1) for n, _t, _f, _b, e0, e1 in recs if n.startswith("seg_igemm")) * 1e-3 if rank0 else 0.0
+        runs.append((tot, recs))
+    order = sorted(range(passes), key=lambda i: runs[i][0])
+    KP.records[:] = runs[order[passes // 2]][1]
+    return KP, [round(r[0], 6) for r in runs]
+
+
 def gemm_summary(KP, peak):
     """Per entry point and for the 3x3 conv stack (every GEMM launch that is not a transposed conv): seconds, FLOPs, fraction of peak."""
     out = {}
@@ -178,7 +193,7 @@ def short_run(workload, dtype, steps, warmup, profile=True):
         res["roofline"] = {"bound": "hbm", "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
     if profile:
-        KP = profiled_step(model, x, targets)
+        KP, _ = profiled_steps(model, x, targets)
         gs = gemm_summary(KP, peak)
         summ = KP.summary()
         res["gemm"] = gs
@@ -304,7 +319,7 @@ def main():
     roofline = None
     if not args.no_profile:
         # EVERY rank runs the profiled step: with data parallelism it contains the gradient all-reduces
-        KP = profiled_step(model, x, targets, rank0=(rank == 0))
+        KP, gemm_pass_s = profiled_steps(model, x, targets, rank0=(rank == 0))
     if not args.no_profile and rank == 0:
         summ = KP.summary()
         if args.dump_launches:
@@ -325,6 +340,7 @@ def main():
                     "algorithmic_flops_per_launch": d_["flops"] / d_["launches"],
                     "step_share": d_["seconds"] / tot_s,
                     "gemm": gemm_summary(KP, peak),
+                    "gemm_seconds_of_each_profiled_pass": gemm_pass_s, "pass_reported": "median",
                     "streaming_kernel_ms_per_step": round((tot_s - gemm_s) * 1e3, 3),
                     "kernel_seconds_per_step": {k: round(v["seconds"], 6) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])},
                     "whole_step_tflops": flop_img * bs / (ms * 1e-3) / 1e12}
