@@ -17,11 +17,15 @@ namespace {
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, bool SPLIT = false>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args p) {
+__global__ __launch_bounds__(256, (SPLIT && BM * BN < 128 * 128) ? 2 : 1) void igemm_fwd_kernel(const seg_igemm_fwd_args p) {
   static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 contraction is the fp32 mode's");
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int EPC = ET<T>::EPC, BK = 4 * EPC;      // elements per 16-B chunk / per K step
-  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+  // split mode: KS = 2 sub-tiles (16 fp32 channels each, rows of [16 hi | 16 lo] halves) per K step - 24 MFMAs per wave and
+  // barrier instead of 12, eight 16-B loads per thread in flight instead of four
+  constexpr int KS = SPLIT ? 2 : 1;
+  constexpr int EPC = ET<T>::EPC, BKS = 4 * EPC, BK = KS * BKS;      // elements per 16-B chunk / per sub-tile / per K step
+  constexpr int A_SUB = BM * ROW_BYTES, B_SUB = BN * ROW_BYTES;
+  constexpr int A_BYTES = KS * A_SUB, B_BYTES = KS * B_SUB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
   int niter = 0;
   for (int s = 0; s < p.nseg; ++s) niter += ((p.seg_c[s] + BK - 1) / BK) * g.ntaps;
 
-  u4 ra[TM], rb[TN];
+  u4 ra[KS][TM], rb[KS][TN];
   const T* wbase = (const T*)p.w;
 
   auto gload = [&](int seg, int c0, int tap) {
@@ -91,23 +95,29 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
     const int sc = p.seg_c[seg];
     const int e = cls * g.ntaps + tap;
     const int dy = g.tap_dy[e], dx = g.tap_dx[e], widx = g.tap_w[e];
-    const int cc = c0 + ld_ch * EPC;
-    const bool cok = cc < sc;
 #pragma unroll
-    for (int r = 0; r < TM; ++r) {
-      int y = a_y[r] + dy, x = a_x[r] + dx;
-      bool ok = cok && a_ok[r] && (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win;
-      size_t off = ((size_t)(a_pix[r] + y * g.Win + x)) * cs + cc;
-      u4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = ld16(sp + off);
-      ra[r] = v;
-    }
-    const T* wp = wbase + (size_t)widx * p.Kpad + p.seg_woff[seg] + cc;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cc = c0 + ks * BKS + ld_ch * EPC;
+      const bool cok = cc < sc;
 #pragma unroll
-    for (int r = 0; r < TN; ++r) {
-      u4 v = {0u, 0u, 0u, 0u};
-      if (b_ok[r]) v = ld16(wp + b_rowoff[r]);
-      rb[r] = v;
+      for (int r = 0; r < TM; ++r) {
+        int y = a_y[r] + dy, x = a_x[r] + dx;
+        bool ok = cok && a_ok[r] && (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win;
+        size_t off = ((size_t)(a_pix[r] + y * g.Win + x)) * cs + cc;
+        u4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = ld16(sp + off);
+        ra[ks][r] = v;
+      }
+      // (a sub-tile past the segment's channels meets zero activations; its weights are not read either - they would come from
+      // the next segment's or the next tap's columns, or from beyond the last row)
+      const bool wok = KS == 1 || cok;
+      const T* wp = wbase + (size_t)widx * p.Kpad + p.seg_woff[seg] + cc;
+#pragma unroll
+      for (int r = 0; r < TN; ++r) {
+        u4 v = {0u, 0u, 0u, 0u};
+        if (b_ok[r] && wok) v = ld16(wp + b_rowoff[r]);
+        rb[ks][r] = v;
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -115,21 +125,27 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const seg_igemm_fwd_args
     unsigned char* B = A + A_BYTES;
     if constexpr (SPLIT) {
 #pragma unroll
-      for (int r = 0; r < TM; ++r) split_store(A, ld_row + 64 * r, ld_ch, ra[r]);
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int r = 0; r < TN; ++r) split_store(B, ld_row + 64 * r, ld_ch, rb[r]);
+        for (int r = 0; r < TM; ++r) split_store(A + ks * A_SUB, ld_row + 64 * r, ld_ch, ra[ks][r]);
+#pragma unroll
+        for (int r = 0; r < TN; ++r) split_store(B + ks * B_SUB, ld_row + 64 * r, ld_ch, rb[ks][r]);
+      }
     } else {
 #pragma unroll
-      for (int r = 0; r < TM; ++r) st16(A + lds_off(ld_row + 64 * r, ld_ch), ra[r]);
+      for (int r = 0; r < TM; ++r) st16(A + lds_off(ld_row + 64 * r, ld_ch), ra[0][r]);
 #pragma unroll
-      for (int r = 0; r < TN; ++r) st16(B + lds_off(ld_row + 64 * r, ld_ch), rb[r]);
+      for (int r = 0; r < TN; ++r) st16(B + lds_off(ld_row + 64 * r, ld_ch), rb[0][r]);
     }
   };
   const int fr = lane & 31, fh = lane >> 5;
   auto compute = [&](int buf) {
     const unsigned char* A = smem + buf * (A_BYTES + B_BYTES);
-    if constexpr (SPLIT) mma_step_split<TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc, accl);
-    else mma_step<T, TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        mma_step_split<TM, TN>(A + ks * A_SUB, A + A_BYTES + ks * B_SUB, wm * (BM / 2), wn * (BN / 2), fr, fh, acc, accl);
+    } else mma_step<T, TM, TN>(A, A + A_BYTES, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
   };
 
   // ---- main loop: iteration order (segment, channel chunk, tap) with taps innermost
@@ -518,7 +534,7 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   const int mblocks = (int)((M + a->tile_m - 1) / a->tile_m);
   const int nblocks = (a->n_rows + a->tile_n - 1) / a->tile_n;
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a->g.ncls, 1), block(256, 1, 1);
-  const int lds_main = 2 * (a->tile_m + a->tile_n) * ROW_BYTES;
+  const int lds_main = 2 * (a->tile_m + a->tile_n) * ROW_BYTES * ((sizeof(T) == 4 && f32_split_enabled()) ? 2 : 1);     // split mode: two sub-tiles per K step
   const int lds_epi = STG_BYTES + 2 * a->tile_n * 2 * 4;
   const size_t lds = (size_t)(lds_main > lds_epi ? lds_main : lds_epi);
   hipStream_t st = (hipStream_t)stream;

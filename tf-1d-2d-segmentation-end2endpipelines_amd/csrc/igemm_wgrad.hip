@@ -10,16 +10,17 @@ namespace {
 // transposing LDS read ds_read_b64_tr_b16 (VARIANT 0) or transposed while being stored to LDS (VARIANT 1).
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int VARIANT, bool SPLIT = false>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
-  static_assert(!SPLIT || (sizeof(T) == 4 && VARIANT == 1), "the split-fp16 contraction is the fp32 mode's (transposing-store form)");
-  static_assert(sizeof(T) == 2 || VARIANT == 1, "the transposing LDS read exists for 16-bit elements only");
+__global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
+  static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 contraction is the fp32 mode's");
+  static_assert(sizeof(T) == 2 || VARIANT == 1 || SPLIT, "the transposing LDS read exists for 16-bit elements only (fp32: as hi / lo halves)");
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int EPC = ET<T>::EPC;
-  constexpr int PK = 4 * EPC;                      // pixels per step (one 64-B LDS row in the transposed tile)
-  // VARIANT 0 tiles: [32 pixels][BM halves] rows of BM*2 + 64 bytes
+  constexpr int PK = (VARIANT == 0) ? 32 : 4 * EPC;   // pixels per step (VARIANT 1: one 64-B LDS row in the transposed tile)
+  // VARIANT 0 tiles: [32 pixels][BM halves] rows of BM*2 + 64 bytes; SPLIT: a hi tile followed by a lo tile of that shape
   constexpr int ZLD = BM * 2 + 64, ALD = BN * 2 + 64;
-  constexpr int Z_BYTES = (VARIANT == 0) ? PK * ZLD : BM * ROW_BYTES;
-  constexpr int A_BYTES = (VARIANT == 0) ? PK * ALD : BN * ROW_BYTES;
+  constexpr int NPL = (SPLIT && VARIANT == 0) ? 2 : 1;
+  constexpr int Z_BYTES = (VARIANT == 0) ? NPL * PK * ZLD : BM * ROW_BYTES;
+  constexpr int A_BYTES = (VARIANT == 0) ? NPL * PK * ALD : BN * ROW_BYTES;
   constexpr int ZCH = BM / EPC, ACH = BN / EPC;    // 16-B chunks per pixel row
   constexpr int ZPT = (PK * ZCH) / 256, APT = (PK * ACH) / 256;   // chunks per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,7 +129,24 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
   auto lstore = [&](int buf) {
     unsigned char* Z = smem + buf * (Z_BYTES + A_BYTES);
     unsigned char* A = Z + Z_BYTES;
-    if constexpr (VARIANT == 0) {
+    if constexpr (VARIANT == 0 && SPLIT) {
+      // 4 fp32 channels of one pixel -> 4 hi halves + 4 lo halves, 8 B each into the [pixel][channel] hi / lo tiles (a wave
+      // writes 256 contiguous bytes per pixel row; the transposing-store form's 2-byte stores ran 16 deep into one bank group)
+#pragma unroll
+      for (int r = 0; r < ZPT; ++r) {
+        h4 hi, lo;
+        split4(rz[r], hi, lo);
+        *reinterpret_cast<h4*>(Z + z_p[r] * ZLD + z_c[r] * 8) = hi;
+        *reinterpret_cast<h4*>(Z + PK * ZLD + z_p[r] * ZLD + z_c[r] * 8) = lo;
+      }
+#pragma unroll
+      for (int r = 0; r < APT; ++r) {
+        h4 hi, lo;
+        split4(ra[r], hi, lo);
+        *reinterpret_cast<h4*>(A + a_p[r] * ALD + a_c[r] * 8) = hi;
+        *reinterpret_cast<h4*>(A + PK * ALD + a_p[r] * ALD + a_c[r] * 8) = lo;
+      }
+    } else if constexpr (VARIANT == 0) {
 #pragma unroll
       for (int r = 0; r < ZPT; ++r) st16(Z + z_p[r] * ZLD + z_c[r] * 16, rz[r]);
 #pragma unroll
@@ -201,10 +219,40 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const seg_igemm_wgrad_
           h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
           bf[b] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
         }
+        if constexpr (SPLIT) {
+          h8 afl[TM], bfl[TN];
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+          for (int a = 0; a < TM; ++a) {
+            int colh = wm * (BM / 2) + a * 32 + 16 * (tg & 1) + 4 * tp;
+            const unsigned char* ad = Z + PK * ZLD + krow * ZLD + colh * 2;
+            s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
+            s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * ZLD));
+            h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
+            afl[a] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
+          }
 #pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b) {
+            int colh = wn * (BN / 2) + b * 32 + 16 * (tg & 1) + 4 * tp;
+            const unsigned char* ad = A + PK * ALD + krow * ALD + colh * 2;
+            s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
+            s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * ALD));
+            h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
+            bfl[b] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
+          }
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+              accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[a], bf[b], accl[a][b], 0, 0, 0);
+              accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bfl[b], accl[a][b], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
       }
     } else {
       if constexpr (SPLIT) mma_step_split<TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc, accl);
@@ -1032,7 +1080,10 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
     SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
     return launch_wgrad_reduce(*a, (hipStream_t)stream);
   }
-  const int variant = (sizeof(T) == 4) ? 1 : (a->variant & 255);      // fp32: transposing-store form only
+  // fp32: split operands through the [pixel][channel] hi / lo tiles + transposing reads (form 0); SEG_F32_WGRAD_TR=1 keeps
+  // the round-1 transposing-store form (1), which the exact fma-chain MFMA (SEG_F32_EXACT=1) always uses
+  static const bool f32_tr = std::getenv("SEG_F32_WGRAD_TR") != nullptr && std::atoi(std::getenv("SEG_F32_WGRAD_TR")) != 0;
+  const int variant = (sizeof(T) == 4) ? ((f32_split_enabled() && !f32_tr) ? 0 : 1) : (a->variant & 255);
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
   int ktiles = 0;
   for (int s = 0; s < a->nseg; ++s) ktiles += (a->seg_c[s] + a->tile_n - 1) / a->tile_n;
@@ -1054,14 +1105,15 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   dim3 grid((unsigned)(rtiles * ktiles), (unsigned)(a->g.ncls * a->g.ntaps), (unsigned)a->splitk), block(256, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const int bm = a->tile_m, bn = a->tile_n;
-  size_t lds = (variant == 0) ? (size_t)2 * 32 * ((bm * 2 + 64) + (bn * 2 + 64)) : (size_t)2 * (bm + bn) * ROW_BYTES;
+  size_t lds = (variant == 0) ? (size_t)2 * 32 * ((bm * 2 + 64) + (bn * 2 + 64)) * (sizeof(T) == 4 ? 2 : 1) : (size_t)2 * (bm + bn) * ROW_BYTES;
 #define SEG_WG(BM_, BN_)                                                                                          \
   do {                                                                                                            \
     if constexpr (sizeof(T) == 2) {                                                                               \
       if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 0>), grid, block, lds, st, *a);        \
       else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
     } else {                                                                                                      \
-      if (f32_split_enabled()) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1, true>), grid, block, lds, st, *a);   \
+      if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 0, true>), grid, block, lds, st, *a);          \
+      else if (f32_split_enabled()) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1, true>), grid, block, lds, st, *a);   \
       else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
     }                                                                                                             \
   } while (0)
