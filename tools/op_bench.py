@@ -27,13 +27,14 @@ def main():
     ap.add_argument("--bk", default="")
     ap.add_argument("--splitk", default="")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="f16", choices=("f16", "f32"), help="f32 = the parity mode's split-fp16 kernels")
     ap.add_argument("--dbg", default="", help="comma list of timing-experiment bit masks for the pipelined halo kernel (fwd / dgrad phases; results are wrong)")
     args = ap.parse_args()
     pkg = importlib.import_module(PKG)
     M = importlib.import_module(PKG + ".model")
     kw, H, W, Cin, bs, loss, _ = bench.WORKLOADS[args.workload]
     model = pkg.unet_model_builder(length=H, width=W, num_channels=Cin, train_mode="from_scratch", **kw).ResNet50()
-    model.build(bs)
+    model.build(bs, dtype=args.dtype)
     model.compile(loss=loss, lr=2e-4)
     x, tg = bench.make_batch(model, bs, H, W, Cin, loss, 0)
     model.train_step(x, tg)
