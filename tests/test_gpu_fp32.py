@@ -28,7 +28,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (64, 64), (128, 64)])
+@pytest.mark.parametrize("tile", [(128, 128), (64, 64), (128, 64), (256, 64)])
 def test_conv_fwd_fp32_is_an_fp32_fma_chain(tile):
     xs = [torch.randn(2, 16, 16, 24), torch.randn(2, 16, 16, 40)]
     kern = rng.standard_normal((3, 3, 64, 72)).astype(np.float32) * 0.1

@@ -17,7 +17,7 @@ namespace {
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, bool SPLIT = false>
-__global__ __launch_bounds__(256, (SPLIT && BM * BN < 128 * 128) ? 2 : 1) void igemm_fwd_kernel(const seg_igemm_fwd_args p) {
+__global__ __launch_bounds__(256, (SPLIT && (BM * BN < 128 * 128 || BM == 256)) ? 2 : 1) void igemm_fwd_kernel(const seg_igemm_fwd_args p) {
   static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 contraction is the fp32 mode's");
   constexpr int TM = BM / 64, TN = BN / 64;
   // split mode: KS = 2 sub-tiles (16 fp32 channels each, rows of [16 hi | 16 lo] halves) per K step - 24 MFMAs per wave and
@@ -541,10 +541,12 @@ static int igemm_fwd_launch(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   if constexpr (sizeof(T) == 2) {
     if (fwd2_eligible(*a)) return launch_fwd2(*a, mblocks, nblocks, st);
   }
-  SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (fp16, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
+  SEG_CHECK_ARG(a->tile_m <= 128 || (sizeof(T) == 4 && f32_split_enabled()),
+                "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (fp16, taps in {1,2,3,4,9,16}, operands < 1 GiB) or the split fp32 kernel");
   if constexpr (sizeof(T) == 4) {
     if (f32_split_enabled()) {      // exact mode on the fp16 MFMA: 3 split products per fp32 product (SEG_F32_EXACT=1: the fp32 fma-chain MFMA)
-      if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 128, true>), grid, block, lds, st, *a);
+      if (a->tile_m == 256) hipLaunchKernelGGL((igemm_fwd_kernel<T, 256, 64, true>), grid, block, lds, st, *a);      // (242 VGPRs: two blocks per CU)
+      else if (a->tile_m == 128 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 128, true>), grid, block, lds, st, *a);
       else if (a->tile_m == 128 && a->tile_n == 64) hipLaunchKernelGGL((igemm_fwd_kernel<T, 128, 64, true>), grid, block, lds, st, *a);
       else if (a->tile_m == 64 && a->tile_n == 128) hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 128, true>), grid, block, lds, st, *a);
       else hipLaunchKernelGGL((igemm_fwd_kernel<T, 64, 64, true>), grid, block, lds, st, *a);

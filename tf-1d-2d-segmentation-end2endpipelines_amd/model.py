@@ -354,6 +354,7 @@ FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo ti
 # behind them instead of running beside them.  OFF by default (SEG_FWD_TWO_STREAMS=1); parity-tested with it on.
 FWD_TWO_STREAMS = os.environ.get("SEG_FWD_TWO_STREAMS", "0") != "0"
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
+F32_SPLIT = os.environ.get("SEG_F32_EXACT", "0") in ("", "0")      # parity mode on the fp16 MFMA with split operands (csrc: f32_split_enabled)
 
 
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
@@ -374,11 +375,14 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
         # parity mode (register-staged split-fp16 kernel): the 128 x 128 tile holds 256 accumulator registers (hi x hi and the
         # cross terms) and runs one block per CU; two blocks of 128 x 64 are 5-15 % faster on every layer, the 64-row tiles at the
         # deep levels (measured per layer, tools/op_bench.py --dtype f32: 61.9 -> 54.4 ms over the C3 forward + data gradients).
-        # The 256-row tile exists on the fp16 LDS-DMA kernels only.
+        # A 256 x 64 split tile (four accumulator tiles per wave, 242 VGPRs: still two blocks per CU) fetches a fifth fewer
+        # operand bytes per FLOP than 128 x 64: +7-10 % on the long reductions, +2-5 % on the data gradients (same sweep); the
+        # fma-chain kernels (SEG_F32_EXACT=1) have no 256-row instance.
+        big = (256, 64) if F32_SPLIT else (128, 64)
         if tm == 256:
-            tm, tn = 128, 64
+            tm, tn = big
         elif n_rows > 64:
-            tm, tn = (128, 64) if M >= 65536 else (64, 128) if M > 1024 else (64, 64)
+            tm, tn = big if M >= 65536 else (64, 128) if M > 1024 else (64, 64)
     return tm, tn, 0
 
 
