@@ -119,3 +119,23 @@ def test_unsupported_layers_say_so():
     assert kinds.count("ReshapeOp") == 2 and m.store.slots["ae/features/kernel"].spec.shape == (8 * 8 * 32, 16)
     with pytest.raises(NotImplementedError, match="ConvLSTM filters"):
         B("UNet", 32, 32, 8, 2, lstm=1).build(2)
+
+
+def test_parity_mode_tiles_have_a_kernel_instance(monkeypatch):
+    """pick_fwd in the fp32 mode only returns tiles the register-staged kernels are instantiated for (csrc/igemm_fwd.hip):
+    256 x 64 exists for the split-fp16 form only, never for the fma-chain form (SEG_F32_EXACT=1)."""
+    g = M.geom_conv(16, 256, 256, 3, 3, 1, 1)
+    split_tiles = {(256, 64), (128, 128), (128, 64), (64, 128), (64, 64)}
+    seen = set()
+    for Mtot in (1024, 4096, 16384, 65536, 262144, 1048576):
+        for n_rows in (8, 64, 128, 384, 2048):
+            for ktot in (288, 1152, 18432):
+                tm, tn, variant = M.pick_fwd(Mtot, n_rows, g, ktot, False)
+                assert variant == 0 and (tm, tn) in split_tiles
+                seen.add((tm, tn))
+    assert (256, 64) in seen and (64, 64) in seen            # large levels take the 256-row tile, the deep ones the 64-row tiles
+    monkeypatch.setattr(M, "F32_SPLIT", False)
+    for Mtot in (65536, 1048576):
+        for n_rows in (64, 128, 384):
+            tm, tn, _ = M.pick_fwd(Mtot, n_rows, g, 1152, False)
+            assert tm <= 128
