@@ -9,6 +9,8 @@
 // LDS rows are 64 B (32 halves) with the 16-B chunk index XOR-swizzled by (row >> 2) & 3 so that every
 // ds_read_b128 16-lane group touches 16 distinct bank quads.  The epilogue stages each 32x32 accumulator
 // tile through a per-wave LDS slab so that global stores are 16 B per lane along the channel axis.
+// fp32 (parity mode): the same kernel with SPLIT - operands split into hi / lo fp16 halves on their way into LDS, three fp16
+// MFMAs per product, two 16-channel sub-tiles per K step; tiles 256x64 / 128x64 / 64x128 / 64x64 (model.pick_fwd).
 #include "igemm_common.h"
 
 namespace {

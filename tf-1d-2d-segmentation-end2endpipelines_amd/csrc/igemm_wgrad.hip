@@ -8,6 +8,8 @@ namespace {
 // weight gradient:  D[n][k] = sum_pix dz[pix][n] * in[pix + tap][k]   (reduction dimension = pixels)
 // Both operands are "reduction-major" in memory, so their MFMA fragments are read with the hardware
 // transposing LDS read ds_read_b64_tr_b16 (VARIANT 0) or transposed while being stored to LDS (VARIANT 1).
+// fp32 (parity mode, SPLIT): VARIANT 0 on hi / lo fp16 tiles of the split operands, three MFMAs per product, 32 pixels per
+// step; VARIANT 1 remains for the fma-chain MFMA (SEG_F32_EXACT=1) and as SEG_F32_WGRAD_TR=1.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int VARIANT, bool SPLIT = false>
 __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
