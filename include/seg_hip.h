@@ -334,10 +334,13 @@ int seg_optimizer_step(int32_t kind, float* p, const float* g, float* s1, float*
  *              as in the plain forms - Keras would propagate the NaN; here the count makes the overflow visible and
  *              harness.fit reacts by halving the fp16 loss scale)                                                       */
 enum { SEG_GRAD_F32 = 0, SEG_GRAD_BF16 = 1 };
-int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float* m, float* v, void* p16, int64_t n, float alpha_t,
+/*   p16_fmt    layout of the operand copy p16 (may be NULL): SEG_OPERAND_F16 = fp16 image, 2 B per element (throughput
+ *              mode); SEG_OPERAND_SPLIT = the parity mode's split pair, 4 B per element (see "parity mode" below)           */
+enum { SEG_OPERAND_F16 = 0, SEG_OPERAND_SPLIT = 1 };
+int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float* m, float* v, void* p16, int32_t p16_fmt, int64_t n, float alpha_t,
                      const float* alpha_ptr, float b1, float b2, float eps, float gmul, uint32_t* nonfinite, seg_stream_t stream);
-int seg_optimizer_step_ex(int32_t kind, float* p, const void* g, int32_t g_dtype, float* s1, float* s2, void* p16, int64_t n,
-                          const float* c, float gmul, uint32_t* nonfinite, seg_stream_t stream);
+int seg_optimizer_step_ex(int32_t kind, float* p, const void* g, int32_t g_dtype, float* s1, float* s2, void* p16, int32_t p16_fmt,
+                          int64_t n, const float* c, float gmul, uint32_t* nonfinite, seg_stream_t stream);
 /* y[i] = bf16(x[i]), round to nearest even, NaN / Inf preserved: packs a finished slice of the flat fp32 gradient buffer
  * for the data-parallel exchange (half the bytes over xGMI).  x 32-byte, y 16-byte aligned.               */
 int seg_cast_f32_bf16(const float* x, void* y, int64_t n, seg_stream_t stream);
@@ -362,17 +365,27 @@ typedef struct seg_transpose_desc {
 int seg_transpose_w_multi(const seg_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, seg_stream_t stream);
 /* fp32 -> fp16 cast of n elements                                                                              */
 int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream);
+/* flat fp32 buffer -> its split image (parity mode's GEMM weight operand): n a multiple of 8, 32-byte aligned  */
+int seg_cast_f32_split(const float* x, void* y, int64_t n, seg_stream_t stream);
 /* fp32 NHWC [npix][C] -> fp16 [npix][cs] zero padded (model input)                                             */
 int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
 /* fp16 [npix][cs] columns [coff, coff+C) -> fp32 [npix][C]                                                     */
 int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
 
-/* ---- exact-fp32 parity mode -----------------------------------------------------------------------------------
+/* ---- parity mode (suffix _f32) ------------------------------------------------------------------------------------
  * Every entry point above that reads or writes activation tensors also exists with the suffix _f32: identical
- * arguments, but activations, the GEMM weight operand `w` (and seg_transpose_w's output) are fp32, and the
- * contraction runs on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain, 1/16 of the fp16 MFMA rate).  It is
- * the mode the 1e-3 / bit-exact-mask parity of the north star is asserted in (tests/test_gpu_fp32.py); the fp16
- * functions are the throughput mode.  seg_igemm_wgrad_f32 always uses the transposing-store form (variant 1). */
+ * arguments (channel counts / strides / offsets in ELEMENTS as before), 4 bytes per element, but an element is stored
+ * as a SPLIT PAIR of fp16 numbers, x ~= hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): ~22 significant
+ * bits for 2^-14 <= |x| < 65504 (absolute error floor ~2^-36 below, Inf / NaN above - loud, not silent).  Eight
+ * consecutive channels (an 8-aligned group; every cs / coff is a multiple of 8) occupy 32 bytes = [8 hi | 8 lo], so a
+ * 16-byte chunk is an MFMA-ready fragment and the GEMM kernels fetch operands by LDS-DMA exactly as in fp16 mode and
+ * contract a b ~= ah bh + (al bh + ah bl) / 2048 with three v_mfma_f32_32x32x16_f16 per product into two fp32
+ * accumulators.  The GEMM weight operand `w` (and seg_transpose_w's output) have the same split layout along their
+ * innermost axis (seg_cast_f32_split / the optimiser's SEG_OPERAND_SPLIT copy produce it from the fp32 master).
+ * seg_pack_input_f32 / seg_unpack_f32_f32 convert from / to plain fp32 at the boundary; model outputs (heads) and
+ * every statistic / gradient-of-parameter buffer are plain fp32 in both modes.  This is the mode the reference's fp32
+ * arithmetic (2DCNN/Train.py:322-325: no mixed-precision policy) is matched in: every output within 1e-3 and equal
+ * masks (tests/test_gpu_fp32.py, tests/test_gpu_fullsize.py); the un-suffixed functions are the fp16 throughput mode. */
 int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t stream);
 int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream);
 int seg_bn_stats_f32(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts,

@@ -32,12 +32,26 @@ def r32(v):
     return (v + 31) // 32 * 32
 
 
+SF = importlib.import_module(PKG + ".splitfmt")
+
+
 def to_dev_nhwc(x: torch.Tensor, dt=torch.float16) -> torch.Tensor:
-    """fp32 NHWC CPU -> fp16 (or fp32) NHWC cuda with the channel stride padded to 8."""
+    """fp32 NHWC CPU -> NHWC cuda with the channel stride padded to 8: fp16, or (dt float32 = the parity mode) split pairs."""
     N, H, W, Cc = x.shape
     t = torch.zeros((N, H, W, r8(Cc)), dtype=dt, device="cuda")
     t[..., :Cc] = x.to("cuda", dt)
-    return t
+    return SF.split_pack(t) if dt == torch.float32 else t
+
+
+def dev_values(t: torch.Tensor) -> torch.Tensor:
+    """fp32 values of a device storage tensor (fp16, or split pairs typed float32), on the CPU."""
+    return (SF.split_unpack(t) if t.dtype == torch.float32 else t.float()).cpu()
+
+
+def dev_weights(E: np.ndarray, f32: bool) -> torch.Tensor:
+    """GEMM weight operand [rows][T][Kpad] (Kpad % 32 == 0) in the storage format of the mode."""
+    w = torch.from_numpy(np.ascontiguousarray(E, np.float32)).cuda()
+    return SF.split_pack(w) if f32 else w.to(torch.float16).contiguous()
 
 
 def h16(x: torch.Tensor) -> torch.Tensor:
@@ -62,7 +76,7 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         k += r32(d.shape[3])
     Kpad = k
     E = M.pack_gemm_weight(kern, cin_l, woff, n_rows, Kpad, transposed)
-    w16 = torch.from_numpy(E).to("cuda", dt).contiguous()
+    w16 = dev_weights(E, f32)
     g = M.geom_convT(N, H, W, kh, kw, *strides) if transposed else M.geom_conv(N, H, W, kh, kw, *strides)
     Ho, Wo = g.Hout, g.Wout
     a = ffi.IgemmFwdArgs()
@@ -76,6 +90,8 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         a.accumulate = 1
     else:
         out = torch.full((N, Ho, Wo, n_rows), 7.0, dtype=dt, device="cuda")
+        if f32:
+            out = SF.split_pack(out)
     a.out, a.out_cs, a.out_coff = out.data_ptr(), n_rows, 0
     bdev = None
     if bias is not None:
@@ -93,8 +109,9 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         a.stats = stats.data_ptr()
     ffi.call("seg_igemm_fwd_f32" if f32 else "seg_igemm_fwd", C.byref(a), stream())
     torch.cuda.synchronize()
-    res = out[..., :cout].float().cpu()
-    pad = out[..., cout:].float().abs().max().item() if n_rows > cout else 0.0
+    outv = dev_values(out)
+    res = outv[..., :cout]
+    pad = outv[..., cout:].abs().max().item() if n_rows > cout else 0.0
     return res, (stats.sum(0).cpu() if stats is not None else None), pad
 
 
@@ -126,7 +143,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
     a.dz, a.dz_cs, a.dz_coff = dzd.data_ptr(), dzd.shape[3], 0
     a.dw, a.Kpad, a.n_rows = dw.data_ptr(), Kpad, n_rows
     Mtot = N * g.Hl * g.Wl
-    tm, tn, sk = M.pick_tile_wgrad(Mtot, n_rows, [d.shape[3] for d in devs], g.ncls, g.ntaps, variant & 255)
+    tm, tn, sk = M.pick_tile_wgrad(Mtot, n_rows, [d.shape[3] for d in devs], g.ncls, g.ntaps, variant & 255, not f32)
     if tile:
         tm, tn = tile
     a.tile_m, a.tile_n, a.splitk = tm, tn, (splitk or sk)
@@ -195,7 +212,7 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, or
         if key not in vals:
             continue
         ref = vals[key].detach()
-        got = t.buf[..., :t.C].float().cpu()
+        got = t.values().cpu()
         if got.shape != ref.shape:
             res["nodes"].append((name, float("nan"), float(ref.abs().max())))
             continue
@@ -213,14 +230,14 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, or
             ref = vals[op.node.name].grad
             t = op.out
             if ref is not None and t.grad is not None:
-                got = t.grad[..., :t.C].float().cpu() / S
+                got = t.grad_values().cpu() / S
                 res["agrads"].append(("d/" + op.node.name, float((got - ref).abs().max()), float(ref.abs().max())))
             seen.add(t.name)
     for name, t in model.tensors.items():
         if name in seen or name.endswith(":z") or t.grad is None or name not in vals or vals[name].grad is None:
             continue
         ref = vals[name].grad
-        got = t.grad[..., :t.C].float().cpu() / S
+        got = t.grad_values().cpu() / S
         if got.shape == ref.shape:
             res["agrads"].append(("d/" + name, float((got - ref).abs().max()), float(ref.abs().max())))
     res["gcos"] = {}

@@ -16,6 +16,7 @@ LOSS = {"mse": 0, "bce": 1, "cce": 2, "mae": 3, "mape": 4, "msle": 5, "huber": 6
         "squared_hinge": 10, "binary_focal": 11, "kld": 12, "categorical_hinge": 13, "cosine": 14, "sparse_cce": 15}
 # the names `TFOptimizers(name, lr).optimizer()` takes (2DCNN/utils/tf_optimizers.py:10-26); Adam has its own entry points
 GRAD_F32, GRAD_BF16 = 0, 1
+OPERAND_F16, OPERAND_SPLIT = 0, 1
 OPTIMIZER = {"SGD": 0, "RMSprop": 1, "Adagrad": 2, "Adadelta": 3, "Adamax": 4, "Nadam": 5, "FTRL": 6}
 # the names `TFLosses(name).loss()` takes (2DCNN/utils/tf_losses.py:9-39)
 LOSS_ALIASES = {"MeanSquaredError": "mse", "BinaryCrossentropy": "bce", "CategoricalCrossentropy": "cce",
@@ -111,12 +112,13 @@ _PROTOS = {
     "seg_grad_scale": ([vp, f32, vp, vp], C.c_int),
     "seg_adam_step": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp], C.c_int),
     "seg_adam_step_dev": ([vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp], C.c_int),
-    "seg_adam_step_ex": ([vp, vp, i32, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, vp, vp], C.c_int),
-    "seg_optimizer_step_ex": ([i32, vp, vp, i32, vp, vp, vp, i64, vp, C.c_float, vp, vp], C.c_int),
+    "seg_adam_step_ex": ([vp, vp, i32, vp, vp, vp, i32, i64, f32, vp, f32, f32, f32, f32, vp, vp], C.c_int),
+    "seg_optimizer_step_ex": ([i32, vp, vp, i32, vp, vp, vp, i32, i64, vp, C.c_float, vp, vp], C.c_int),
     "seg_cast_f32_bf16": ([vp, vp, i64, vp], C.c_int),
     "seg_transpose_w": ([vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "seg_transpose_w_multi": ([vp, i32, i32, vp], C.c_int),
     "seg_cast_f32_f16": ([vp, vp, i64, vp], C.c_int),
+    "seg_cast_f32_split": ([vp, vp, i64, vp], C.c_int),
     "seg_pack_input": ([vp, vp, i64, i32, i32, vp], C.c_int),
     "seg_unpack_f32": ([vp, vp, i64, i32, i32, i32, vp], C.c_int),
 }

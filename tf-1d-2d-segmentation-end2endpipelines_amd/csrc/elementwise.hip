@@ -730,7 +730,7 @@ __global__ __launch_bounds__(TPB) void mul_bcast_fwd_kernel(const T* a, const T*
   const int64_t items = npix * CH;
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
     const int64_t pix = it / CH;
-    const float rv = (float)r[pix * r_cs];
+    const float rv = load1(r + pix * r_cs, 0);
     float f[8];
     load8(a + it * 8, f);
 #pragma unroll
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const T* dy, const T
     const int64_t pix = pix0 + grp;
     const bool ok = pix < npix;
     float dot = 0.f;
-    const float rv = ok ? (float)r[pix * r_cs] : 0.f;
+    const float rv = ok ? load1(r + pix * r_cs, 0) : 0.f;
     for (int ch = sub; ch < CH; ch += LPP) {
       if (!ok) break;
       float g[8], av[8], o[8];
@@ -773,9 +773,9 @@ __global__ __launch_bounds__(TPB) void mul_bcast_bwd_kernel(const T* dy, const T
     if (ok && sub == 0 && dr != nullptr) {
       float f[8] = {dot, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       T* dst = dr + pix * r_cs;
-      if (acc_r) f[0] += (float)dst[0];
+      if (acc_r) f[0] += load1(dst, 0);
       if (r_cs >= 8) store8(dst, f);
-      else dst[0] = (T)f[0];
+      else store1(dst, 0, f[0]);           // (fp16 only: a split tensor always has whole 8-channel groups, host-checked)
     }
   }
 }
@@ -1162,13 +1162,13 @@ __global__ __launch_bounds__(TPB) void head_act_fwd_kernel(const T* x, int cs, i
     float* yp = y + pix * C;
     if (act == SEG_ACT_SOFTMAX) {
       float mx = -3.4e38f;
-      for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)xp[k]);
+      for (int k = 0; k < C; ++k) mx = fmaxf(mx, load_elem(xp, k));
       float s = 0.f;
-      for (int k = 0; k < C; ++k) s += expf((float)xp[k] - mx);
+      for (int k = 0; k < C; ++k) s += expf(load_elem(xp, k) - mx);
       const float inv = 1.f / s;
-      for (int k = 0; k < C; ++k) yp[k] = expf((float)xp[k] - mx) * inv;
+      for (int k = 0; k < C; ++k) yp[k] = expf(load_elem(xp, k) - mx) * inv;
     } else {
-      for (int k = 0; k < C; ++k) yp[k] = seg_act((float)xp[k], act, 0.f);
+      for (int k = 0; k < C; ++k) yp[k] = seg_act(load_elem(xp, k), act, 0.f);
     }
   }
 }
@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(TPB) void head_act_bwd_kernel(const float* dy, cons
     for (int k = 0; k < cs; ++k) {
       float d = 0.f;
       if (k < C) d = (act == SEG_ACT_SOFTMAX ? yp[k] * (dp[k] - dot) : dp[k] * seg_act_grad_from_out(yp[k], act, 0.f)) * gs;
-      xp[k] = accumulate ? (T)((float)xp[k] + d) : (T)d;
+      store_elem(xp, k, accumulate ? load_elem(xp, k) + d : d);
     }
   }
 }
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(TPB) void transpose_w_kernel(const float* w, T* wt,
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = kt * 32 + ty + 8 * j, r = rt * 32 + tx;
-    if (k < K && r < rows_pad) wt[((int64_t)k * Tn + t) * rows_pad + r] = (T)tile[tx][ty + 8 * j];
+    if (k < K && r < rows_pad) store_elem(wt, ((int64_t)k * Tn + t) * rows_pad + r, tile[tx][ty + 8 * j]);
   }
 }
 
@@ -1485,12 +1485,21 @@ __global__ __launch_bounds__(TPB) void transpose_w_multi_kernel(const seg_transp
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = kt * 32 + ty + 8 * j, r = rt * 32 + tx;
-    if (k < d.kcount && r < d.rows_pad) wt[((int64_t)k * d.T + t) * d.dst_ld + d.dst_coff + r] = (T)tile[tx][ty + 8 * j];
+    if (k < d.kcount && r < d.rows_pad) store_elem(wt, ((int64_t)k * d.T + t) * d.dst_ld + d.dst_coff + r, tile[tx][ty + 8 * j]);
   }
 }
 
 __global__ __launch_bounds__(TPB) void cast_kernel(const float* x, half_t* y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) y[i] = (half_t)x[i];
+}
+
+// flat fp32 buffer -> its split image (8 consecutive elements -> [8 hi | 8 lo]); n a multiple of 8
+__global__ __launch_bounds__(TPB) void cast_split_kernel(const float* x, split_t* y, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * TPB) {
+    float f[8];
+    load8(x + 8 * i, f);
+    store8(y + 8 * i, f);
+  }
 }
 
 template <typename T>
@@ -1499,7 +1508,7 @@ __global__ __launch_bounds__(TPB) void pack_input_kernel(const float* x, T* y, i
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int c = (int)(i % cs);
     const int64_t pix = i / cs;
-    y[i] = (c < C) ? (T)x[pix * C + c] : (T)0.f;
+    store_elem(y + pix * cs, c, (c < C) ? x[pix * C + c] : 0.f);
   }
 }
 
@@ -1509,7 +1518,7 @@ __global__ __launch_bounds__(TPB) void unpack_kernel(const T* x, float* y, int64
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int c = (int)(i % C);
     const int64_t pix = i / C;
-    y[i] = (float)x[pix * cs + coff + c];
+    y[i] = load_elem(x + pix * cs, coff + c);
   }
 }
 
@@ -1522,9 +1531,11 @@ __global__ __launch_bounds__(TPB) void copy_channels_kernel(const T* src, int sr
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int64_t pix = i / C;
     const int c = (int)(i - pix * C);
-    const float v = (float)src[pix * src_cs + src_coff + c];
-    T* d = dst + pix * dst_cs + dst_coff + c;
-    *d = (T)(accumulate ? v + (float)*d : v);
+    // (element index from the tensor's base: a row stride that is not a multiple of 8 - the flattened side of the autoencoder's
+    // Reshape - still addresses whole 8-element groups of the split layout correctly)
+    const int64_t es = pix * src_cs + src_coff + c, ed = pix * dst_cs + dst_coff + c;
+    const float v = load_elem(src, es);
+    store_elem(dst, ed, accumulate ? v + load_elem(dst, ed) : v);
   }
 }
 
@@ -1545,7 +1556,7 @@ static int seg_bn_stats_impl(const void* x, int64_t npix, int32_t cs, int32_t co
   return SEG_OK;
 }
 extern "C" int seg_bn_stats(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_bn_stats_impl<half_t>(x, npix, cs, coff, C, stats, nparts, stats_ld, stats_coff, stream); }
-extern "C" int seg_bn_stats_f32(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_bn_stats_impl<float>(x, npix, cs, coff, C, stats, nparts, stats_ld, stats_coff, stream); }
+extern "C" int seg_bn_stats_f32(const void* x, int64_t npix, int32_t cs, int32_t coff, int32_t C, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_bn_stats_impl<split_t>(x, npix, cs, coff, C, stats, nparts, stats_ld, stats_coff, stream); }
 
 extern "C" int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, int64_t count, const float* gamma, const float* beta,
                                float eps, float momentum, float* moving_mean, float* moving_var, int32_t unbiased_moving,
@@ -1587,7 +1598,7 @@ static int seg_bn_act_apply_impl(const void* x, int32_t x_cs, int32_t x_coff, vo
   return SEG_OK;
 }
 extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<half_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
-extern "C" int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<float>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
+extern "C" int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<split_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
 
 static bool check_inject(const seg_head_inject* inj, const void* dy, int32_t C, const char* who) {
   if (inj == nullptr) {
@@ -1622,9 +1633,9 @@ static int seg_bn_act_bwd_reduce_impl(const void* dy, int32_t dy_cs, int32_t dy_
   return SEG_OK;
 }
 extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
-extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<float>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
+extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
 extern "C" int seg_bn_act_bwd_reduce_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
-extern "C" int seg_bn_act_bwd_reduce_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<float>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
+extern "C" int seg_bn_act_bwd_reduce_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
 
 extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma, float* dbeta,
                                    float gscale, const float* gscale_ptr, float* c1, float* c2, seg_stream_t stream) {
@@ -1660,9 +1671,9 @@ static int seg_bn_act_bwd_apply_impl(const void* dy, int32_t dy_cs, int32_t dy_c
   return SEG_OK;
 }
 extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
-extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<float>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
+extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
 extern "C" int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
-extern "C" int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<float>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
+extern "C" int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
 
 template <typename T>
 static int seg_act_bwd_impl(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,
@@ -1677,7 +1688,7 @@ static int seg_act_bwd_impl(const void* dy, const void* y, void* dx, int64_t npi
   return SEG_OK;
 }
 extern "C" int seg_act_bwd(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) { return seg_act_bwd_impl<half_t>(dy, y, dx, npix, cs, C, act, alpha, dbias, gscale, gscale_ptr, stream); }
-extern "C" int seg_act_bwd_f32(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) { return seg_act_bwd_impl<float>(dy, y, dx, npix, cs, C, act, alpha, dbias, gscale, gscale_ptr, stream); }
+extern "C" int seg_act_bwd_f32(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha, float* dbias, float gscale, const float* gscale_ptr, seg_stream_t stream) { return seg_act_bwd_impl<split_t>(dy, y, dx, npix, cs, C, act, alpha, dbias, gscale, gscale_ptr, stream); }
 
 template <typename T>
 static int seg_maxpool_fwd_impl(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw,
@@ -1689,7 +1700,7 @@ static int seg_maxpool_fwd_impl(const void* x, void* y, int32_t N, int32_t H, in
   return SEG_OK;
 }
 extern "C" int seg_maxpool_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_maxpool_fwd_impl<half_t>(x, y, N, H, W, cs, ph, pw, stream); }
-extern "C" int seg_maxpool_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_maxpool_fwd_impl<float>(x, y, N, H, W, cs, ph, pw, stream); }
+extern "C" int seg_maxpool_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_maxpool_fwd_impl<split_t>(x, y, N, H, W, cs, ph, pw, stream); }
 
 template <typename T>
 static int seg_maxpool_bwd_impl(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs,
@@ -1702,7 +1713,7 @@ static int seg_maxpool_bwd_impl(const void* dy, const void* x, const void* y, vo
   return SEG_OK;
 }
 extern "C" int seg_maxpool_bwd(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) { return seg_maxpool_bwd_impl<half_t>(dy, x, y, dx, N, H, W, cs, ph, pw, accumulate, stream); }
-extern "C" int seg_maxpool_bwd_f32(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) { return seg_maxpool_bwd_impl<float>(dy, x, y, dx, N, H, W, cs, ph, pw, accumulate, stream); }
+extern "C" int seg_maxpool_bwd_f32(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t ph, int32_t pw, int32_t accumulate, seg_stream_t stream) { return seg_maxpool_bwd_impl<split_t>(dy, x, y, dx, N, H, W, cs, ph, pw, accumulate, stream); }
 
 template <typename T>
 static int seg_upsample_fwd_impl(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
@@ -1715,7 +1726,7 @@ static int seg_upsample_fwd_impl(const void* x, void* y, int32_t N, int32_t H, i
   return SEG_OK;
 }
 extern "C" int seg_upsample_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, seg_stream_t stream) { return seg_upsample_fwd_impl<half_t>(x, y, N, H, W, cs, fh, fw, bilinear, stream); }
-extern "C" int seg_upsample_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, seg_stream_t stream) { return seg_upsample_fwd_impl<float>(x, y, N, H, W, cs, fh, fw, bilinear, stream); }
+extern "C" int seg_upsample_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, seg_stream_t stream) { return seg_upsample_fwd_impl<split_t>(x, y, N, H, W, cs, fh, fw, bilinear, stream); }
 
 template <typename T>
 static int seg_upsample_bwd_impl(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw,
@@ -1728,7 +1739,7 @@ static int seg_upsample_bwd_impl(const void* dy, void* dx, int32_t N, int32_t H,
   return SEG_OK;
 }
 extern "C" int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream) { return seg_upsample_bwd_impl<half_t>(dy, dx, N, H, W, cs, fh, fw, bilinear, accumulate, stream); }
-extern "C" int seg_upsample_bwd_f32(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream) { return seg_upsample_bwd_impl<float>(dy, dx, N, H, W, cs, fh, fw, bilinear, accumulate, stream); }
+extern "C" int seg_upsample_bwd_f32(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream) { return seg_upsample_bwd_impl<split_t>(dy, dx, N, H, W, cs, fh, fw, bilinear, accumulate, stream); }
 
 template <typename T>
 static int seg_add_act_fwd_impl(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) {
@@ -1740,7 +1751,7 @@ static int seg_add_act_fwd_impl(const void* const* xs, int32_t n, void* y, int64
   return SEG_OK;
 }
 extern "C" int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<half_t>(xs, n, y, nelem, act, alpha, stream); }
-extern "C" int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<float>(xs, n, y, nelem, act, alpha, stream); }
+extern "C" int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<split_t>(xs, n, y, nelem, act, alpha, stream); }
 
 template <typename T>
 static int seg_add_act_bwd_impl(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha,
@@ -1754,7 +1765,7 @@ static int seg_add_act_bwd_impl(const void* dy, const void* y, void* const* dxs,
   return SEG_OK;
 }
 extern "C" int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<half_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
-extern "C" int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<float>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
+extern "C" int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<split_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
 
 template <typename T>
 static int seg_mul_bcast_fwd_impl(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) {
@@ -1765,12 +1776,12 @@ static int seg_mul_bcast_fwd_impl(const void* a, const void* r, void* y, int64_t
   return SEG_OK;
 }
 extern "C" int seg_mul_bcast_fwd(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) { return seg_mul_bcast_fwd_impl<half_t>(a, r, y, npix, cs, r_cs, stream); }
-extern "C" int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) { return seg_mul_bcast_fwd_impl<float>(a, r, y, npix, cs, r_cs, stream); }
+extern "C" int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) { return seg_mul_bcast_fwd_impl<split_t>(a, r, y, npix, cs, r_cs, stream); }
 
 template <typename T>
 static int seg_mul_bcast_bwd_impl(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs,
                                  int32_t acc_a, int32_t acc_r, seg_stream_t stream) {
-  SEG_CHECK_ARG(dy && a && r && npix > 0 && (cs & 7) == 0 && r_cs >= 1, "seg_mul_bcast_bwd: bad arguments");
+  SEG_CHECK_ARG(dy && a && r && npix > 0 && (cs & 7) == 0 && r_cs >= 1 && (sizeof(T) == 2 || (r_cs & 7) == 0), "seg_mul_bcast_bwd: bad arguments");
   int LPP = pow2ceil(cs / 8);
   if (LPP > 64) LPP = 64;
   const int gpb = TPB / LPP;
@@ -1782,7 +1793,7 @@ static int seg_mul_bcast_bwd_impl(const void* dy, const void* a, const void* r, 
   return SEG_OK;
 }
 extern "C" int seg_mul_bcast_bwd(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream) { return seg_mul_bcast_bwd_impl<half_t>(dy, a, r, da, dr, npix, cs, r_cs, acc_a, acc_r, stream); }
-extern "C" int seg_mul_bcast_bwd_f32(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream) { return seg_mul_bcast_bwd_impl<float>(dy, a, r, da, dr, npix, cs, r_cs, acc_a, acc_r, stream); }
+extern "C" int seg_mul_bcast_bwd_f32(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs, int32_t r_cs, int32_t acc_a, int32_t acc_r, seg_stream_t stream) { return seg_mul_bcast_bwd_impl<split_t>(dy, a, r, da, dr, npix, cs, r_cs, acc_a, acc_r, stream); }
 
 template <typename T>
 static int seg_convlstm_gate_fwd_impl(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) {
@@ -1794,7 +1805,7 @@ static int seg_convlstm_gate_fwd_impl(const void* z, int32_t z_cs, void* h, int3
   return SEG_OK;
 }
 extern "C" int seg_convlstm_gate_fwd(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_fwd_impl<half_t>(z, z_cs, h, h_cs, npix, F, stream); }
-extern "C" int seg_convlstm_gate_fwd_f32(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_fwd_impl<float>(z, z_cs, h, h_cs, npix, F, stream); }
+extern "C" int seg_convlstm_gate_fwd_f32(const void* z, int32_t z_cs, void* h, int32_t h_cs, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_fwd_impl<split_t>(z, z_cs, h, h_cs, npix, F, stream); }
 
 template <typename T>
 static int seg_convlstm_gate_bwd_impl(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F,
@@ -1806,7 +1817,7 @@ static int seg_convlstm_gate_bwd_impl(const void* dh, int32_t h_cs, const void* 
   return SEG_OK;
 }
 extern "C" int seg_convlstm_gate_bwd(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_bwd_impl<half_t>(dh, h_cs, z, z_cs, dz, npix, F, stream); }
-extern "C" int seg_convlstm_gate_bwd_f32(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_bwd_impl<float>(dh, h_cs, z, z_cs, dz, npix, F, stream); }
+extern "C" int seg_convlstm_gate_bwd_f32(const void* dh, int32_t h_cs, const void* z, int32_t z_cs, void* dz, int64_t npix, int32_t F, seg_stream_t stream) { return seg_convlstm_gate_bwd_impl<split_t>(dh, h_cs, z, z_cs, dz, npix, F, stream); }
 
 static int head_lpp(int Cin) {
   int LPP = pow2ceil((Cin + 7) / 8);
@@ -1838,7 +1849,7 @@ static int seg_head_fwd_impl(const void* x, int32_t cs, int32_t Cin, int32_t N, 
   return SEG_OK;
 }
 extern "C" int seg_head_fwd(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) { return seg_head_fwd_impl<half_t>(x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout, act, y, stream); }
-extern "C" int seg_head_fwd_f32(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) { return seg_head_fwd_impl<float>(x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout, act, y, stream); }
+extern "C" int seg_head_fwd_f32(const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, const float* b, int32_t Cout, int32_t act, float* y, seg_stream_t stream) { return seg_head_fwd_impl<split_t>(x, cs, Cin, N, H, W, sy, sx, w, w_ld, b, Cout, act, y, stream); }
 
 template <typename T>
 static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W,
@@ -1879,7 +1890,7 @@ static int seg_head_bwd_impl(const float* dy, const float* y, const void* x, int
   return SEG_OK;
 }
 extern "C" int seg_head_bwd(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<half_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
-extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<float>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
+extern "C" int seg_head_bwd_f32(const float* dy, const float* y, const void* x, int32_t cs, int32_t Cin, int32_t N, int32_t H, int32_t W, int32_t sy, int32_t sx, const float* w, int32_t w_ld, int32_t Cout, int32_t act, void* dx, int32_t accumulate, const float* gs_ptr, float* dw, float* db, float* work, int64_t work_elems, seg_stream_t stream) { return seg_head_bwd_impl<split_t>(dy, y, x, cs, Cin, N, H, W, sy, sx, w, w_ld, Cout, act, dx, accumulate, gs_ptr, dw, db, work, work_elems, stream); }
 
 template <typename T>
 static int seg_head_act_fwd_impl(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) {
@@ -1889,7 +1900,7 @@ static int seg_head_act_fwd_impl(const void* x, int32_t cs, int64_t npix, int32_
   return SEG_OK;
 }
 extern "C" int seg_head_act_fwd(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) { return seg_head_act_fwd_impl<half_t>(x, cs, npix, C, act, y, stream); }
-extern "C" int seg_head_act_fwd_f32(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) { return seg_head_act_fwd_impl<float>(x, cs, npix, C, act, y, stream); }
+extern "C" int seg_head_act_fwd_f32(const void* x, int32_t cs, int64_t npix, int32_t C, int32_t act, float* y, seg_stream_t stream) { return seg_head_act_fwd_impl<split_t>(x, cs, npix, C, act, y, stream); }
 
 template <typename T>
 static int seg_head_act_bwd_impl(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs,
@@ -1900,7 +1911,7 @@ static int seg_head_act_bwd_impl(const float* dy, const float* y, int64_t npix, 
   return SEG_OK;
 }
 extern "C" int seg_head_act_bwd(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream) { return seg_head_act_bwd_impl<half_t>(dy, y, npix, C, act, gs_ptr, dx, cs, accumulate, stream); }
-extern "C" int seg_head_act_bwd_f32(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream) { return seg_head_act_bwd_impl<float>(dy, y, npix, C, act, gs_ptr, dx, cs, accumulate, stream); }
+extern "C" int seg_head_act_bwd_f32(const float* dy, const float* y, int64_t npix, int32_t C, int32_t act, const float* gs_ptr, void* dx, int32_t cs, int32_t accumulate, seg_stream_t stream) { return seg_head_act_bwd_impl<split_t>(dy, y, npix, C, act, gs_ptr, dx, cs, accumulate, stream); }
 
 extern "C" int seg_loss_fwd_bwd_w(int32_t kind, const float* pred, const float* target, int64_t npix, int32_t C, float weight,
                                   const int32_t* binary_flag, float* loss_out, float* dpred, seg_stream_t stream) {
@@ -1977,7 +1988,7 @@ static int seg_transpose_w_impl(const float* w, void* wt, int32_t rows, int32_t 
   return SEG_OK;
 }
 extern "C" int seg_transpose_w(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<half_t>(w, wt, rows, Tn, K, rows_pad, stream); }
-extern "C" int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<float>(w, wt, rows, Tn, K, rows_pad, stream); }
+extern "C" int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t Tn, int32_t K, int32_t rows_pad, seg_stream_t stream) { return seg_transpose_w_impl<split_t>(w, wt, rows, Tn, K, rows_pad, stream); }
 
 template <typename T>
 static int seg_transpose_w_multi_impl(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) {
@@ -1987,12 +1998,20 @@ static int seg_transpose_w_multi_impl(const seg_transpose_desc* descs, int32_t n
   return SEG_OK;
 }
 extern "C" int seg_transpose_w_multi(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) { return seg_transpose_w_multi_impl<half_t>(descs, n, total_tiles, stream); }
-extern "C" int seg_transpose_w_multi_f32(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) { return seg_transpose_w_multi_impl<float>(descs, n, total_tiles, stream); }
+extern "C" int seg_transpose_w_multi_f32(const seg_transpose_desc* descs, int32_t n, int32_t total_tiles, seg_stream_t stream) { return seg_transpose_w_multi_impl<split_t>(descs, n, total_tiles, stream); }
 
 extern "C" int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && n > 0, "seg_cast_f32_f16: bad arguments");
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST(stream), x, (half_t*)y, n);
   SEG_CHECK_LAUNCH("seg_cast_f32_f16");
+  return SEG_OK;
+}
+
+extern "C" int seg_cast_f32_split(const float* x, void* y, int64_t n, seg_stream_t stream) {
+  SEG_CHECK_ARG(x && y && n > 0 && (n & 7) == 0 && ((uintptr_t)x & 31) == 0 && ((uintptr_t)y & 31) == 0,
+                "seg_cast_f32_split: bad arguments (n a multiple of 8, 32-B aligned buffers)");
+  hipLaunchKernelGGL(cast_split_kernel, dim3(grid_for(n / 8)), dim3(TPB), 0, ST(stream), x, (split_t*)y, n / 8);
+  SEG_CHECK_LAUNCH("seg_cast_f32_split");
   return SEG_OK;
 }
 
@@ -2004,7 +2023,7 @@ static int seg_pack_input_impl(const float* x, void* y, int64_t npix, int32_t C,
   return SEG_OK;
 }
 extern "C" int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<half_t>(x, y, npix, C, cs, stream); }
-extern "C" int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<float>(x, y, npix, C, cs, stream); }
+extern "C" int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<split_t>(x, y, npix, C, cs, stream); }
 
 template <typename T>
 static int seg_unpack_f32_impl(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) {
@@ -2014,7 +2033,7 @@ static int seg_unpack_f32_impl(const void* x, float* y, int64_t npix, int32_t C,
   return SEG_OK;
 }
 extern "C" int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<half_t>(x, y, npix, C, cs, coff, stream); }
-extern "C" int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<float>(x, y, npix, C, cs, coff, stream); }
+extern "C" int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) { return seg_unpack_f32_impl<split_t>(x, y, npix, C, cs, coff, stream); }
 
 template <typename T>
 static int seg_copy_channels_impl(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C,
@@ -2027,4 +2046,4 @@ static int seg_copy_channels_impl(const void* src, int32_t src_cs, int32_t src_c
   return SEG_OK;
 }
 extern "C" int seg_copy_channels(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream) { return seg_copy_channels_impl<half_t>(src, src_cs, src_coff, dst, dst_cs, dst_coff, C, npix, accumulate, stream); }
-extern "C" int seg_copy_channels_f32(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream) { return seg_copy_channels_impl<float>(src, src_cs, src_coff, dst, dst_cs, dst_coff, C, npix, accumulate, stream); }
+extern "C" int seg_copy_channels_f32(const void* src, int32_t src_cs, int32_t src_coff, void* dst, int32_t dst_cs, int32_t dst_coff, int32_t C, int64_t npix, int32_t accumulate, seg_stream_t stream) { return seg_copy_channels_impl<split_t>(src, src_cs, src_coff, dst, dst_cs, dst_coff, C, npix, accumulate, stream); }

@@ -12,83 +12,44 @@ namespace {
 constexpr int ROW_BYTES = 64;     // one LDS tile row = one K step = 4 chunks of 16 B (32 halves or 16 floats)
 template <typename T> struct ET;
 template <> struct ET<half_t> { static constexpr int EPC = 8; };   // elements per 16-B chunk
-template <> struct ET<float> { static constexpr int EPC = 4; };
 
-// One K step (64 B per row) of MFMAs for a (TM x TN) grid of 32x32 tiles.  A/B point at the rows of this wave's
-// tiles; lane (fr = lane & 31, fh = lane >> 5) reads row fr.  fp16: two v_mfma_f32_32x32x16_f16 (k = 8 fh + j);
-// fp32: eight v_mfma_f32_32x32x2_f32 - lane half fh owns k = 8 fh .. 8 fh + 7 of the 16-deep step and MFMA j
-// contracts the pair {j, 8 + j} (the sum over k is order-free as long as A and B use the same assignment).
-template <typename T, int TM, int TN>
+// One K step (64 B per row = 32 fp16 channels) of MFMAs for a (TM x TN) grid of 32x32 tiles.  A/B point at the rows of this
+// wave's tiles; lane (fr = lane & 31, fh = lane >> 5) reads row fr: two v_mfma_f32_32x32x16_f16 (k = 8 fh + j).
+template <int TM, int TN>
 __device__ __forceinline__ void mma_step(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
                                          f16v (&acc)[TM][TN]) {
   const int fswz = (fr >> 2) & 3;
-  if constexpr (sizeof(T) == 2) {
-    // all eight fragment reads of the 32-deep step are issued before the first MFMA: the LDS latency is paid once
-    h8 af[2][TM], bf[2][TN];
+  // all eight fragment reads of the 32-deep step are issued before the first MFMA: the LDS latency is paid once
+  h8 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ((ks * 2 + fh) ^ fswz) << 4;
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((ks * 2 + fh) ^ fswz) << 4;
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[ks][a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * ROW_BYTES + ch);
+    for (int a = 0; a < TM; ++a) af[ks][a] = *reinterpret_cast<const h8*>(A + (a_row0 + a * 32 + fr) * ROW_BYTES + ch);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[ks][b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * ROW_BYTES + ch);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
-  } else {
-    const int c0 = ((2 * fh) ^ fswz) << 4, c1 = ((2 * fh + 1) ^ fswz) << 4;
-    f4 a0[TM], a1[TM], b0[TN], b1[TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const unsigned char* r = A + (a_row0 + a * 32 + fr) * ROW_BYTES;
-      a0[a] = *reinterpret_cast<const f4*>(r + c0);
-      a1[a] = *reinterpret_cast<const f4*>(r + c1);
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const unsigned char* r = B + (b_row0 + b * 32 + fr) * ROW_BYTES;
-      b0[b] = *reinterpret_cast<const f4*>(r + c0);
-      b1[b] = *reinterpret_cast<const f4*>(r + c1);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a][j], b0[b][j], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a][j], b1[b][j], acc[a][b], 0, 0, 0);
-        }
+    for (int b = 0; b < TN; ++b) bf[ks][b] = *reinterpret_cast<const h8*>(B + (b_row0 + b * 32 + fr) * ROW_BYTES + ch);
   }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
 }
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-// ---- fp32 operands contracted on the fp16 MFMA ("split" form of the exact mode, 3 MFMAs per product instead of the
-// 1/16-rate v_mfma_f32_32x32x2_f32): x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048) - the residual is
-// exact in fp32 and scaled into fp16's normal range, so hi + lo / 2048 carries ~22 significant bits of x.  Products of fp16
-// values are exact in the fp32 accumulator: a b ~= ah bh + (al bh + ah bl) / 2048 (the al bl term, 2^-22 relative, is
-// dropped); the two sums live in separate accumulators and are combined once at the end.  An LDS row (one K step of 16
-// fp32 values) holds [16 hi | 16 lo] halves = the same 64 B as the 16 floats.
-constexpr float SPLIT_SCALE = 2048.f;
-__device__ __forceinline__ void split4(const u4& raw, h4& hi, h4& lo) {
-  // the conversions as vectors (v_cvt_pk_f16_f32, round to nearest even: two values per instruction), the residual as scalars:
-  // 16 VALU instructions per 4 values instead of 24 - the split is what bounds the register-staged fp32 kernels
-  const f4 x = __builtin_bit_cast(f4, raw);
-  hi = __builtin_convertvector(x, h4);
-  f4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = (x[i] - (float)hi[i]) * SPLIT_SCALE;
-  lo = __builtin_convertvector(r, h4);
-}
+// ---- parity mode: operands STORED as split pairs (seg_common.h, split_t), x = hi + lo / 2048.  To every loader a split
+// tensor is an fp16 tensor with twice the channels ("pseudo-channels": an 8-channel group = 16 pseudo-channels, [8 hi | 8 lo]) -
+// the launchers double seg_c / seg_cs / seg_woff / Kpad and the fp16 loaders run unchanged.  A 64-B LDS row is then 16 real K
+// values as chunks (hi 0-7, lo 0-7, hi 8-15, lo 8-15): lane half fh contracts k = 8 fh .. 8 fh + 7, its hi fragment is chunk
+// 2 fh, its lo fragment chunk 2 fh + 1.  Products of fp16 values are exact in the fp32 accumulator:
+// a b ~= ah bh + (al bh + ah bl) / 2048 (al bl, 2^-22 relative, is dropped): three MFMAs per product, the two sums in separate
+// accumulators that are combined once at the end (split_combine).
 template <int TM, int TN>
 __device__ __forceinline__ void mma_step_split(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
                                                f16v (&acc)[TM][TN], f16v (&accl)[TM][TN]) {
   const int fswz = (fr >> 2) & 3;
-  const int ch = (fh ^ fswz) << 4, cl = ((2 + fh) ^ fswz) << 4;       // chunks 0,1: hi (k = 8 fh ..), chunks 2,3: lo
+  const int ch = ((2 * fh) ^ fswz) << 4, cl = ((2 * fh + 1) ^ fswz) << 4;
   h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
@@ -111,17 +72,23 @@ __device__ __forceinline__ void mma_step_split(const unsigned char* A, const uns
       accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
     }
 }
-// LDS store of 4 consecutive fp32 K values (16-B chunk `chunk` of a row) in the split row format
-__device__ __forceinline__ void split_store(unsigned char* tile, int row, int chunk, const u4& raw) {
-  h4 hi, lo;
-  split4(raw, hi, lo);
-  const int sub = (chunk & 1) * 8;
-  *reinterpret_cast<h4*>(tile + lds_off(row, chunk >> 1) + sub) = hi;
-  *reinterpret_cast<h4*>(tile + lds_off(row, 2 + (chunk >> 1)) + sub) = lo;
+template <int TM, int TN>
+__device__ __forceinline__ void split_combine(f16v (&acc)[TM][TN], const f16v (&accl)[TM][TN]) {
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] += accl[a][b][q] * SPLIT_INV;
 }
-inline bool f32_split_enabled() {
-  static const bool exact = std::getenv("SEG_F32_EXACT") != nullptr && std::atoi(std::getenv("SEG_F32_EXACT")) != 0;
-  return !exact;
+// host side: the argument block as the loaders of a split launch see it (pseudo-channels); the output side (n_rows, out_cs,
+// spans: the epilogue's units) stays in real channels
+template <typename Args>
+inline Args split_view(const Args& a) {
+  Args b = a;
+  for (int s = 0; s < a.nseg; ++s) { b.seg_c[s] *= 2; b.seg_cs[s] *= 2; b.seg_woff[s] *= 2; }
+  b.Kpad *= 2;
+  return b;
 }
 
 constexpr int STG_LD = 36;        // floats per staging row (32 + 4 pad, keeps 16-B alignment)
@@ -199,16 +166,14 @@ template <> struct Raw8<half_t> {
     for (int t = 0; t < 8; ++t) f[t] += o[t];
   }
 };
-template <> struct Raw8<float> {
-  struct type { f4 a, b; };
-  static __device__ __forceinline__ void zero(type& r) { r.a = f4{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
-  static __device__ __forceinline__ void load(const float* p, type& r) {
-    r.a = *reinterpret_cast<const f4*>(p);
-    r.b = *reinterpret_cast<const f4*>(p + 4);
-  }
+template <> struct Raw8<split_t> {
+  struct type { u4 hi, lo; };
+  static __device__ __forceinline__ void zero(type& r) { r.hi = u4{0u, 0u, 0u, 0u}; r.lo = r.hi; }
+  static __device__ __forceinline__ void load(const split_t* p, type& r) { r.hi = ld16(p); r.lo = ld16(p + 4); }
   static __device__ __forceinline__ void add(const type& r, float* f) {
+    const h8 hi = __builtin_bit_cast(h8, r.hi), lo = __builtin_bit_cast(h8, r.lo);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { f[t] += r.a[t]; f[4 + t] += r.b[t]; }
+    for (int t = 0; t < 8; ++t) f[t] += (float)hi[t] + (float)lo[t] * SPLIT_INV;
   }
 };
 
@@ -305,7 +270,7 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   // accumulating outputs (data gradients summed over the consumers of a tensor): fetch every old value up front, so
   // the read-modify-write costs one memory latency per block instead of one per 32x32 tile and row pass
   // (in groups of two 32-row tiles: 16 registers per tile row)
-  constexpr int AG = TM > 2 ? 2 : TM;
+  constexpr int AG = sizeof(T) == 4 ? 1 : (TM > 2 ? 2 : TM);      // (split pairs are twice the registers: one tile row at a time)
   typename Raw8<T>::type oldv[AG][TN][2], yv[AG][TN][2];
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
@@ -501,10 +466,27 @@ bool check_segs(const Args& a, const char* who) {
   return true;
 }
 
+inline int check_wgrad_args(const seg_igemm_wgrad_args* a, const char* who) {
+  SEG_CHECK_ARG(a != nullptr, "%s: null args", who);
+  if (!check_geom(a->g, who) || !check_segs(*a, who)) return SEG_ERR_ARG;
+  SEG_CHECK_ARG(a->dz && a->dw, "%s: null pointer", who);
+  SEG_CHECK_ARG(a->n_rows > 0 && (a->n_rows & 7) == 0 && (a->dz_cs & 7) == 0 && (a->dz_coff & 7) == 0 && a->dz_coff + a->n_rows <= a->dz_cs,
+                "%s: n_rows=%d dz_cs=%d dz_coff=%d", who, a->n_rows, a->dz_cs, a->dz_coff);
+  SEG_CHECK_ARG((a->Kpad & 31) == 0, "%s: Kpad=%d", who, a->Kpad);
+  SEG_CHECK_ARG(a->partial == nullptr || (((uintptr_t)a->partial | (uintptr_t)a->dw) & 15) == 0, "%s: partial / dw must be 16-byte aligned for the split reduce", who);
+  SEG_CHECK_ARG((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64), "%s: tile %dx%d", who, a->tile_m, a->tile_n);
+  SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "%s: splitk=%d", who, a->splitk);
+  SEG_CHECK_ARG((a->variant & 255) >= 0 && (a->variant & 255) <= 2, "%s: variant=%d", who, a->variant);
+  return SEG_OK;
+}
+
 }  // namespace
 
+// second pass of the deterministic pixel split of the weight-gradient kernels (igemm_wgrad.hip)
+int seg_launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st);
 // halo-tile (variant 3) forward launcher, igemm_halo.hip
 int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st);
+int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st);      // parity mode; v = split_view(args)
 // its software-pipelined generation (igemm_halo2.hip); called by seg_launch_fwd3 after the argument checks
 int seg_launch_fwd4(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st);
 // wave-specialised 512 x 64 halo-tile forward (igemm_halo3.hip); called by seg_launch_fwd3 for tile_m == 512

@@ -13,9 +13,13 @@ namespace {
 // traffic per MFMA 2-3x and, with TG = 3, the barriers per MFMA 3x against the per-tap kernel above.
 // Waves: BN = 128: 2 (M) x 2 (N), each 128 px x 64 channels; BN = 64: 4 x 1, each 64 px x 64 channels.
 // ---------------------------------------------------------------------------------------------------------
-template <int PW, int BN, int NT, int TG, int NPL>
+// Parity mode (SPLIT, BN = 64 only): the tensors are split pairs and the loaders see twice the channels (igemm_common.h), so a
+// "32-channel chunk" is 16 real channels as hi / lo 16-B chunks; per tap and tile pair three MFMAs into two accumulator sets.
+template <int PW, int BN, int NT, int TG, int NPL, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!SPLIT || BN == 64, "parity mode: 64 x 64 accumulators per wave, twice");
+  typedef std::conditional_t<SPLIT, split_t, half_t> TO;
   constexpr int PH = 256 / PW, HC = PW + 2, HROWS = (PH + 2) * HC;
   constexpr int NI_A = (HROWS + 15) / 16;                  // LDS-DMA wave instructions per halo tile (16 rows of 64 B)
   constexpr int NA_HI = (NI_A + 3) / 4, NA_REM = NI_A % 4;  // per wave: NA_HI for waves < NA_REM (all when NA_REM == 0), else NA_HI - 1
@@ -150,6 +154,15 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  f16v accl[SPLIT ? TMw : 1][SPLIT ? 2 : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int a = 0; a < TMw; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accl[a][b][q] = 0.f;
+  }
 
   // ---- fragment addressing.  A: halo row of (tile a, lane row fr) under tap t = arow[a] + t_shift[t] + lrow
   const int fr = lane & 31, fh = lane >> 5;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) boff[b][ks] = lds_off(wn * 64 + b * 32 + fr, ks * 2 + fh);
+    for (int ks = 0; ks < 2; ++ks) boff[b][ks] = lds_off(wn * 64 + b * 32 + fr, SPLIT ? 2 * fh + ks : ks * 2 + fh);      // (split: ks = 0 hi, 1 lo)
 
   auto compute = [&](auto tgc, int abuf, int slot) {
     constexpr int tg = decltype(tgc)::value;
@@ -179,19 +192,41 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
 #pragma unroll
       for (int a = 0; a < TMw; ++a) {
         const int row = arow[a] + t_shift[t] + lr;
-        o0[a] = (row << 6) + ((fh ^ ((row >> 2) & 3)) << 4);
+        o0[a] = (row << 6) + (((SPLIT ? 2 * fh : fh) ^ ((row >> 2) & 3)) << 4);
       }
+      if constexpr (SPLIT) {
+        h8 ah[TMw], al[TMw], bh[2], bl[2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        h8 af[TMw], bf[2];
+        for (int a = 0; a < TMw; ++a) {
+          ah[a] = *reinterpret_cast<const h8*>(A + o0[a]);
+          al[a] = *reinterpret_cast<const h8*>(A + (o0[a] ^ 16));
+        }
 #pragma unroll
-        for (int a = 0; a < TMw; ++a) af[a] = *reinterpret_cast<const h8*>(A + (o0[a] ^ (ks * 32)));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][ks]);
+        for (int b = 0; b < 2; ++b) {
+          bh[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][0]);
+          bl[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][1]);
+        }
 #pragma unroll
         for (int a = 0; a < TMw; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < 2; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], accl[a][b], 0, 0, 0);
+            accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          h8 af[TMw], bf[2];
+#pragma unroll
+          for (int a = 0; a < TMw; ++a) af[a] = *reinterpret_cast<const h8*>(A + (o0[a] ^ (ks * 32)));
+#pragma unroll
+          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][ks]);
+#pragma unroll
+          for (int a = 0; a < TMw; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
       }
     }
   };
@@ -259,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
     advance(cC);
   }
   __syncthreads();
-  conv_epilogue<half_t, TMw, 2, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, cls, npatch, mb, 0, 0, pn, y0, x0);
+  if constexpr (SPLIT) split_combine(acc, accl);
+  conv_epilogue<TO, TMw, 2, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, cls, npatch, mb, 0, 0, pn, y0, x0);
 #endif
 }
 template __global__ void igemm_fwd3_kernel<32, 128, 9, 1, 1>(const seg_igemm_fwd_args);
@@ -276,6 +312,13 @@ template __global__ void igemm_fwd3_kernel<32, 128, 4, 1, 4>(const seg_igemm_fwd
 template __global__ void igemm_fwd3_kernel<16, 128, 4, 1, 4>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4>(const seg_igemm_fwd_args);
+// parity mode
+template __global__ void igemm_fwd3_kernel<32, 64, 9, 3, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 9, 3, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true>(const seg_igemm_fwd_args);
 
 }  // namespace
 
@@ -365,5 +408,30 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   else if (a.g.ntaps == 9) launch_fwd3_nt<9, 1, 3>(a, pw, grid, st);
   else launch_fwd3_nt<4, 1, 2>(a, pw, grid, st);
   SEG_CHECK_LAUNCH("seg_igemm_fwd (halo tiles)");
+  return SEG_OK;
+}
+
+// ---- parity mode: `v` is the split view of the arguments (igemm_common.h: the loaders' pseudo-channels); 256 x 64 tiles only
+template <int NT, int TG, int NPL>
+static void launch_fwd3_split_nt(const seg_igemm_fwd_args& v, int pw, dim3 grid, hipStream_t st) {
+  const int ni_a = pw == 32 ? 22 : 21;
+  const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (TG * 4096);
+  if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 64, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
+  else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 64, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
+}
+int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st) {
+  const int pw = seg_fwd_halo_patch(&v.g);
+  SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd_f32: variant 3 needs a stride-1 3x3 'same' conv, a 4x4 / stride-2 transposed conv (or the data gradient of either), and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
+  SEG_CHECK_ARG(v.tile_m == 256 && v.tile_n == 64, "seg_igemm_fwd_f32: the variant 3 tile is 256x64, not %dx%d", v.tile_m, v.tile_n);
+  const long pix = (long)v.g.N * v.g.Hin * v.g.Win;
+  for (int s = 0; s < v.nseg; ++s) SEG_CHECK_ARG(pix * v.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
+  SEG_CHECK_ARG((long)v.n_rows * v.g.T_total * v.Kpad * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
+  const int npatch = (int)((long)v.g.N * v.g.Hl * v.g.Wl / 256);
+  const int nblocks = (v.n_rows + 63) / 64;
+  dim3 grid((unsigned)(npatch * nblocks), (unsigned)v.g.ncls, 1);
+  if (v.g.ntaps == 16) launch_fwd3_split_nt<4, 2, 4>(v, pw, grid, st);
+  else if (v.g.ntaps == 9) launch_fwd3_split_nt<9, 3, 1>(v, pw, grid, st);
+  else launch_fwd3_split_nt<4, 2, 1>(v, pw, grid, st);
+  SEG_CHECK_LAUNCH("seg_igemm_fwd_f32 (halo tiles)");
   return SEG_OK;
 }

@@ -8,19 +8,18 @@ namespace {
 // weight gradient:  D[n][k] = sum_pix dz[pix][n] * in[pix + tap][k]   (reduction dimension = pixels)
 // Both operands are "reduction-major" in memory, so their MFMA fragments are read with the hardware
 // transposing LDS read ds_read_b64_tr_b16 (VARIANT 0) or transposed while being stored to LDS (VARIANT 1).
-// fp32 (parity mode, SPLIT): VARIANT 0 on hi / lo fp16 tiles of the split operands, three MFMAs per product, 32 pixels per
-// step; VARIANT 1 remains for the fma-chain MFMA (SEG_F32_EXACT=1) and as SEG_F32_WGRAD_TR=1.
+// (The parity mode's kernels - operands stored as split pairs - are in igemm_wgrad_split.hip.)
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int VARIANT, bool SPLIT = false>
-__global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
-  static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 contraction is the fp32 mode's");
-  static_assert(sizeof(T) == 2 || VARIANT == 1 || SPLIT, "the transposing LDS read exists for 16-bit elements only (fp32: as hi / lo halves)");
+template <int BM, int BN, int VARIANT>
+__global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const seg_igemm_wgrad_args p) {
+  typedef half_t T;
+  constexpr bool SPLIT = false;       // (the parity mode's kernels are in igemm_wgrad_split.hip)
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int EPC = ET<T>::EPC;
   constexpr int PK = (VARIANT == 0) ? 32 : 4 * EPC;   // pixels per step (VARIANT 1: one 64-B LDS row in the transposed tile)
   // VARIANT 0 tiles: [32 pixels][BM halves] rows of BM*2 + 64 bytes; SPLIT: a hi tile followed by a lo tile of that shape
   constexpr int ZLD = BM * 2 + 64, ALD = BN * 2 + 64;
-  constexpr int NPL = (SPLIT && VARIANT == 0) ? 2 : 1;
+  constexpr int NPL = 1;
   constexpr int Z_BYTES = (VARIANT == 0) ? NPL * PK * ZLD : BM * ROW_BYTES;
   constexpr int A_BYTES = (VARIANT == 0) ? NPL * PK * ALD : BN * ROW_BYTES;
   constexpr int ZCH = BM / EPC, ACH = BN / EPC;    // 16-B chunks per pixel row
@@ -90,15 +89,6 @@ __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wg
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-  f16v accl[SPLIT ? TM : 1][SPLIT ? TN : 1];
-  if constexpr (SPLIT) {
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) accl[a][b][q] = 0.f;
-  }
 
   u4 rz[ZPT], ra[APT];
   auto gload = [&](int pb) {
@@ -131,24 +121,7 @@ __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wg
   auto lstore = [&](int buf) {
     unsigned char* Z = smem + buf * (Z_BYTES + A_BYTES);
     unsigned char* A = Z + Z_BYTES;
-    if constexpr (VARIANT == 0 && SPLIT) {
-      // 4 fp32 channels of one pixel -> 4 hi halves + 4 lo halves, 8 B each into the [pixel][channel] hi / lo tiles (a wave
-      // writes 256 contiguous bytes per pixel row; the transposing-store form's 2-byte stores ran 16 deep into one bank group)
-#pragma unroll
-      for (int r = 0; r < ZPT; ++r) {
-        h4 hi, lo;
-        split4(rz[r], hi, lo);
-        *reinterpret_cast<h4*>(Z + z_p[r] * ZLD + z_c[r] * 8) = hi;
-        *reinterpret_cast<h4*>(Z + PK * ZLD + z_p[r] * ZLD + z_c[r] * 8) = lo;
-      }
-#pragma unroll
-      for (int r = 0; r < APT; ++r) {
-        h4 hi, lo;
-        split4(ra[r], hi, lo);
-        *reinterpret_cast<h4*>(A + a_p[r] * ALD + a_c[r] * 8) = hi;
-        *reinterpret_cast<h4*>(A + PK * ALD + a_p[r] * ALD + a_c[r] * 8) = lo;
-      }
-    } else if constexpr (VARIANT == 0) {
+    if constexpr (VARIANT == 0) {
 #pragma unroll
       for (int r = 0; r < ZPT; ++r) st16(Z + z_p[r] * ZLD + z_c[r] * 16, rz[r]);
 #pragma unroll
@@ -163,13 +136,7 @@ __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wg
 #pragma unroll
         for (int t = 0; t < EPC; ++t) {
           int row = z_c[r] * EPC + t;
-          if constexpr (SPLIT) {      // row = [16 hi | 16 lo] halves over the step's 16 pixels
-            const half_t hi = (half_t)v[t];
-            *reinterpret_cast<half_t*>(Z + lds_off(row, pp >> 3) + (pp & 7) * 2) = hi;
-            *reinterpret_cast<half_t*>(Z + lds_off(row, 2 + (pp >> 3)) + (pp & 7) * 2) = (half_t)(((float)v[t] - (float)hi) * SPLIT_SCALE);
-          } else {
-            *reinterpret_cast<T*>(Z + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
-          }
+          *reinterpret_cast<T*>(Z + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
         }
       }
 #pragma unroll
@@ -179,13 +146,7 @@ __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wg
 #pragma unroll
         for (int t = 0; t < EPC; ++t) {
           int row = a_c[r] * EPC + t;
-          if constexpr (SPLIT) {
-            const half_t hi = (half_t)v[t];
-            *reinterpret_cast<half_t*>(A + lds_off(row, pp >> 3) + (pp & 7) * 2) = hi;
-            *reinterpret_cast<half_t*>(A + lds_off(row, 2 + (pp >> 3)) + (pp & 7) * 2) = (half_t)(((float)v[t] - (float)hi) * SPLIT_SCALE);
-          } else {
-            *reinterpret_cast<T*>(A + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
-          }
+          *reinterpret_cast<T*>(A + lds_off(row, pp / EPC) + (pp % EPC) * (int)sizeof(T)) = v[t];
         }
       }
     }
@@ -221,44 +182,14 @@ __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wg
           h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
           bf[b] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
         }
-        if constexpr (SPLIT) {
-          h8 afl[TM], bfl[TN];
 #pragma unroll
-          for (int a = 0; a < TM; ++a) {
-            int colh = wm * (BM / 2) + a * 32 + 16 * (tg & 1) + 4 * tp;
-            const unsigned char* ad = Z + PK * ZLD + krow * ZLD + colh * 2;
-            s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
-            s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * ZLD));
-            h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
-            afl[a] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
-          }
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            int colh = wn * (BN / 2) + b * 32 + 16 * (tg & 1) + 4 * tp;
-            const unsigned char* ad = A + PK * ALD + krow * ALD + colh * 2;
-            s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad));
-            s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(ad + 4 * ALD));
-            h4 l4 = __builtin_bit_cast(h4, lo), h4v = __builtin_bit_cast(h4, hi);
-            bfl[b] = h8{l4[0], l4[1], l4[2], l4[3], h4v[0], h4v[1], h4v[2], h4v[3]};
-          }
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-              accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[a], bf[b], accl[a][b], 0, 0, 0);
-              accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bfl[b], accl[a][b], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+
       }
     } else {
-      if constexpr (SPLIT) mma_step_split<TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc, accl);
-      else mma_step<T, TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
+      mma_step<TM, TN>(Z, A, wm * (BM / 2), wn * (BN / 2), fr, fh, acc);
     }
   };
 
@@ -274,14 +205,6 @@ __global__ __launch_bounds__(256, (SPLIT && VARIANT == 0) ? 2 : 1) void igemm_wg
     __syncthreads();
   }
 
-  if constexpr (SPLIT) {
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[a][b][q] += accl[a][b][q] * (1.f / SPLIT_SCALE);
-  }
   // ---- epilogue: fp32 atomics, lanes 0..31 hit 32 consecutive K columns of one weight row
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
@@ -938,7 +861,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
   }
 }
 
-int launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st) {
+}  // namespace
+int seg_launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st) {
   if (a.partial == nullptr || a.splitk <= 1) return SEG_OK;
   const long numel = (long)a.n_rows * a.g.T_total * a.Kpad;          // Kpad is a multiple of 32: whole float4 groups
   if (a.splitk >= 32) {
@@ -953,8 +877,6 @@ int launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st) {
   SEG_CHECK_LAUNCH("seg_igemm_wgrad (split reduce)");
   return SEG_OK;
 }
-
-}  // namespace
 
 // taps handled per block by the weight-gradient kernels (1 = the per-tap kernel); exported so that the host can
 // size the pixel split with the same rule
@@ -1014,24 +936,12 @@ extern "C" int seg_wgrad_halo_class_groups(const seg_geom* g) {
   return 2;
 }
 
-template <typename T>
-static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
-  SEG_CHECK_ARG(a != nullptr, "seg_igemm_wgrad: null args");
-  if (!check_geom(a->g, "seg_igemm_wgrad") || !check_segs(*a, "seg_igemm_wgrad")) return SEG_ERR_ARG;
-  SEG_CHECK_ARG(a->dz && a->dw, "seg_igemm_wgrad: null pointer");
-  SEG_CHECK_ARG(a->n_rows > 0 && (a->n_rows & 7) == 0 && (a->dz_cs & 7) == 0 && (a->dz_coff & 7) == 0 &&
-                    a->dz_coff + a->n_rows <= a->dz_cs,
-                "seg_igemm_wgrad: n_rows=%d dz_cs=%d dz_coff=%d", a->n_rows, a->dz_cs, a->dz_coff);
-  SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_wgrad: Kpad=%d", a->Kpad);
-  SEG_CHECK_ARG(a->partial == nullptr || (((uintptr_t)a->partial | (uintptr_t)a->dw) & 15) == 0, "seg_igemm_wgrad: partial / dw must be 16-byte aligned for the split reduce");
-  SEG_CHECK_ARG((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64),
-                "seg_igemm_wgrad: tile %dx%d", a->tile_m, a->tile_n);
-  SEG_CHECK_ARG(a->splitk >= 1 && a->splitk <= 65535, "seg_igemm_wgrad: splitk=%d", a->splitk);
-  SEG_CHECK_ARG((a->variant & 255) >= 0 && (a->variant & 255) <= 2, "seg_igemm_wgrad: variant=%d", a->variant);
+extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
+  typedef half_t T;
+  if (const int rc = check_wgrad_args(a, "seg_igemm_wgrad")) return rc;
   SEG_CHECK_ARG(a->bias_part == nullptr || ((a->variant & 255) == 2 && seg_wgrad_halo_class_groups(&a->g) == 2),
                 "seg_igemm_wgrad: bias_part needs variant 2 on a transposed conv of the class-pair kernel");
   if ((a->variant & 255) == 2) {      // (bits 8.. : timing-experiment switches of the halo kernel)
-    SEG_CHECK_ARG(sizeof(T) == 2, "seg_igemm_wgrad: variant 2 (LDS-DMA halo tiles) is fp16 only");
     const int pc = seg_wgrad_halo_patch(&a->g);
     SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 32 == 0 and H %% 2 == 0, W %% 16 == 0 and H %% 4 == 0, or W and H %% 8 == 0");
     const long pix = (long)a->g.N * a->g.Hin * a->g.Win;
@@ -1080,12 +990,9 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
 #undef SEG_HALO_PC
     }
     SEG_CHECK_LAUNCH("seg_igemm_wgrad (halo)");
-    return launch_wgrad_reduce(*a, (hipStream_t)stream);
+    return seg_launch_wgrad_reduce(*a, (hipStream_t)stream);
   }
-  // fp32: split operands through the [pixel][channel] hi / lo tiles + transposing reads (form 0); SEG_F32_WGRAD_TR=1 keeps
-  // the round-1 transposing-store form (1), which the exact fma-chain MFMA (SEG_F32_EXACT=1) always uses
-  static const bool f32_tr = std::getenv("SEG_F32_WGRAD_TR") != nullptr && std::atoi(std::getenv("SEG_F32_WGRAD_TR")) != 0;
-  const int variant = (sizeof(T) == 4) ? ((f32_split_enabled() && !f32_tr) ? 0 : 1) : (a->variant & 255);
+  const int variant = a->variant & 255;
   const int rtiles = (a->n_rows + a->tile_m - 1) / a->tile_m;
   int ktiles = 0;
   for (int s = 0; s < a->nseg; ++s) ktiles += (a->seg_c[s] + a->tile_n - 1) / a->tile_n;
@@ -1101,23 +1008,17 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
       else if (a->tile_n == 128 && ntb == 4) hipLaunchKernelGGL((igemm_wgrad_mt_kernel<128, 4>), gridm, dim3(256), ldsm, stm, *a);
       else hipLaunchKernelGGL((igemm_wgrad_mt_kernel<128, 3>), gridm, dim3(256), ldsm, stm, *a);
       SEG_CHECK_LAUNCH("seg_igemm_wgrad (multi-tap)");
-      return launch_wgrad_reduce(*a, (hipStream_t)stream);
+      return seg_launch_wgrad_reduce(*a, (hipStream_t)stream);
     }
   }
   dim3 grid((unsigned)(rtiles * ktiles), (unsigned)(a->g.ncls * a->g.ntaps), (unsigned)a->splitk), block(256, 1, 1);
   hipStream_t st = (hipStream_t)stream;
   const int bm = a->tile_m, bn = a->tile_n;
-  size_t lds = (variant == 0) ? (size_t)2 * 32 * ((bm * 2 + 64) + (bn * 2 + 64)) * (sizeof(T) == 4 ? 2 : 1) : (size_t)2 * (bm + bn) * ROW_BYTES;
-#define SEG_WG(BM_, BN_)                                                                                          \
-  do {                                                                                                            \
-    if constexpr (sizeof(T) == 2) {                                                                               \
-      if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 0>), grid, block, lds, st, *a);        \
-      else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
-    } else {                                                                                                      \
-      if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 0, true>), grid, block, lds, st, *a);          \
-      else if (f32_split_enabled()) hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1, true>), grid, block, lds, st, *a);   \
-      else hipLaunchKernelGGL((igemm_wgrad_kernel<T, BM_, BN_, 1>), grid, block, lds, st, *a);                     \
-    }                                                                                                             \
+  size_t lds = (variant == 0) ? (size_t)2 * 32 * ((bm * 2 + 64) + (bn * 2 + 64)) : (size_t)2 * (bm + bn) * ROW_BYTES;
+#define SEG_WG(BM_, BN_)                                                                                  \
+  do {                                                                                                    \
+    if (variant == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, 0>), grid, block, lds, st, *a);     \
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, 1>), grid, block, lds, st, *a);                  \
   } while (0)
   if (bm == 128 && bn == 128) SEG_WG(128, 128);
   else if (bm == 128 && bn == 64) SEG_WG(128, 64);
@@ -1125,7 +1026,5 @@ static int igemm_wgrad_launch(const seg_igemm_wgrad_args* a, seg_stream_t stream
   else SEG_WG(64, 64);
 #undef SEG_WG
   SEG_CHECK_LAUNCH("seg_igemm_wgrad");
-  return launch_wgrad_reduce(*a, st);
+  return seg_launch_wgrad_reduce(*a, st);
 }
-extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream) { return igemm_wgrad_launch<half_t>(a, stream); }
-extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream) { return igemm_wgrad_launch<float>(a, stream); }

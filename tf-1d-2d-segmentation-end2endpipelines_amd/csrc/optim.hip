@@ -18,6 +18,19 @@ constexpr int TPB = 256;
 __device__ __forceinline__ float grad_load(const float* g, int64_t i) { return g[i]; }
 __device__ __forceinline__ float grad_load(const uint16_t* g, int64_t i) { return __uint_as_float((uint32_t)g[i] << 16); }     // bf16
 
+// operand copy of an updated parameter for the GEMM kernels: the fp16 image (throughput mode) or the split pair of the parity
+// mode (seg_common.h: element i of the flat buffer -> halves [16 (i / 8) + i % 8] = hi and [.. + 8] = lo)
+__device__ __forceinline__ void operand_store(half_t* p16, int fmt, int64_t i, float v) {
+  if (fmt == SEG_OPERAND_F16) {
+    p16[i] = (half_t)v;
+  } else {
+    const int64_t o = ((i >> 3) << 4) + (i & 7);
+    const half_t hi = (half_t)v;
+    p16[o] = hi;
+    p16[o + 8] = (half_t)((v - (float)hi) * SPLIT_SCALE);
+  }
+}
+
 __device__ __forceinline__ void count_nonfinite(uint32_t* counter, uint32_t mine) {
   if (counter == nullptr) return;
   // rare path: one atomic per wave that saw any
@@ -30,7 +43,7 @@ __device__ __forceinline__ void count_nonfinite(uint32_t* counter, uint32_t mine
 }
 
 template <typename GT>
-__global__ __launch_bounds__(TPB) void adam_kernel(float* p, const GT* g, float* m, float* v, half_t* p16, int64_t n, float alpha_t,
+__global__ __launch_bounds__(TPB) void adam_kernel(float* p, const GT* g, float* m, float* v, half_t* p16, int p16_fmt, int64_t n, float alpha_t,
                                                    float b1, float b2, float eps, float gmul, const float* alpha_ptr, uint32_t* nonfinite) {
   if (alpha_ptr != nullptr) alpha_t *= *alpha_ptr;      // step size from device memory: a captured hipGraph replays with a fresh value
   uint32_t bad = 0;
@@ -47,7 +60,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* p, const GT* g, float*
     } else {
       ++bad;
     }
-    if (p16) p16[i] = (half_t)pi;
+    if (p16) operand_store(p16, p16_fmt, i, pi);
   }
   count_nonfinite(nonfinite, bad);
 }
@@ -55,7 +68,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* p, const GT* g, float*
 // The other optimisers of utils/tf_optimizers.py:12-26 with the Keras (>= 2.11) update rules; s1 / s2 are the two state
 // buffers (the flat m / v buffers of the parameter store), c[] the per-step scalars the host computes (seg_hip.h).
 template <typename GT>
-__global__ __launch_bounds__(TPB) void optimizer_kernel(int kind, float* p, const GT* g, float* s1, float* s2, half_t* p16, int64_t n,
+__global__ __launch_bounds__(TPB) void optimizer_kernel(int kind, float* p, const GT* g, float* s1, float* s2, half_t* p16, int p16_fmt, int64_t n,
                                                         float c0, float c1, float c2, float c3, float c4, float gmul, uint32_t* nonfinite) {
   uint32_t bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(TPB) void optimizer_kernel(int kind, float* p, cons
     } else {
       ++bad;
     }
-    if (p16) p16[i] = (half_t)pi;
+    if (p16) operand_store(p16, p16_fmt, i, pi);
   }
   count_nonfinite(nonfinite, bad);
 }
@@ -155,15 +168,16 @@ int optimizer_grid(int64_t n) {
 
 }  // namespace
 
-extern "C" int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float* m, float* v, void* p16, int64_t n, float alpha_t,
+extern "C" int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float* m, float* v, void* p16, int32_t p16_fmt, int64_t n, float alpha_t,
                                 const float* alpha_ptr, float b1, float b2, float eps, float gmul, uint32_t* nonfinite, seg_stream_t stream) {
   SEG_CHECK_ARG(p && g && m && v && n > 0, "seg_adam_step_ex: bad arguments");
   SEG_CHECK_ARG(g_dtype == SEG_GRAD_F32 || g_dtype == SEG_GRAD_BF16, "seg_adam_step_ex: g_dtype=%d", g_dtype);
+  SEG_CHECK_ARG(p16_fmt == SEG_OPERAND_F16 || p16_fmt == SEG_OPERAND_SPLIT, "seg_adam_step_ex: p16_fmt=%d", p16_fmt);
   if (g_dtype == SEG_GRAD_F32)
-    hipLaunchKernelGGL((adam_kernel<float>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, (const float*)g, m, v, (half_t*)p16, n, alpha_t,
+    hipLaunchKernelGGL((adam_kernel<float>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, (const float*)g, m, v, (half_t*)p16, p16_fmt, n, alpha_t,
                        b1, b2, eps, gmul, alpha_ptr, nonfinite);
   else
-    hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, (const uint16_t*)g, m, v, (half_t*)p16, n,
+    hipLaunchKernelGGL((adam_kernel<uint16_t>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), p, (const uint16_t*)g, m, v, (half_t*)p16, p16_fmt, n,
                        alpha_t, b1, b2, eps, gmul, alpha_ptr, nonfinite);
   SEG_CHECK_LAUNCH("seg_adam_step_ex");
   return SEG_OK;
@@ -171,30 +185,31 @@ extern "C" int seg_adam_step_ex(float* p, const void* g, int32_t g_dtype, float*
 
 extern "C" int seg_adam_step(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float alpha_t, float b1, float b2, float eps,
                              float gmul, seg_stream_t stream) {
-  return seg_adam_step_ex(p, g, SEG_GRAD_F32, m, v, p16, n, alpha_t, nullptr, b1, b2, eps, gmul, nullptr, stream);
+  return seg_adam_step_ex(p, g, SEG_GRAD_F32, m, v, p16, SEG_OPERAND_F16, n, alpha_t, nullptr, b1, b2, eps, gmul, nullptr, stream);
 }
 extern "C" int seg_adam_step_dev(float* p, const float* g, float* m, float* v, void* p16, int64_t n, const float* alpha_ptr, float b1, float b2,
                                  float eps, float gmul, seg_stream_t stream) {
   SEG_CHECK_ARG(alpha_ptr != nullptr, "seg_adam_step_dev: null alpha_ptr");
-  return seg_adam_step_ex(p, g, SEG_GRAD_F32, m, v, p16, n, 1.0f, alpha_ptr, b1, b2, eps, gmul, nullptr, stream);
+  return seg_adam_step_ex(p, g, SEG_GRAD_F32, m, v, p16, SEG_OPERAND_F16, n, 1.0f, alpha_ptr, b1, b2, eps, gmul, nullptr, stream);
 }
 
-extern "C" int seg_optimizer_step_ex(int32_t kind, float* p, const void* g, int32_t g_dtype, float* s1, float* s2, void* p16, int64_t n,
+extern "C" int seg_optimizer_step_ex(int32_t kind, float* p, const void* g, int32_t g_dtype, float* s1, float* s2, void* p16, int32_t p16_fmt, int64_t n,
                                      const float* c, float gmul, uint32_t* nonfinite, seg_stream_t stream) {
   SEG_CHECK_ARG(p && g && s1 && s2 && c && n > 0 && kind >= SEG_OPT_SGD && kind <= SEG_OPT_FTRL, "seg_optimizer_step_ex: bad arguments");
   SEG_CHECK_ARG(g_dtype == SEG_GRAD_F32 || g_dtype == SEG_GRAD_BF16, "seg_optimizer_step_ex: g_dtype=%d", g_dtype);
+  SEG_CHECK_ARG(p16_fmt == SEG_OPERAND_F16 || p16_fmt == SEG_OPERAND_SPLIT, "seg_optimizer_step_ex: p16_fmt=%d", p16_fmt);
   if (g_dtype == SEG_GRAD_F32)
     hipLaunchKernelGGL((optimizer_kernel<float>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), kind, p, (const float*)g, s1, s2, (half_t*)p16,
-                       n, c[0], c[1], c[2], c[3], c[4], gmul, nonfinite);
+                       p16_fmt, n, c[0], c[1], c[2], c[3], c[4], gmul, nonfinite);
   else
     hipLaunchKernelGGL((optimizer_kernel<uint16_t>), dim3(optimizer_grid(n)), dim3(TPB), 0, ST(stream), kind, p, (const uint16_t*)g, s1, s2,
-                       (half_t*)p16, n, c[0], c[1], c[2], c[3], c[4], gmul, nonfinite);
+                       (half_t*)p16, p16_fmt, n, c[0], c[1], c[2], c[3], c[4], gmul, nonfinite);
   SEG_CHECK_LAUNCH("seg_optimizer_step_ex");
   return SEG_OK;
 }
 extern "C" int seg_optimizer_step(int32_t kind, float* p, const float* g, float* s1, float* s2, void* p16, int64_t n, const float* c,
                                   float gmul, seg_stream_t stream) {
-  return seg_optimizer_step_ex(kind, p, g, SEG_GRAD_F32, s1, s2, p16, n, c, gmul, nullptr, stream);
+  return seg_optimizer_step_ex(kind, p, g, SEG_GRAD_F32, s1, s2, p16, SEG_OPERAND_F16, n, c, gmul, nullptr, stream);
 }
 
 extern "C" int seg_cast_f32_bf16(const float* x, void* y, int64_t n, seg_stream_t stream) {

@@ -37,6 +37,7 @@ import torch
 from . import _ffi
 from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs, HeadInject
 from .graph import Graph, Node, ParamSpec
+from .splitfmt import split_pack, split_unpack
 
 BN_PARTS_BWD = int(os.environ.get("SEG_BN_PARTS_BWD", "1024"))
 GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
@@ -354,11 +355,12 @@ FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo ti
 # behind them instead of running beside them.  OFF by default (SEG_FWD_TWO_STREAMS=1); parity-tested with it on.
 FWD_TWO_STREAMS = os.environ.get("SEG_FWD_TWO_STREAMS", "0") != "0"
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
-F32_SPLIT = os.environ.get("SEG_F32_EXACT", "0") in ("", "0")      # parity mode on the fp16 MFMA with split operands (csrc: f32_split_enabled)
 
 
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
-    """(tile_m, tile_n, variant) of a forward / data-gradient launch."""
+    """(tile_m, tile_n, variant) of a forward / data-gradient launch.  f16 = False: the parity mode (split-pair tensors, csrc
+    igemm_fwd_split.hip / igemm_halo.hip SPLIT): the same kernel families with two accumulator sets per wave, hence the halo
+    tile is 256 x 64 only and the per-tap LDS-DMA kernel has no 64-deep K step."""
     # wave-specialised 512 x 64 tile: measured (tools/op_bench.py, C3, same box) +4 .. +8 % on the long-K 64-channel layers
     # (X03 .. X05 forward, gathered data gradients), +14 % on the transposed-conv forward (class-fastest blocks share the halo
     # tile in L2), but -2 .. -13 % on short reductions (K = 576 data gradients, the first layer) where the longer prologue /
@@ -366,23 +368,11 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     if (f16 and FWD_HALO and FWD_WS and n_rows <= 64 and fwd_halo_patch512(g) and g.ncls * (M // 512) >= FWD_WS_MIN_BLOCKS
             and (g.ncls == 4 or ktot >= FWD_WS_MIN_K)):
         return 512, 64, 3
-    if f16 and FWD_HALO and fwd_halo_patch(g):
-        tn = 64 if n_rows <= 64 else 128
+    if FWD_HALO and fwd_halo_patch(g):
+        tn = 64 if (n_rows <= 64 or not f16) else 128
         if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
             return 256, tn, 3
     tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
-    if not f16:
-        # parity mode (register-staged split-fp16 kernel): the 128 x 128 tile holds 256 accumulator registers (hi x hi and the
-        # cross terms) and runs one block per CU; two blocks of 128 x 64 are 5-15 % faster on every layer, the 64-row tiles at the
-        # deep levels (measured per layer, tools/op_bench.py --dtype f32: 61.9 -> 54.4 ms over the C3 forward + data gradients).
-        # A 256 x 64 split tile (four accumulator tiles per wave, 242 VGPRs: still two blocks per CU) fetches a fifth fewer
-        # operand bytes per FLOP than 128 x 64: +7-10 % on the long reductions, +2-5 % on the data gradients (same sweep); the
-        # fma-chain kernels (SEG_F32_EXACT=1) have no 256-row instance.
-        big = (256, 64) if F32_SPLIT else (128, 64)
-        if tm == 256:
-            tm, tn = big
-        elif n_rows > 64:
-            tm, tn = big if M >= 65536 else (64, 128) if M > 1024 else (64, 64)
     return tm, tn, 0
 
 
@@ -446,10 +436,10 @@ HALO_BLOCKS_TC = int(os.environ.get("SEG_HALO_BLOCKS_TC", os.environ.get("SEG_HA
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
 
 
-def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1):
+def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1, plane=64):
     """Patch-range split of the variant-2 kernel: fill whole rounds of HALO_BLOCKS co-resident blocks, keep at least 8
-    patches (512 pixels) per block."""
-    tiles = ncls * _cdiv(n_rows, 64) * sum(_cdiv(c, 64) for c in seg_cs)
+    patches (512 pixels) per block.  plane: input channels per block (64; parity mode 32)."""
+    tiles = ncls * _cdiv(n_rows, 64) * sum(_cdiv(c, plane) for c in seg_cs)
     npatch = M // 64
     best, best_eff = 1, 0.0
     HB = HALO_BLOCKS_TC if ncls > 1 else HALO_BLOCKS
@@ -461,9 +451,11 @@ def pick_split_halo(M, n_rows, seg_cs: Sequence[int], ncls=1):
     return best
 
 
-def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0):
+def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0, f16=True):
     if variant == 2:
-        return 64, 64, pick_split_halo(M, n_rows, seg_cs, ncls)
+        return 64, 64, pick_split_halo(M, n_rows, seg_cs, ncls, 64 if f16 else 32)
+    if not f16:
+        variant = 1          # (no multi-tap form in the parity mode: one tap per block)
     tm = 128 if n_rows > 64 else 64
     tn = 128 if max(seg_cs) > 64 else 64
     ntb = wgrad_taps_per_block(tm, tn, ntaps, variant)
@@ -474,7 +466,8 @@ def pick_tile_wgrad(M, n_rows, seg_cs: Sequence[int], ncls, ntaps, variant=0):
 
 # ------------------------------------------------------------------------------------------------ tensors / params
 class DevTensor:
-    """NHWC fp16 activation with channel stride cs (multiple of 8); pad channels are zero."""
+    """NHWC activation with channel stride cs (multiple of 8); pad channels are zero.  Storage: fp16 (throughput mode) or the
+    parity mode's split pairs - 4 bytes per element that torch sees as float32 (splitfmt.py); values() / grad_values() decode."""
     registry: Optional[Dict[str, "DevTensor"]] = None
     dtype = torch.float16
 
@@ -497,6 +490,17 @@ class DevTensor:
         if self.grad is None:
             self.grad = torch.zeros_like(self.buf)
         return self.grad
+
+    @staticmethod
+    def decode(t: torch.Tensor) -> torch.Tensor:
+        """fp32 values of a storage tensor (fp16, or split pairs typed float32)."""
+        return split_unpack(t) if t.dtype == torch.float32 else t.float()
+
+    def values(self) -> torch.Tensor:
+        return self.decode(self.buf)[..., :self.C]
+
+    def grad_values(self) -> Optional[torch.Tensor]:
+        return None if self.grad is None else self.decode(self.grad)[..., :self.C]
 
     def claim(self, owner: Optional[tuple] = None) -> int:
         """Returns the accumulate flag for the next producer of this tensor's gradient."""
@@ -523,7 +527,7 @@ class ParamStore:
         self.order: List[Tuple[int, int]] = []
         self.n_train = 0
         self.n_state = 0
-        self.P = self.G = self.M = self.V = self.P16 = self.S = None
+        self.P = self.G = self.M = self.V = self.P16 = self.PS = self.S = None
 
     def add(self, spec, numel, to_engine, from_engine):
         s = Slot(spec, numel, to_engine, from_engine, spec.trainable)
@@ -537,13 +541,15 @@ class ParamStore:
         self.slots[spec.name] = s
         return s
 
-    def allocate(self):
+    def allocate(self, dtype="f16"):
         n = max(self.n_train, self.ALIGN)
         self.P = torch.zeros(n, dtype=torch.float32, device=_dev())
         self.G = torch.zeros(n, dtype=torch.float32, device=_dev())
         self.M = torch.zeros(n, dtype=torch.float32, device=_dev())
         self.V = torch.zeros(n, dtype=torch.float32, device=_dev())
-        self.P16 = torch.zeros(n, dtype=torch.float16, device=_dev())
+        # operand copy of the weights the GEMM kernels read: fp16 image (throughput mode) or split pairs (parity mode, 4 B each)
+        self.P16 = torch.zeros(n, dtype=torch.float16, device=_dev()) if dtype == "f16" else None
+        self.PS = torch.zeros(n, dtype=torch.float32, device=_dev()) if dtype != "f16" else None
         self.S = torch.zeros(max(self.n_state, self.ALIGN), dtype=torch.float32, device=_dev())
         self.G16 = None           # bf16 image of G for the data-parallel exchange (allocated by dp.DataParallel(grad_dtype="bf16"))
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=_dev())      # elements whose update was skipped (NaN / Inf gradient)
@@ -697,7 +703,7 @@ class ConvOp(Op):
         a.nseg = len(self.segs)
         for s, (t, _c) in enumerate(self.segs):
             a.seg_c[s], a.seg_cs[s], a.seg_woff[s], a.seg_ptr[s] = t.cs, t.cs, self.woff[s], t.buf.data_ptr()
-        a.w = st.ptr(self.wname, "P16" if self.m.dtype == "f16" else "P").value
+        a.w = st.ptr(self.wname, "P16" if self.m.dtype == "f16" else "PS").value
         a.Kpad, a.n_rows, a.n_valid = self.Kpad, self.n_rows, self.cout
         a.out, a.out_cs, a.out_coff = self.z.buf.data_ptr(), self.z.cs, 0
         a.bias = st.ptr(self.bname, "P").value if self.bname else None
@@ -719,10 +725,12 @@ class ConvOp(Op):
         wg.dw = st.ptr(self.wname, "G").value
         wg.Kpad, wg.n_rows = self.Kpad, self.n_rows
         variant = WGRAD_VARIANT
-        if variant == 0 and self.m.dtype == "f16" and WGRAD_HALO and wgrad_halo_patch(self.g_fwd):
-            variant = 2         # 3x3 stride-1 layers: LDS-DMA halo-tile kernel
+        f16 = self.m.dtype == "f16"
+        if variant == 0 and WGRAD_HALO and wgrad_halo_patch(self.g_fwd):
+            variant = 2         # 3x3 stride-1 layers and 4x4 / stride-2 transposed convs: LDS-DMA halo-tile kernel
         tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs],
-                                     wgrad_halo_class_groups(self.g_fwd) if variant == 2 else self.g_fwd.ncls, self.g_fwd.ntaps, variant)
+                                     wgrad_halo_class_groups(self.g_fwd) if (variant == 2 and f16) else self.g_fwd.ncls, self.g_fwd.ntaps,
+                                     variant, f16)
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = variant
@@ -737,7 +745,7 @@ class ConvOp(Op):
             wg.partial = self.wg_partial.data_ptr()
         # transposed convs on the class-pair kernel: the bias gradient (column sums of dz) comes out of the weight-gradient
         # launch as per-block partial rows instead of a separate pass over dz
-        self.bias_from_wgrad = (BIAS_FROM_WGRAD and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
+        self.bias_from_wgrad = (BIAS_FROM_WGRAD and f16 and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
                                 and wgrad_halo_class_groups(self.g_fwd) == 2)
         if self.bias_from_wgrad:
             self.wg_bias_parts = 2 * sk
@@ -954,7 +962,7 @@ class GatherDgrad:
         a.out, a.out_cs, a.out_coff, a.accumulate = self.t.grad.data_ptr(), self.t.cs, 0, acc
         a.bias, a.act, a.alpha, a.stats, a.nout = None, 0, 0.0, None, 0
         Md = op0.N * op0.g_dgrad.Hl * op0.g_dgrad.Wl
-        a.tile_m, a.tile_n, a.variant = pick_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, True)
+        a.tile_m, a.tile_n, a.variant = pick_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16")
         self.args = a
         self.flops = sum(op.flops_seg[si] for op, si in self.members)
 
@@ -967,7 +975,7 @@ class GatherDgrad:
 
 def plan_gathers(m, ops) -> List[GatherDgrad]:
     """Tensors with >= 2 consuming 3x3 stride-1 convs whose data-gradient geometry the halo-tile kernel takes."""
-    if m.dtype != "f16" or not GATHER_DGRAD:
+    if not GATHER_DGRAD:
         return []
     users: Dict[int, list] = {}
     tens: Dict[int, DevTensor] = {}
@@ -1698,7 +1706,7 @@ class SegModel:
                 raise NotImplementedError("model outputs must be 1x1 conv heads")
         self.out_heads = [val[oi] for oi in g.outputs]
         # ---- parameters: ops allocate in creation order, so each op owns one contiguous slice of the flat buffers
-        self.store.allocate()
+        self.store.allocate(self.dtype)
         for op in self.ops:
             if isinstance(op, ConvOp):
                 op.finalize()
@@ -1864,6 +1872,8 @@ class SegModel:
         self._enter()
         if self.dtype == "f16":
             call("seg_cast_f32_f16", _p(st.P), _p(st.P16), st.P.numel(), _stream())
+        else:
+            call("seg_cast_f32_split", _p(st.P), _p(st.PS), st.P.numel(), _stream())
         for op in self.ops:
             op.post_step()
         self.refresh_derived()
@@ -2130,18 +2140,18 @@ class SegModel:
 
         def adam(lo, hi, exchanged=False):
             off = lambda t: C.c_void_p(t.data_ptr() + lo * t.element_size())
-            p16 = off(st.P16) if self.dtype == "f16" else None
+            p16, pfmt = (off(st.P16), _ffi.OPERAND_F16) if self.dtype == "f16" else (off(st.PS), _ffi.OPERAND_SPLIT)
             # a slice that went through the bf16 exchange is read from there (the sum over the ranks), everything else from G
             if exchanged and self.grad_dtype == "bf16":
                 g, gdt = off(st.G16), _ffi.GRAD_BF16
             else:
                 g, gdt = off(st.G), _ffi.GRAD_F32
             if other is not None:        # the rest of the registry: same slices, same streams, another update rule
-                call("seg_optimizer_step_ex", other[0], off(st.P), g, gdt, off(st.M), off(st.V), p16, hi - lo, other[1], 1.0 / self.world_size,
+                call("seg_optimizer_step_ex", other[0], off(st.P), g, gdt, off(st.M), off(st.V), p16, pfmt, hi - lo, other[1], 1.0 / self.world_size,
                      _p(st.nonfinite), _stream())
             else:                        # (a captured step reads its step size from device memory, refreshed before every replay)
                 dev = self._graph_mode
-                call("seg_adam_step_ex", off(st.P), g, gdt, off(st.M), off(st.V), p16, hi - lo, 1.0 if dev else a_t,
+                call("seg_adam_step_ex", off(st.P), g, gdt, off(st.M), off(st.V), p16, pfmt, hi - lo, 1.0 if dev else a_t,
                      _p(self._alpha_dev) if dev else None, self.beta_1, self.beta_2, self.epsilon, 1.0 / self.world_size, _p(st.nonfinite), _stream())
 
         n = st.P.numel()
