@@ -1026,7 +1026,7 @@ def test_bf16_gradient_operand_nonfinite_counter_and_pack():
         p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
         p16 = torch.zeros(n, dtype=torch.float16, device="cuda")
         cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-        ffi.call("seg_adam_step_ex", P(p), P(gbuf), gdt, P(m), P(v), P(p16), n, 1e-3, None, 0.9, 0.999, 1e-7, 0.5, P(cnt), stream())
+        ffi.call("seg_adam_step_ex", P(p), P(gbuf), gdt, P(m), P(v), P(p16), ffi.OPERAND_F16, n, 1e-3, None, 0.9, 0.999, 1e-7, 0.5, P(cnt), stream())
         torch.cuda.synchronize()
         assert int(cnt.cpu()) == 3                                   # the three non-finite elements, counted once each
         assert torch.equal(p.cpu()[~ok], p0[~ok]) and float(m.cpu()[~ok].abs().max()) == 0.0      # ... and left alone
@@ -1037,9 +1037,34 @@ def test_bf16_gradient_operand_nonfinite_counter_and_pack():
     cs = (C.c_float * 5)(1e-2, 0, 0, 0, 0)
     p, s1, s2 = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ffi.call("seg_optimizer_step_ex", ffi.OPTIMIZER["SGD"], P(p), P(g16), ffi.GRAD_BF16, P(s1), P(s2), None, n, cs, 1.0, P(cnt), stream())
+    ffi.call("seg_optimizer_step_ex", ffi.OPTIMIZER["SGD"], P(p), P(g16), ffi.GRAD_BF16, P(s1), P(s2), None, ffi.OPERAND_F16, n, cs, 1.0, P(cnt), stream())
     torch.cuda.synchronize()
     assert int(cnt.cpu()) == 3 and torch.allclose(p.cpu()[ok], (p0 - 1e-2 * want.float())[ok], rtol=1e-6, atol=1e-7)
+
+
+def test_split_operand_copy_of_the_optimisers_and_the_flat_cast():
+    """Parity mode: the optimiser kernels refresh the GEMM weight operand as split pairs (SEG_OPERAND_SPLIT: element i of the flat
+    buffer -> halves 16 (i / 8) + i % 8 and + 8); seg_cast_f32_split writes the same image from the master weights.  Both decode
+    to the updated fp32 parameter within 2^-22 relative (absolute floor 2^-36), the two images are bit-identical."""
+    n = 4096 + 64
+    p0 = torch.randn(n) * (10.0 ** torch.randint(-3, 2, (n,)).float())
+    g = torch.randn(n)
+    for which in ("adam", "sgd"):
+        p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        ps = torch.zeros(n, dtype=torch.float32, device="cuda")
+        if which == "adam":
+            ffi.call("seg_adam_step_ex", P(p), P(g.cuda()), ffi.GRAD_F32, P(m), P(v), P(ps), ffi.OPERAND_SPLIT, n, 1e-3, None, 0.9, 0.999, 1e-7, 1.0, None, stream())
+        else:
+            import ctypes as C
+            cs = (C.c_float * 5)(1e-2, 0, 0, 0, 0)
+            ffi.call("seg_optimizer_step_ex", ffi.OPTIMIZER["SGD"], P(p), P(g.cuda()), ffi.GRAD_F32, P(m), P(v), P(ps), ffi.OPERAND_SPLIT, n, cs, 1.0, None, stream())
+        ps2 = torch.zeros(n, dtype=torch.float32, device="cuda")
+        ffi.call("seg_cast_f32_split", P(p), P(ps2), n, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(ps.view(torch.int32), ps2.view(torch.int32))
+        back = U.SF.split_unpack(ps.reshape(1, n)).reshape(n).cpu()
+        assert float(((back - p.cpu()).abs() / (p.cpu().abs() + 2.0 ** -14)).max()) < 2.0 ** -21
+        assert not torch.equal(p.cpu(), p0)
 
 
 @pytest.mark.parametrize("name", ["SGD", "RMSprop", "Adagrad", "Adadelta", "Adamax", "Nadam", "FTRL"])
