@@ -391,12 +391,31 @@ def main():
                     "streaming_kernel_ms_per_step": round((tot_s - gemm_s) * 1e3, 3),
                     "kernel_seconds_per_step": {k: round(v["seconds"], 6) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])},
                     "whole_step_tflops": flop_img * bs / (ms * 1e-3) / 1e12}
+    exposed = None
+    if world > 1 or args.force_exchange:
+        # exposed communication: a few more steps with the waits for the gradient slices timed by events on the waiting stream
+        # (not part of `value`: the events serialise nothing, but the numbers are per rank and need a gather)
+        model.comm_timing = True
+        model.exposed_comm_ms()
+        n_x = 5
+        for _ in range(n_x):
+            step(x, targets)
+        mine = torch.tensor([model.exposed_comm_ms() / n_x], dtype=torch.float64, device="cuda")
+        model.comm_timing = False
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        exposed = [round(float(t.item()), 4) for t in allr]
     if world > 1:
         dist.barrier()
 
     rccl = {"backend": (dist.get_backend() if dist.is_initialized() else None), "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
-            "version": None, "gradient_bytes_per_step": int(model.store.n_train * (2 if getattr(dpm, "grad_dtype", "f32") == "f16" else 4)),
-            "gradient_dtype": getattr(dpm, "grad_dtype", "f32")}
+            "version": None, "gradient_bytes_per_step": int(model.store.n_train * (2 if getattr(dpm, "grad_dtype", "f32") == "bf16" else 4)),
+            "gradient_dtype": getattr(dpm, "grad_dtype", "f32"),
+            "exposed_comm_ms_per_step_by_rank": exposed,
+            "exposed_comm_what": "time the optimiser's stream waited for gradient slices (HIP events around each wait), mean of 5 extra steps"}
     try:
         v = torch.cuda.nccl.version()
         rccl["version"] = ".".join(str(i) for i in v) if isinstance(v, tuple) else str(v)

@@ -94,7 +94,12 @@ def _worker(rank, world, port, q):
         m3.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m3.out_heads])
         nb = len(m3.grad_buckets())
         ok5 = ok5 and M._DryRun.log.count("seg_cast_f32_bf16") == nb and bool((m3.store.G16[:m3.store.n_train].float() == 3.0).all())
-        q.put((rank, ok1, ok2, ok3 and ok4 and ok5, None))
+        # 5. a parity-mode model (dtype f32) exchanges the fp32 buffer by default: same numerics on 1 and N GPUs
+        m4 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
+        m4.build(2, dtype="f32")
+        d4 = dp.DataParallel(m4, bucket_elems=20000)
+        ok6 = d4.grad_dtype == "f32" and m4.grad_dtype == "f32" and m4.store.G16 is None
+        q.put((rank, ok1, ok2, ok3 and ok4 and ok5 and ok6, None))
         dist.destroy_process_group()
     except Exception as e:      # pragma: no cover
         import traceback

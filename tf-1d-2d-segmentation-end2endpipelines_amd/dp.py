@@ -1,9 +1,12 @@
 """Data-parallel training: one process per GPU, minibatch sharded across ranks (weak scaling, bs/GPU fixed),
 per-replica BatchNorm statistics (the reference has no SyncBN), and ONE exchange step per optimiser step: a sum
-all-reduce of the flat gradient buffer over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).  With more
-than one rank the slices travel as bf16 (half the bytes per link, SURVEY.md 8e mitigation 1: C3 795 MB -> 398 MB per
-step): a finished fp32 slice is packed by `seg_cast_f32_bf16`, summed by RCCL in bf16, and the optimiser kernel widens
-it back to fp32 - optimiser state and master weights never leave fp32.  `grad_dtype="f32"` exchanges the buffer itself.
+all-reduce of the flat gradient buffer over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
+What travels follows the model's numeric mode: a parity-mode model (dtype f32) exchanges the fp32 buffer itself - the
+same arithmetic on 1 and on N GPUs up to the summation order; a throughput-mode model (dtype f16) exchanges bf16 slices
+(half the bytes per link, SURVEY.md 8e mitigation 1: C3 795 MB -> 398 MB per step): a finished fp32 slice is packed by
+`seg_cast_f32_bf16`, summed by RCCL in bf16, and the optimiser kernel widens it back to fp32 - optimiser state and
+master weights never leave fp32.  `grad_dtype=` / SEG_DP_GRAD_DTYPE override; a backend that rejects bf16 all-reduce
+(probed once at construction) falls back to f32.
 
 The reference is single-device (no tf.distribute anywhere); this is the data-parallel
 train_step the north star adds around `2DCNN/Train.py:394-415`.
@@ -74,8 +77,8 @@ class DataParallel:
                  grad_dtype: Optional[str] = None):
         """force_exchange: take the exchange path even in a group of one rank (tests: the RCCL launches, their stream
         ordering against the side stream and the per-slice optimiser can then be exercised on a single GPU).
-        grad_dtype: "bf16" | "f32" - what the all-reduce moves (default: SEG_DP_GRAD_DTYPE, else bf16 when there is an
-        exchange with more than one rank, f32 otherwise)."""
+        grad_dtype: "bf16" | "f32" - what the all-reduce moves (default: SEG_DP_GRAD_DTYPE, else f32 for a parity-mode model,
+        bf16 for a throughput-mode model when there is an exchange with more than one rank)."""
         self.model, self.group, self.bucket_elems = model, group, bucket_elems
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -85,9 +88,12 @@ class DataParallel:
         model.bucket_elems = bucket_elems
         exchange = self.world_size > 1 or (force_exchange and dist.is_initialized())
         if grad_dtype is None:
-            grad_dtype = os.environ.get("SEG_DP_GRAD_DTYPE") or ("bf16" if (exchange and self.world_size > 1) else "f32")
+            grad_dtype = os.environ.get("SEG_DP_GRAD_DTYPE") or (
+                "bf16" if (exchange and self.world_size > 1 and getattr(model, "dtype", "f16") == "f16") else "f32")
         if grad_dtype not in ("bf16", "f32"):
             raise ValueError("grad_dtype must be 'bf16' or 'f32'")
+        if grad_dtype == "bf16" and exchange and not self._bf16_allreduce_works(model.store.G.device, group):
+            grad_dtype = "f32"
         self.grad_dtype = grad_dtype if (exchange and overlap) else "f32"      # (the non-overlapped path exchanges the buffer itself)
         model.grad_dtype = self.grad_dtype
         if self.grad_dtype == "bf16":
@@ -109,6 +115,16 @@ class DataParallel:
             broadcast_flat(scal, 0, group)
             model.adam_t, model._u_product, model.lr = int(scal[0].item()), float(scal[1].item()), float(scal[2].item())
             model._refresh_copies()
+
+    @staticmethod
+    def _bf16_allreduce_works(device, group) -> bool:
+        """One tiny bf16 all-reduce: RCCL sums bf16; a gloo build may not (every rank sees the same outcome)."""
+        try:
+            t = torch.ones(8, dtype=torch.bfloat16, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return bool(float(t[0]) == float(dist.get_world_size(group)))
+        except (RuntimeError, ValueError, TypeError):
+            return False
 
     def _allreduce(self, flat_grads: torch.Tensor):
         allreduce_flat(flat_grads, self.bucket_elems, self.group, force=self.force_exchange)

@@ -1378,6 +1378,7 @@ class SegModel:
         self.metric_names: List[str] = []   # compile(metrics=[...]): names of utils/tf_metrics.py, evaluated by harness.fit
         self._label_flag = None
         self.world_size = 1
+        self.comm_timing, self._comm_events = False, []     # bench.py --gpus N: event-timed waits for the gradient slices
         self.grad_dtype = "f32"        # what the data-parallel exchange moves: "f32" (the flat buffer itself) or "bf16" (store.G16)
         self.grad_target = GRAD_TARGET  # max |dLoss/dOut| is scaled into [target/2, target) before the fp16 backward pass
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
@@ -2166,7 +2167,7 @@ class SegModel:
             events, pos = [], 0
             with torch.cuda.stream(side):
                 for lo, hi, work in sorted(self.bucket_waits(), key=lambda t: t[0]):
-                    work.wait()                    # stream-side for RCCL: the side stream waits for this collective
+                    self._timed_wait(work, side)   # stream-side for RCCL: the side stream waits for this collective
                     if lo > pos:
                         adam(pos, lo)
                     adam(lo, hi, True)
@@ -2185,7 +2186,7 @@ class SegModel:
             # waits are stream-side), so the optimiser of the decoder's slices runs under the exchange of the encoder's
             done = []
             for lo, hi, work in self.bucket_waits():
-                work.wait()
+                self._timed_wait(work, None)
                 adam(lo, hi, True)
                 done.append((lo, hi))
             done.sort()
@@ -2226,6 +2227,28 @@ class SegModel:
                 self.refresh_derived()
             if self._graph_mode:          # a captured step has to end with every forked stream joined
                 torch.cuda.current_stream().wait_stream(self.side_stream)
+
+    def _timed_wait(self, work, stream):
+        """Wait for one gradient slice's collective.  With `comm_timing` set (bench.py --gpus N) the wait is bracketed by two
+        events on the waiting stream: their distance is the time that stream sat idle for the exchange, i.e. communication
+        the backward sweep / the optimiser of earlier slices did not cover."""
+        if not getattr(self, "comm_timing", False) or _DryRun.on:
+            work.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = stream if stream is not None else torch.cuda.current_stream()
+        e0.record(stream)
+        work.wait()
+        e1.record(stream)
+        self._comm_events.append((e0, e1))
+
+    def exposed_comm_ms(self, reset=True) -> float:
+        """Sum of the timed waits since the last call (see _timed_wait); synchronises."""
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self._comm_events)
+        if reset:
+            self._comm_events = []
+        return ms
 
     def train_step(self, x, targets, loss: Optional[str] = None) -> torch.Tensor:
         """One optimiser step = Keras' default train_step (Train.py:394-415): forward (training BN) -> loss -> backward
