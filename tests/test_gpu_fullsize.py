@@ -10,10 +10,12 @@ channels (K = 18 432 fp16 contraction) and the multi-GB activation plan.
 (the oracle costs seconds per image on the host cores, hence the reduced batch; bench.py runs the full batch.)
 
 Asserted per config, with the oracle computed ONCE and shared by both modes:
-  f32 mode  every output within 1e-3 of the oracle (the north star, as written; measured 1e-6 .. 1e-4), masks identical
-            on every pixel that is not a near-tie (|p - 0.5| or the top-2 gap not above the measured output error: a
-            probability within fp32 summation-order noise of the threshold has no defined mask; the count of such pixels is
-            reported and bounded), every node within 1e-3 relative, gradients to 2e-2 relative L2 per parameter tensor
+  f32 mode  every output within 1e-3 of the oracle (the north star, as written; measured 2e-6 .. 7e-5), masks identical
+            on every pixel whose decision margin (|p - 0.5| or the top-2 gap) exceeds a FIXED band of 1e-4 - a tenth of the
+            tolerance, independent of what this run measured: a probability that close to the threshold has no defined mask
+            under any two fp32 summation orders.  Reported per config: pixels inside the band and pixels whose mask actually
+            differs (gpurun_out/fullsize_report.json; a differing pixel is by the assertion inside the band).
+            Every node within 1e-3 relative, gradients to 2e-2 relative L2 per parameter tensor
   f16 mode  fp16 operands carry a 2^-12 relative rounding per stored activation and weight; through a random-initialised
             network the relative error grows ~1.2x per ReLU layer (measured and reproduced by the rounding-emulating oracle,
             DESIGN.md section 3), so this mode is NOT the north-star mode.  Asserted: the RMS output error (F16_RMS), the
@@ -39,6 +41,7 @@ import gpu_util as U
 from test_gpu_models import masks, margin
 
 NORTH_STAR_TOL = 1e-3
+TIE_BAND = 1e-4            # decision margin below which a mask pixel is a near-tie (fixed: a tenth of the tolerance)
 # f16 mode: bound on the max error x max(1, |ref|) and on the RMS error.  Measured on MI355X (gpurun_out/fullsize_report.json):
 # C2 1.7e-3 / 2.3e-4, C3 1.9e-3 (sigmoid out; <= 1.7e-3 x |ref| on the linear DS heads) / 3.2e-4, C5 1.8e-3 / 3.5e-4;
 # the narrow, deep stacks C1 (16 channels, 18 BN layers) 1.8e-2 / 2.4e-3 and C4 (5..512 channels, ~100 conv layers) more:
@@ -111,11 +114,14 @@ def test_baseline_config_at_its_own_size(cfg):
                          "loss": r["loss"]})
     for e in r["outs"]:
         assert e < NORTH_STAR_TOL, (cfg, r["outs"])
-    ties = 0
+    ties = flipped = npx = 0
     for (got, ref), e in zip(r["out_tensors"], r["outs"]):
-        near = margin(ref) <= max(e, 1e-6)          # |got - ref| <= e: only a pixel this close to the decision boundary can flip
+        near = margin(ref) <= TIE_BAND
+        differ = masks(got) != masks(ref)
         ties += int(near.sum())
-        assert torch.equal(masks(got)[~near], masks(ref)[~near]), f"{cfg}: masks differ in f32 mode outside the near-tie band"
+        flipped += int(differ.sum())
+        npx += differ.numel()
+        assert not bool(differ[~near].any()), f"{cfg}: masks differ in f32 mode outside the near-tie band"
         assert float(near.float().mean()) < 1e-3, f"{cfg}: near-tie band covers {float(near.float().mean()):.2e} of the pixels"
     assert worst_node[0] < 1e-3, worst_node
     assert abs(r["loss"][0] - r["loss"][1]) < 1e-5 * max(1.0, abs(r["loss"][1]))
@@ -123,7 +129,8 @@ def test_baseline_config_at_its_own_size(cfg):
     for k, (e, nrm) in r["gl2"].items():
         # (a conv bias in front of BatchNormalization has an exactly-zero gradient: both sides hold summation noise ~1e-4 x gn there)
         assert e < GRAD_L2.get(cfg, 2e-2) * (nrm + 5e-3 * gn), (cfg, k, e, nrm)
-    _record(cfg, "f32_ties", {"near_tie_pixels": ties})
+    _record(cfg, "f32_ties", {"near_tie_pixels": ties, "mask_pixels_differing": flipped, "mask_pixels": npx, "band": TIE_BAND})
+    assert flipped <= ties
     assert pads_are_zero(model32) is None
     del model32, r
     torch.cuda.empty_cache()
@@ -165,12 +172,70 @@ def test_baseline_config_at_its_own_size(cfg):
     assert pads_are_zero(model16) is None
 
 
-@pytest.mark.parametrize("cfg", ["C1", "C2", "C3", "C5", "C4"])
-def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg):
+def test_c3_forward_at_the_benched_batch_matches_the_oracle():
+    """The headline configuration at the batch bench.py times (16): training-mode forward (BatchNormalization statistics over
+    all 16 images - not the 2 of the per-config test above) in the parity mode against the oracle's forward pass."""
+    torch.manual_seed(21)
+    model, x, _targets, _loss = CONFIGS["C3"](16)
+    model.build(16, dtype="f32")
+    w = {k: torch.from_numpy(np.array(v, np.float32)) for k, v in model.get_weights().items()}
+    from ir_interp import run_graph
+    with torch.no_grad():
+        ref = run_graph(model.graph, x, w, training=True)
+    outs = model.forward(x, training=True)
+    torch.cuda.synchronize()
+    errs, flips, ties = [], 0, 0
+    for o, r in zip(outs, ref):
+        oc = o.cpu()
+        errs.append(float((oc - r).abs().max()))
+        flips += int((masks(oc) != masks(r)).sum())
+        ties += int((margin(r) <= TIE_BAND).sum())
+    _record("C3", "f32_batch16_forward", {"out_err": errs, "mask_pixels_differing": flips, "near_tie_pixels": ties})
+    assert max(errs) < TIE_BAND < NORTH_STAR_TOL
+    o0, r0 = outs[0].cpu(), ref[0]
+    near = margin(r0) <= TIE_BAND
+    assert not bool((masks(o0) != masks(r0))[~near].any())
+
+
+def test_load_keras_model_walks_the_layer_graph_into_the_engine():
+    """SegModel.load_keras_model / export_to_keras_model on the device: a (fake) tf.keras model of the reference - auto-named
+    layers in shuffled order, pairwise-folded concatenates, only `inbound_nodes` telling the structure (tests/test_keras_map.py)
+    - is taken over by a built model, predicts like a model that got the same weights by structural name, and gets them back."""
+    from test_keras_map import FakeKerasModel
+    m = B("UNetPP", 32, 32, 8, 2, num_channels=3, ds=1)
+    m.build(2, dtype="f32")
+    fake = FakeKerasModel(m.graph, np.random.default_rng(4))
+    for k, v in fake.planted.items():                     # keep BatchNormalization's moving variance positive
+        if k.endswith("moving_variance"):
+            fake.planted[k] = np.abs(v) + 0.5
+    for layer in fake.layers:
+        ws = layer.get_weights()
+        if type(layer).__name__ == "BatchNormalization":
+            ws[3] = np.abs(ws[3]) + 0.5
+            layer.set_weights(ws)
+    m.load_keras_model(fake)
+    got = m.get_weights()
+    assert all(np.array_equal(got[k], fake.planted[k]) for k in got)
+    m2 = B("UNetPP", 32, 32, 8, 2, num_channels=3, ds=1)
+    m2.build(2, dtype="f32")
+    m2.set_weights(fake.planted)
+    x = torch.rand(2, 32, 32, 3)
+    p1, p2 = m.predict(x), m2.predict(x)
+    assert all(np.array_equal(a, b) for a, b in zip(p1, p2)) and all(np.isfinite(a).all() for a in p1)
+    m.train_step(x, [bern(2, 32, 32, 1)] * len(m.out_heads), "mse")
+    m.export_to_keras_model(fake)
+    from segamd import keras_map as KM
+    back = KM.keras_weights_by_structural_name(fake, m.graph)
+    now = m.get_weights()
+    assert all(np.array_equal(back[k], now[k]) for k in now) and any(not np.array_equal(now[k], fake.planted[k]) for k in now)
+
+
+@pytest.mark.parametrize("cfg,dtype", [("C1", "f16"), ("C2", "f16"), ("C3", "f16"), ("C5", "f16"), ("C4", "f16"), ("C3", "f32"), ("C4", "f32")])
+def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg, dtype):
     torch.manual_seed(5)
     n = BASELINE_BATCH[cfg]
     model, x, targets, loss = CONFIGS[cfg](n)
-    model.build(n, dtype="f16")
+    model.build(n, dtype=dtype)
     model.compile(loss=loss, lr=2e-4)
     losses = [float(model.train_step(x, targets).cpu()) for _ in range(4)]
     assert all(np.isfinite(losses)), losses
@@ -186,11 +251,11 @@ def test_training_is_bit_reproducible_at_the_headline_config():
     32 x 32 tile of a deep-level data gradient - a write-after-read hazard on an LDS ring slot across s_barrier (fragment reads
     issued but not returned when the slot was refilled), visible only with the other stream's kernels backing up the LDS; every
     ring kernel now waits for its own LDS reads in front of the slot-releasing barrier (tools/repro_probe.py)."""
-    def run(side_stream, steps, grads_only=False):
+    def run(side_stream, steps, grads_only=False, dtype="f16"):
         torch.manual_seed(5)
         model, x, targets, loss = CONFIGS["C3"](16)
         model.use_side_stream = side_stream
-        model.build(16, dtype="f16")
+        model.build(16, dtype=dtype)
         model.compile(loss=loss, lr=2e-4)
         assert any(op.wg_partial is not None for op in model.ops if hasattr(op, "wg_partial"))
         for _ in range(steps):
@@ -210,3 +275,8 @@ def test_training_is_bit_reproducible_at_the_headline_config():
     _, _, g0 = run(True, 0, grads_only=True)          # from identical weights: one forward / backward pass
     _, _, g1 = run(True, 0, grads_only=True)
     assert torch.equal(g0, g1)
+    del g0, g1
+    # the parity mode (the bench headline): its halo kernels use the same ring discipline and the same ordered split reduce
+    p0, s0, g0 = run(True, 2, grads_only=True, dtype="f32")
+    p1, s1, g1 = run(True, 2, grads_only=True, dtype="f32")
+    assert torch.equal(p0, p1) and torch.equal(s0, s1) and torch.equal(g0, g1), "parity mode: two identical runs differ"
