@@ -108,9 +108,6 @@ typedef struct seg_igemm_fwd_args {
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
 /* patch width (32: 8x32 pixels, 16: 16x16 pixels) the variant-3 kernel uses for this geometry; 0: not eligible   */
 int seg_fwd_halo_patch(const seg_geom* g);
-/* the same for the 512 x 64 tile of the wave-specialised kernel (tile_m = 512, n_rows <= 64): 32 = 16 x 32-pixel patches,
- * 16 = 32 x 16, 0 = not eligible (then use the 256-row tiles)                                                       */
-int seg_fwd_halo_patch512(const seg_geom* g);
 
 /* ---- implicit-GEMM weight gradient of the same layers:
  *   dw[n][tap_w][woff_seg + c] += scale * (*scale_ptr) * sum_pix dz[outpix][n] * in_seg[pix+tap][c]
@@ -173,17 +170,6 @@ int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32
                      int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
                      const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
                      seg_stream_t stream);
-/* Data gradient of a 1x1 output head folded into the BN backward of the layer that produced the head's input (the
- * *_inj forms below): both passes add  gs * dpre(pix) . w  to dy on the fly, dpre = the head's pre-activation gradient from
- * its fp32 dy / y (sigmoid, softmax or linear head of `cout` <= 4 channels, stride 1).  Replaces the read-modify-write of
- * seg_head_bwd's dx over the 64-channel gradient tensor; dy may be NULL when the head is the tensor's only consumer.    */
-typedef struct seg_head_inject {
-  const float* dy;        /* [npix][cout]  dLoss / d(head output)                                          */
-  const float* y;         /* [npix][cout]  head output (after its activation)                              */
-  const float* w;         /* [cout][w_ld]  head weights, engine layout (zero beyond the real channels)     */
-  int32_t w_ld, cout, act;
-  const float* gs;        /* device scalar: the loss scale the fp16 gradient tensors carry, or NULL (= 1)  */
-} seg_head_inject;
 /* backward, pass 1: g = dy * act'(y), y = x*scale+shift; partial[part][0][c] = sum g, [1][c] = sum g*xhat       */
 int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
                           int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
@@ -440,24 +426,6 @@ int seg_transpose_w_multi_f32(const seg_transpose_desc* descs_dev, int32_t n, in
 int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
 int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
 
-
-/* BN backward passes with a head gradient injected (see seg_head_inject); inj == NULL: the plain forms              */
-int seg_bn_act_bwd_reduce_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
-                              int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean,
-                              const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts,
-                              const seg_head_inject* inj, seg_stream_t stream);
-int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
-                             void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale,
-                             const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2,
-                             int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream);
-int seg_bn_act_bwd_reduce_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
-                                  int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean,
-                                  const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts,
-                                  const seg_head_inject* inj, seg_stream_t stream);
-int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
-                                 void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale,
-                                 const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2,
-                                 int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -97,9 +97,6 @@ def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
         assert got == M.fwd_halo_patch(g)
         seen.add(got)
     assert seen == {0, 16, 32}
-    geoms += [M.geom_conv(2, h, w, 3, 3, 1, 1) for (h, w) in ((16, 32), (32, 16), (64, 48), (16, 16))]
-    assert {L.seg_fwd_halo_patch512(ctypes.byref(g)) for g in geoms} == {0, 16, 32}
-    assert all(L.seg_fwd_halo_patch512(ctypes.byref(g)) == M.fwd_halo_patch512(g) for g in geoms)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -91,21 +91,3 @@ def test_masks_bit_exact_fp32_mode(name):
     got = torch.from_numpy(p if len(model.output_names) == 1 else p[0])
     assert float((got - ref).abs().max()) < 1e-4
     assert torch.equal(masks(got), masks(ref))               # bit-exact masks
-
-
-@pytest.mark.parametrize("name", ["unetpp_ds_mse", "unet_softmax_cce", "unet_w64_bce"])
-def test_head_gradient_injection_option_matches_the_oracle(name, monkeypatch):
-    """SEG_HEAD_INJECT (off by default: step-neutral on C3): the data gradient of the 1x1 output heads is added inside the
-    BN backward passes of the producing layer (seg_bn_act_bwd_*_inj) instead of being read-modify-written by seg_head_bwd.
-    Same gradients as the default path, to the exact mode's tolerance."""
-    M = U.M
-    monkeypatch.setattr(M, "HEAD_INJECT", True)
-    torch.manual_seed(7)
-    model, x, targets, loss = CASES[name]()
-    model.build(x.shape[0], dtype="f32")
-    assert any(getattr(op, "head_inject", None) is not None for op in model.ops)
-    r = U.compare_model(model, x, targets, loss, emulate_fp16=False)
-    gn = max(n for _e, n in r["gl2"].values())
-    for k, (e, n) in r["gl2"].items():
-        assert e < 2e-2 * (n + 1e-3 * gn), (k, e, n)
-    assert U.grad_rel_err(r, floor=1e-3) < 5e-2

@@ -328,11 +328,6 @@ def test_wgrad_matches_autograd(case, variant):
     dict(shape=(1, 32, 32), cins=[40], cout=200, tile=(256, 128)),                 # two N tiles, the second ragged
     dict(shape=(3, 16, 16), cins=[128, 24], cout=136, tile=(256, 128)),            # 16x16 patches, 128-wide tile
     dict(shape=(1, 8, 32), cins=[8], cout=8, tile=(256, 64)),                      # smallest: one chunk of 8 channels
-    # wave-specialised 512 x 64 tile (8 compute + 4 loader waves): 16 x 32 and 32 x 16 patches, virtual concat, padded channels
-    dict(shape=(2, 16, 32), cins=[64], cout=64, tile=(512, 64)),
-    dict(shape=(1, 32, 64), cins=[64, 32, 8], cout=40, tile=(512, 64)),
-    dict(shape=(2, 32, 16), cins=[96], cout=64, tile=(512, 64)),
-    dict(shape=(1, 64, 48), cins=[72, 8], cout=24, tile=(512, 64)),
 ], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-{c['tile']}")
 @pytest.mark.parametrize("mode", ["plain", "bias_relu_stats", "accumulate"])
 def test_conv_fwd_halo_kernel(case, mode):
@@ -361,8 +356,6 @@ def test_conv_fwd_halo_kernel(case, mode):
     dict(shape=(1, 16, 16), cin=72, cout=24, tile=(256, 64)),
     dict(shape=(2, 8, 64), cin=64, cout=128, tile=(256, 128)),
     dict(shape=(1, 16, 16), cin=160, cout=136, tile=(256, 128)),
-    dict(shape=(2, 16, 32), cin=128, cout=64, tile=(512, 64)),                      # wave-specialised tile
-    dict(shape=(1, 32, 16), cin=72, cout=24, tile=(512, 64)),
 ], ids=lambda c: f"{c['shape']}-{c['cin']}->{c['cout']}-{c['tile']}")
 def test_conv_transpose_fwd_halo_kernel(case):
     """variant 3 on Conv2DTranspose(4x4, stride 2): four sub-pixel classes of 2x2 taps from the same halo tile."""
@@ -416,12 +409,12 @@ def test_conv_statistics_at_full_size_are_exact_and_repeatable():
     dict(shape=(3, 8, 8), cins=[128, 40], cout=72, sk=2),                 # 8x8 patches: a 16-pixel K block spans two image rows
     dict(shape=(2, 16, 24), cins=[64], cout=64, sk=3),                    # W = 24 -> 8-wide patches, several per row
 ], ids=lambda c: f"{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
-@pytest.mark.parametrize("gen", ["auto", "ts", "ts16", "ws", "r1"])
+@pytest.mark.parametrize("gen", ["auto", "ts", "ws", "r1"])
 def test_wgrad_halo_kernel_matches_autograd(case, gen):
     """variant 2: LDS-DMA halo tiles + transposed LDS reads, 3x3 stride-1 'same' convs.  Three generations of the kernel
-    behind the same entry point (bits 8.. of `variant` force one): tap-split (default for larger grids; ts16 = its
-    16x16x32-MFMA form), wave-specialised (default for small grids), round 1."""
-    variant = 2 | ({"auto": 0, "ws": 0x40, "r1": 0x80, "ts": 0x100, "ts16": 0x300}[gen] << 8)
+    behind the same entry point (bits 8.. of `variant` force one): tap-split (default for larger grids), wave-specialised
+    (default for small grids), round 1."""
+    variant = 2 | ({"auto": 0, "ws": 0x40, "r1": 0x80, "ts": 0x100}[gen] << 8)
     N, H, W = case["shape"]
     xs = [h16(torch.randn(N, H, W, c)) for c in case["cins"]]
     cin = sum(case["cins"])

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseg_hip.so")
+# SEG_LIB=<path>: another build of the library (A/B runs and bisecting - tools/ab_bench.sh - select a build this way instead
+# of overwriting the in-tree file)
+LIB_PATH = os.environ.get("SEG_LIB") or os.path.join(_HERE, "libseg_hip.so")
 
 MAX_SEG, MAX_TAPS, MAX_CLS = 8, 16, 4
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "leaky_relu": 2, "sigmoid": 3, "softmax": 4}
@@ -56,11 +58,6 @@ class IgemmWgradArgs(C.Structure):
                 ("overwrite", C.c_int32), ("partial", C.c_void_p)]
 
 
-class HeadInject(C.Structure):
-    _fields_ = [("dy", C.c_void_p), ("y", C.c_void_p), ("w", C.c_void_p), ("w_ld", C.c_int32), ("cout", C.c_int32), ("act", C.c_int32),
-                ("gs", C.c_void_p)]
-
-
 class TransposeDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("rows", C.c_int32), ("T", C.c_int32), ("K", C.c_int32),
                 ("k0", C.c_int32), ("kcount", C.c_int32), ("rows_pad", C.c_int32), ("dst_ld", C.c_int32),
@@ -77,15 +74,12 @@ _PROTOS = {
     "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_wgrad_halo_class_groups": ([C.POINTER(Geom)], C.c_int),
     "seg_fwd_halo_patch": ([C.POINTER(Geom)], C.c_int),
-    "seg_fwd_halo_patch512": ([C.POINTER(Geom)], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),
     "seg_bn_act_bwd_reduce": ([vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, f32, vp, i32, vp], C.c_int),
     "seg_bn_bwd_finalize": ([vp, i32, i32, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_bwd_apply": ([vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp], C.c_int),
-    "seg_bn_act_bwd_reduce_inj": ([vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, f32, vp, i32, C.POINTER(HeadInject), vp], C.c_int),
-    "seg_bn_act_bwd_apply_inj": ([vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, C.POINTER(HeadInject), vp], C.c_int),
     "seg_act_bwd": ([vp, vp, vp, i64, i32, i32, i32, f32, vp, f32, vp, vp], C.c_int),
     "seg_maxpool_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_maxpool_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
@@ -125,7 +119,6 @@ _PROTOS = {
 
 # entry points that touch activation tensors exist twice: fp16 (throughput mode) and *_f32 (exact-fp32 parity mode)
 DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
-        "seg_bn_act_bwd_reduce_inj", "seg_bn_act_bwd_apply_inj",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
         "seg_add_act_bwd", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
         "seg_head_fwd", "seg_head_bwd", "seg_head_act_fwd", "seg_head_act_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")

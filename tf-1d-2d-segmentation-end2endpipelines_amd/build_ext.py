@@ -1,7 +1,8 @@
 """Builds libseg_hip.so in-tree: hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
 
 Every csrc/*.hip is its own translation unit: the units compile in parallel (the two big ones take about a minute each)
-and only the ones whose source - or a header - changed are rebuilt; the objects live in csrc/_build/ (git-ignored)."""
+and only the ones whose source, a header or the compiler flags changed (by content hash, kept beside each object) are
+rebuilt; the objects live in csrc/_build/ (git-ignored)."""
 import glob
 import hashlib
 import os
@@ -30,11 +31,24 @@ def _obj(src):
     return os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _obj_key(src, hdrs) -> str:
+    """What an object file depends on: its source, every header and the compiler flags, by content (a flags-only change or a
+    copy that does not keep modification times must recompile, an unchanged unit must not)."""
+    h = hashlib.sha256()
+    for f in [src] + list(hdrs):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(CFLAGS).encode())
+    return h.hexdigest()
+
+
+def _stale(obj, key) -> bool:
+    stamp = obj + ".key"
+    if not (os.path.exists(obj) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as fh:
+        return fh.read().strip() != key
 
 
 def _fingerprint() -> str:
@@ -64,12 +78,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     jobs = []
     for s in srcs:
-        if force or _stale(_obj(s), [s] + hdrs):
+        key = _obj_key(s, hdrs)
+        if force or _stale(_obj(s), key):
+            if os.path.exists(_obj(s) + ".key"):
+                os.remove(_obj(s) + ".key")
             cmd = [hipcc] + CFLAGS + inc + ["-c", s, "-o", _obj(s)]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            jobs.append((s, subprocess.Popen(cmd)))
-    failed = [s for s, p in jobs if p.wait() != 0]
+            jobs.append((s, key, subprocess.Popen(cmd)))
+    failed = []
+    for s, key, p in jobs:
+        if p.wait() != 0:
+            failed.append(s)
+        else:
+            with open(_obj(s) + ".key", "w") as fh:
+                fh.write(key + "\n")
     if failed:
         raise RuntimeError("hipcc failed for " + ", ".join(os.path.basename(f) for f in failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in srcs] + ["-o", OUT]

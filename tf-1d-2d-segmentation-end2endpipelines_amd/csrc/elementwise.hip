@@ -276,49 +276,11 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const T* x, int 
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
-template <int CO>
-__device__ __forceinline__ void head_dpre(const float* dy, const float* y, int Cout, int act, float* d);
-
-// Gradient of a 1x1 output head (HeadOp) INJECTED into the BN backward of the layer that produced the head's input: the
-// head's data gradient gs * dpre(pix) . w is a rank-Cout update per pixel, so instead of a separate read-modify-write pass
-// over the 64-channel gradient tensor (seg_head_bwd: 3 x 134 MB per head at 256x256, bs 16) both BN passes add it on the
-// fly from the head's dy / y (fp32, Cout values per pixel).  HCO = 0: no injection; 1 / 4: head channels (rounded up).
-// dy == nullptr (only with an injection): the tensor has no other gradient producer.
-template <int HCO>
-__device__ __forceinline__ void head_inject_load(const seg_head_inject& h, int ch, float (&hw)[HCO > 0 ? HCO : 1][8]) {
-  if constexpr (HCO > 0) {
-    const float gs = h.gs ? *h.gs : 1.f;
-#pragma unroll
-    for (int k = 0; k < HCO; ++k)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) hw[k][t] = (k < h.cout) ? h.w[k * h.w_ld + ch * 8 + t] * gs : 0.f;
-  }
-}
-template <int HCO>
-__device__ __forceinline__ void head_inject_add(const seg_head_inject& h, int64_t pix, const float (&hw)[HCO > 0 ? HCO : 1][8], float* g) {
-  if constexpr (HCO > 0) {
-    float dyv[HCO], yv[HCO], d[HCO];
-#pragma unroll
-    for (int k = 0; k < HCO; ++k) {
-      dyv[k] = (k < h.cout) ? h.dy[pix * h.cout + k] : 0.f;
-      yv[k] = (k < h.cout) ? h.y[pix * h.cout + k] : 0.f;
-    }
-    head_dpre<HCO>(dyv, yv, h.cout, h.act, d);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < HCO; ++k) s += d[k] * hw[k][t];
-      g[t] += s;
-    }
-  }
-}
-
-template <typename T, int HCO>
+template <typename T>
 __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int dy_cs, int dy_coff, const T* x, int x_cs,
                                                                 int x_coff, int64_t npix, int C, const float* scale,
                                                                 const float* shift, const float* mean, const float* invstd, int act,
-                                                                float alpha, float* partial, int nparts, ColLayout L, seg_head_inject inj) {
+                                                                float alpha, float* partial, int nparts, ColLayout L) {
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
   const int part = blockIdx.x;
@@ -334,16 +296,9 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int
         const int c = ch * 8 + t;
         sc[t] = scale[c]; sh[t] = shift[c]; mu[t] = mean[c]; is[t] = invstd[c];
       }
-      float hw[HCO > 0 ? HCO : 1][8];
-      head_inject_load<HCO>(inj, ch, hw);
       for (int64_t pix = (int64_t)part * L.RP + rowi; pix < npix; pix += (int64_t)L.RP * nparts) {   // interleaved rows
         float g[8], xv[8];
-        if (HCO == 0 || dy != nullptr) load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
-        else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) g[t] = 0.f;
-        }
-        head_inject_add<HCO>(inj, pix, hw, g);
+        load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
         load8(x + pix * x_cs + x_coff + ch * 8, xv);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -381,12 +336,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* parti
   c2[c] = q * inv_count;
 }
 
-template <typename T, int HCO>
+template <typename T>
 __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int dy_cs, int dy_coff, const T* x, int x_cs,
                                                                int x_coff, T* dx, int dx_cs, int dx_coff, int64_t npix, int C,
                                                                const float* scale, const float* shift, const float* mean,
                                                                const float* invstd, const float* c1, const float* c2, int act,
-                                                               float alpha, int accumulate, ColLayout L, seg_head_inject inj) {
+                                                               float alpha, int accumulate, ColLayout L) {
   // thread = (pixel row rowi, channel chunk col); blocks walk the tensor in interleaved chunks of RP * UNR pixels (as
   // act_bwd_kernel: concurrently running blocks stream neighbouring addresses - 2.9 -> 4.5 TB/s against a plain
   // grid-stride loop whose four loads per thread are megabytes apart); the channel chunk of a thread is fixed, so
@@ -413,22 +368,15 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
         kb[t] = 0.f;
       }
     }
-    float hw[HCO > 0 ? HCO : 1][8];
-    head_inject_load<HCO>(inj, ch, hw);
     for (int64_t pb = blockIdx.x * chunk + rowi; pb < npix; pb += chunk * gridDim.x) {
       float g[UNR][8], xv[UNR][8], old[UNR][8];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int64_t pix = pb + (int64_t)u * L.RP;
         if (pix < npix) {
-          if (HCO == 0 || dy != nullptr) load8(dy + pix * dy_cs + dy_coff + ch * 8, g[u]);
-          else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) g[u][t] = 0.f;
-          }
+          load8(dy + pix * dy_cs + dy_coff + ch * 8, g[u]);
           load8(x + pix * x_cs + x_coff + ch * 8, xv[u]);
           if (accumulate) load8(dx + pix * dx_cs + dx_coff + ch * 8, old[u]);
-          head_inject_add<HCO>(inj, pix, hw, g[u]);
         }
       }
 #pragma unroll
@@ -1600,42 +1548,21 @@ static int seg_bn_act_apply_impl(const void* x, int32_t x_cs, int32_t x_coff, vo
 extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<half_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
 extern "C" int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<split_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
 
-static bool check_inject(const seg_head_inject* inj, const void* dy, int32_t C, const char* who) {
-  if (inj == nullptr) {
-    if (dy == nullptr) { seg_set_error("%s: null dy without a head injection", who); return false; }
-    return true;
-  }
-  if (!(inj->dy && inj->y && inj->w && inj->cout >= 1 && inj->cout <= 4 && inj->w_ld >= C && inj->act >= SEG_ACT_NONE && inj->act <= SEG_ACT_SOFTMAX)) {
-    seg_set_error("%s: bad head injection (cout=%d w_ld=%d act=%d; 1..4 head channels)", who, inj->cout, inj->w_ld, inj->act);
-    return false;
-  }
-  return true;
-}
-
 template <typename T>
 static int seg_bn_act_bwd_reduce_impl(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
                                      int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean,
-                                     const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj,
+                                     const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts,
                                      seg_stream_t stream) {
-  SEG_CHECK_ARG(x && scale && shift && mean && invstd && partial && npix > 0 && C > 0 && (C & 7) == 0 && nparts > 0 &&
+  SEG_CHECK_ARG(dy && x && scale && shift && mean && invstd && partial && npix > 0 && C > 0 && (C & 7) == 0 && nparts > 0 &&
                     dy_coff + C <= dy_cs && x_coff + C <= x_cs,
                 "seg_bn_act_bwd_reduce: bad arguments");
-  if (!check_inject(inj, dy, C, "seg_bn_act_bwd_reduce")) return SEG_ERR_ARG;
-  const seg_head_inject none = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
-#define SEG_LAUNCH_RED(HCO, INJ)                                                                                                       \
-  hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, HCO>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff, (const T*)x, \
-                     x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C), INJ)
-  if (inj == nullptr) SEG_LAUNCH_RED(0, none);
-  else if (inj->cout == 1) SEG_LAUNCH_RED(1, *inj);
-  else SEG_LAUNCH_RED(4, *inj);
-#undef SEG_LAUNCH_RED
+  hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff, (const T*)x,
+                     x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C));
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_reduce");
   return SEG_OK;
 }
-extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
-extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
-extern "C" int seg_bn_act_bwd_reduce_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
-extern "C" int seg_bn_act_bwd_reduce_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
+extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, stream); }
+extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, stream); }
 
 extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma, float* dbeta,
                                    float gscale, const float* gscale_ptr, float* c1, float* c2, seg_stream_t stream) {
@@ -1650,30 +1577,21 @@ template <typename T>
 static int seg_bn_act_bwd_apply_impl(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx,
                                     int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
                                     const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha,
-                                    int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) {
-  SEG_CHECK_ARG(x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
+                                    int32_t accumulate, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
                     dx_coff + C <= dx_cs && (c1 == nullptr || (c2 && mean && invstd)),
                 "seg_bn_act_bwd_apply: bad arguments");
-  if (!check_inject(inj, dy, C, "seg_bn_act_bwd_apply")) return SEG_ERR_ARG;
   const ColLayout L = col_layout(C);
   int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
   if (blocks > 512) blocks = 512;       // two blocks per CU: 96 us per 134 MB tensor against 114 us at 2048 blocks (measured sweep)
-  const seg_head_inject none = {nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
-#define SEG_LAUNCH_APP(HCO, INJ)                                                                                                     \
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, HCO>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,     \
-                     (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,     \
-                     accumulate, L, INJ)
-  if (inj == nullptr) SEG_LAUNCH_APP(0, none);
-  else if (inj->cout == 1) SEG_LAUNCH_APP(1, *inj);
-  else SEG_LAUNCH_APP(4, *inj);
-#undef SEG_LAUNCH_APP
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
+                     (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
+                     accumulate, L);
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply");
   return SEG_OK;
 }
-extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
-extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
-extern "C" int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
-extern "C" int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
+extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, stream); }
+extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, stream); }
 
 template <typename T>
 static int seg_act_bwd_impl(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,

@@ -489,8 +489,6 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st);
 int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st);      // parity mode; v = split_view(args)
 // its software-pipelined generation (igemm_halo2.hip); called by seg_launch_fwd3 after the argument checks
 int seg_launch_fwd4(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st);
-// wave-specialised 512 x 64 halo-tile forward (igemm_halo3.hip); called by seg_launch_fwd3 for tile_m == 512
-int seg_launch_fwd5(const seg_igemm_fwd_args& a, hipStream_t st);
 // wave-specialised halo-tile weight gradient (igemm_wgrad2.hip); called by seg_igemm_wgrad after the argument checks
 int seg_launch_wgrad_halo_ws(const seg_igemm_wgrad_args& a, int pc, dim3 grid, hipStream_t st);
 int seg_launch_wgrad_halo_ts(const seg_igemm_wgrad_args& a, int pc, dim3 grid, hipStream_t st);   // igemm_wgrad3.hip

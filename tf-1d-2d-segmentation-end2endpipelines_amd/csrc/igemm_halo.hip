@@ -383,12 +383,10 @@ static void launch_fwd3_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipSt
 int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   const int pw = seg_fwd_halo_patch(&a.g);
   SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd: variant 3 needs a stride-1 3x3 'same' conv, a 4x4 / stride-2 transposed conv (or the data gradient of either), and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
-  SEG_CHECK_ARG((a.tile_m == 256 && (a.tile_n == 64 || a.tile_n == 128)) || (a.tile_m == 512 && a.tile_n == 64),
-                "seg_igemm_fwd: variant 3 tiles are 256x64, 256x128 and 512x64, not %dx%d", a.tile_m, a.tile_n);
+  SEG_CHECK_ARG(a.tile_m == 256 && (a.tile_n == 64 || a.tile_n == 128), "seg_igemm_fwd: variant 3 tiles are 256x64 and 256x128, not %dx%d", a.tile_m, a.tile_n);
   const long pix = (long)a.g.N * a.g.Hin * a.g.Win;
   for (int s = 0; s < a.nseg; ++s) SEG_CHECK_ARG(pix * a.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd: variant 3 needs operands below 1 GiB");
   SEG_CHECK_ARG((long)a.n_rows * a.g.T_total * a.Kpad * 2 < (1L << 30), "seg_igemm_fwd: variant 3 needs operands below 1 GiB");
-  if (a.tile_m == 512) return seg_launch_fwd5(a, st);        // wave-specialised generation for <= 64 output channels (igemm_halo3.hip)
   const int npatch = (int)((long)a.g.N * a.g.Hl * a.g.Wl / 256);
   const int nblocks = (a.n_rows + a.tile_n - 1) / a.tile_n;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)a.g.ncls, 1);
@@ -399,7 +397,7 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   // bounds the kernel, not the exposed ds_read latency (ablations in DESIGN.md section 4).  SEG_FWD_PIPE=0 / 1 forces one.
   static const char* pipe_env = std::getenv("SEG_FWD_PIPE");
   const bool pipe = pipe_env != nullptr ? std::atoi(pipe_env) != 0 : (a.g.ntaps != 9);
-  if (pipe || ((a.variant >> 8) != 0 && a.tile_m != 512)) {
+  if (pipe || (a.variant >> 8) != 0) {
     seg_launch_fwd4(a, pw, grid, st);
     SEG_CHECK_LAUNCH("seg_igemm_fwd (halo tiles, pipelined)");
     return SEG_OK;

@@ -35,7 +35,7 @@ import numpy as np
 import torch
 
 from . import _ffi
-from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs, HeadInject
+from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs
 from .graph import Graph, Node, ParamSpec
 from .splitfmt import split_pack, split_unpack
 
@@ -322,24 +322,6 @@ def fwd_halo_patch(g: Geom) -> int:
     return 0
 
 
-def fwd_halo_patch512(g: Geom) -> int:
-    """Mirror of seg_fwd_halo_patch512(): 512-pixel patches (16 x 32 or 32 x 16) of the wave-specialised 512 x 64 tile."""
-    if not fwd_halo_patch(g) or g.isy != 1:
-        return 0
-    if g.Wl % 32 == 0 and g.Hl % 16 == 0:
-        return 32
-    if g.Wl % 16 == 0 and g.Hl % 32 == 0:
-        return 16
-    return 0
-
-
-# wave-specialised 512 x 64 halo tile for layers with <= 64 output channels (igemm_halo3.hip).  Faster alone (see pick_fwd), but in
-# the training step - next to the weight gradients of the side stream - C3 is 0.3-0.5 ms SLOWER with it (same-box A/B,
-# gpurun_out/r2k): a 768-thread one-block-per-CU kernel leaves the side stream less room than two 256-thread blocks.  OFF by
-# default; SEG_FWD_WS=1 enables it (forward-only / inference workloads profit).
-FWD_WS = os.environ.get("SEG_FWD_WS", "0") != "0"
-FWD_WS_MIN_BLOCKS = int(os.environ.get("SEG_FWD_WS_MIN_BLOCKS", "512"))
-FWD_WS_MIN_K = int(os.environ.get("SEG_FWD_WS_MIN_K", "2048"))       # taps x K channels from which the 512 x 64 tile pays
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
@@ -350,10 +332,6 @@ DP_BUSBW_GBS = float(os.environ.get("SEG_DP_BUSBW_GBS", "300"))                 
 ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
 ADAM_URGENT_FIRST = os.environ.get("SEG_ADAM_URGENT_FIRST", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
-# forward pass: deep (small-image) ops on a second stream.  Measured step-neutral on C3 (24.71 / 24.51 against 24.59 / 24.55 ms,
-# same box, gpurun_out/r2m): the full-resolution kernels already occupy every CU's LDS, so the deep kernels' blocks queue
-# behind them instead of running beside them.  OFF by default (SEG_FWD_TWO_STREAMS=1); parity-tested with it on.
-FWD_TWO_STREAMS = os.environ.get("SEG_FWD_TWO_STREAMS", "0") != "0"
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
 
 
@@ -361,13 +339,6 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     """(tile_m, tile_n, variant) of a forward / data-gradient launch.  f16 = False: the parity mode (split-pair tensors, csrc
     igemm_fwd_split.hip / igemm_halo.hip SPLIT): the same kernel families with two accumulator sets per wave, hence the halo
     tile is 256 x 64 only and the per-tap LDS-DMA kernel has no 64-deep K step."""
-    # wave-specialised 512 x 64 tile: measured (tools/op_bench.py, C3, same box) +4 .. +8 % on the long-K 64-channel layers
-    # (X03 .. X05 forward, gathered data gradients), +14 % on the transposed-conv forward (class-fastest blocks share the halo
-    # tile in L2), but -2 .. -13 % on short reductions (K = 576 data gradients, the first layer) where the longer prologue /
-    # epilogue of a one-block-per-CU kernel is not amortised
-    if (f16 and FWD_HALO and FWD_WS and n_rows <= 64 and fwd_halo_patch512(g) and g.ncls * (M // 512) >= FWD_WS_MIN_BLOCKS
-            and (g.ncls == 4 or ktot >= FWD_WS_MIN_K)):
-        return 512, 64, 3
     if FWD_HALO and fwd_halo_patch(g):
         tn = 64 if (n_rows <= 64 or not f16) else 128
         if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
@@ -426,11 +397,6 @@ def wgrad_halo_class_groups(g: Geom) -> int:
 
 WGRAD_FORK_EARLY = os.environ.get("SEG_WGRAD_FORK_EARLY", "1") != "0"   # side stream forks when dz is final, before the op's data gradients are enqueued
 HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
-# output heads on a conv+BN tensor: data gradient folded into that layer's BN backward (seg_bn_act_bwd_*_inj).  Measured on C3
-# (same box A/B, gpurun_out/r2i): seg_head_bwd 0.70 -> 0.32 ms per step, but the two BN passes of the six level-0 tensors
-# grow by 0.39 ms (two extra 4-byte gathers per pixel in kernels that sit on the HBM roofline): step-neutral, so it is OFF
-# by default and kept as a tested option (SEG_HEAD_INJECT=1)
-HEAD_INJECT = os.environ.get("SEG_HEAD_INJECT", "0") != "0"
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = int(os.environ.get("SEG_HALO_BLOCKS_TC", os.environ.get("SEG_HALO_BLOCKS", "256")))   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
@@ -570,14 +536,6 @@ class Op:
     def forward(self, training: bool):
         raise NotImplementedError
 
-    def reads(self) -> list:
-        """Activation tensors the forward pass of this op reads / writes (the two-stream forward schedule orders ops that run
-        on different streams through these)."""
-        return []
-
-    def writes(self) -> list:
-        return []
-
     def plan_backward(self):
         """Called once, in reverse order, to fix accumulate flags."""
 
@@ -592,12 +550,6 @@ class InputOp(Op):
     def __init__(self, m, t: DevTensor, Cin):
         self.m, self.t, self.Cin = m, t, Cin
         t.needs_grad = False
-
-    def reads(self):
-        return []
-
-    def writes(self):
-        return [self.t]
 
     def forward(self, training):
         x = self.m._x
@@ -690,7 +642,6 @@ class ConvOp(Op):
         self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
         self.wt = torch.zeros(Kpad * self.T * self.rows_pad, dtype=DevTensor.dtype, device=dev) if any(self.need_dgrad) else None
         self.fwd_args = None
-        self.head_inject: Optional["HeadOp"] = None       # output head whose data gradient this layer's BN backward adds on the fly
         self.gathered: Dict[int, "GatherDgrad"] = {}      # segment index -> gathered data gradient that covers it
         self.gather_launch: List["GatherDgrad"] = []      # gathered data gradients launched at the end of this op's backward
         self.dz_ptr = None
@@ -759,12 +710,6 @@ class ConvOp(Op):
             return []
         return [(self.m.store.ptr(self.wname, self.m.src_buf).value, self.wt.data_ptr(), self.n_rows, self.T, self.Kpad, 0, self.Kpad,
                  self.rows_pad, self.rows_pad, 0)]
-
-    def reads(self):
-        return [t for t, _c in self.segs]
-
-    def writes(self):
-        return [t for t in (self.out, self.z, self.pooled) if t is not None]
 
     def forward(self, training):
         st, s = self.m.store, _stream()
@@ -864,23 +809,15 @@ class ConvOp(Op):
         if self.has_bn:
             bn = self.bn_name
             dA = self.out.ensure_grad()
-            inj, sfx = None, ""
             src = _p(dA)
-            if self.head_inject is not None:
-                # the head's data gradient (a rank-Cout update per pixel) is added by both passes instead of having been
-                # read-modify-written into dA by seg_head_bwd; with no other consumer nothing was written into dA at all
-                inj, sfx = C.byref(self.head_inject.inject_args()), "_inj"
-                if not self.out.claimers:
-                    src = None
-            extra = (inj,) if inj is not None else ()
-            call("seg_bn_act_bwd_reduce" + sfx, src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
+            call("seg_bn_act_bwd_reduce", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
                  _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
-                 _p(self.bpart), BN_PARTS_BWD, *extra, s)
+                 _p(self.bpart), BN_PARTS_BWD, s)
             call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
                  st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
-            call("seg_bn_act_bwd_apply" + sfx, src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
+            call("seg_bn_act_bwd_apply", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
                  self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
-                 _p(self.c2), ACT[self.act], float(self.alpha), 0, *extra, s)
+                 _p(self.c2), ACT[self.act], float(self.alpha), 0, s)
             dz = dA
         elif self.kind == "convlstm":
             dz = self.z.ensure_grad()
@@ -1022,38 +959,12 @@ class HeadOp(Op):
         m.store.add(bspec, cout, lambda b: np.asarray(b, np.float32), lambda f: f[:cout].copy())
         self.wname, self.bname = kspec.name, bspec.name
 
-    def reads(self):
-        return [self.x]
-
-    def writes(self):
-        return []
-
     def forward(self, training):
         st = self.m.store
         call("seg_head_fwd", _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W, self.sy, self.sx,
              st.ptr(self.wname), self.w_ld, st.ptr(self.bname), self.cout, self.act, _p(self.y), _stream())
 
-    def inject_args(self) -> HeadInject:
-        if self._inj is None:
-            st = self.m.store
-            h = HeadInject()
-            h.dy, h.y, h.w = self.dy.data_ptr(), self.y.data_ptr(), st.ptr(self.wname).value
-            h.w_ld, h.cout, h.act, h.gs = self.w_ld, self.cout, self.act, self.m.gs.data_ptr()
-            self._inj = h
-        return self._inj
-
     def plan_backward(self):
-        self._inj = None
-        self.injected = False
-        prod = self.m.producer_of.get(id(self.x)) if hasattr(self.m, "producer_of") else None
-        if (HEAD_INJECT and not isinstance(self, WideHeadOp) and prod is not None and prod.has_bn and prod.head_inject is None
-                and prod.out is self.x and (self.sy, self.sx) == (1, 1) and self.cout <= 4 and self.x.needs_grad):
-            # the producing layer's BN backward adds this head's data gradient on the fly: no pass over x.grad here
-            prod.head_inject = self
-            self.injected = True
-            self.x.gw = True                   # the tensor does receive a gradient (the producer must run its backward)
-            self.acc = None
-            return
         self.acc = self.x.claim() if self.x.needs_grad else None
 
     def backward(self):
@@ -1090,12 +1001,6 @@ class WideHeadOp(HeadOp):
         self.y = torch.zeros((logits.N, logits.H, logits.W, self.cout), dtype=torch.float32, device=_dev())
         self.dy = torch.zeros_like(self.y)
 
-    def reads(self):
-        return [self.x]
-
-    def writes(self):
-        return []
-
     def forward(self, training):
         x = self.x
         call("seg_head_act_fwd", _p(x.buf), x.cs, x.npix, self.cout, self.act, _p(self.y), _stream())
@@ -1129,12 +1034,6 @@ class ReshapeOp(Op):
         else:
             call("seg_copy_channels", _p(src), img.C, 0, _p(dst), img.cs, 0, img.C, img.npix, accumulate, _stream())
 
-    def reads(self):
-        return [self.x]
-
-    def writes(self):
-        return [self.out]
-
     def forward(self, training):
         self._copy(self.to_flat, self.x.buf, self.out.buf, 0)
 
@@ -1163,12 +1062,6 @@ class BNOp(Op):
         self.bpart = torch.zeros(BN_PARTS_BWD * 2 * self.C, dtype=torch.float32, device=dev)
         self.mean, self.invstd, self.scale, self.shift, self.c1, self.c2 = (
             torch.zeros(self.C, dtype=torch.float32, device=dev) for _ in range(6))
-
-    def reads(self):
-        return [self.x]
-
-    def writes(self):
-        return [self.out]
 
     def forward(self, training):
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
@@ -1208,12 +1101,6 @@ class ConcatOp(Op):
     def __init__(self, m, segs: List[Tuple[DevTensor, int]], out: DevTensor):
         self.m, self.segs, self.out = m, segs, out
 
-    def reads(self):
-        return [t for t, _c in self.segs]
-
-    def writes(self):
-        return [self.out]
-
     def forward(self, training):
         off = 0
         for t, c in self.segs:
@@ -1245,12 +1132,6 @@ class AddOp(Op):
             raise NotImplementedError("add of more than 4 tensors")
         self.ptrs = (C.c_void_p * 4)(*[x.buf.data_ptr() for x in xs])
 
-    def reads(self):
-        return list(self.xs)
-
-    def writes(self):
-        return [self.out]
-
     def forward(self, training):
         call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
              float(self.alpha), _stream())
@@ -1281,12 +1162,6 @@ class MulOp(Op):
         if r.C != 1:
             raise NotImplementedError("mul: the second operand must be a 1-channel map (Attention_Block)")
 
-    def reads(self):
-        return [self.a, self.r]
-
-    def writes(self):
-        return [self.out]
-
     def forward(self, training):
         call("seg_mul_bcast_fwd", _p(self.a.buf), _p(self.r.buf), _p(self.out.buf), self.a.npix, self.a.cs, self.r.cs, _stream())
 
@@ -1307,12 +1182,6 @@ class UpsampleOp(Op):
     def __init__(self, m, x: DevTensor, size, bilinear, out: DevTensor):
         self.m, self.x, self.size, self.bilinear, self.out = m, x, size, 1 if bilinear else 0, out
 
-    def reads(self):
-        return [self.x]
-
-    def writes(self):
-        return [self.out]
-
     def forward(self, training):
         x = self.x
         call("seg_upsample_fwd", _p(x.buf), _p(self.out.buf), x.N, x.H, x.W, x.cs, self.size[0], self.size[1], self.bilinear, _stream())
@@ -1332,12 +1201,6 @@ class UpsampleOp(Op):
 class PoolOp(Op):
     def __init__(self, m, x: DevTensor, size, out: DevTensor):
         self.m, self.x, self.size, self.out = m, x, size, out
-
-    def reads(self):
-        return [self.x]
-
-    def writes(self):
-        return [self.out]
 
     def forward(self, training):
         x = self.x
@@ -1715,7 +1578,6 @@ class SegModel:
         self.gathers = [] if _DryRun.on else plan_gathers(self, self.ops)
         self._build_transpose_table()
         self.set_weights({p.name: init_param(p, self.seed) for p in g.param_specs()})
-        self._plan_forward_streams()
         # ---- static backward schedule (accumulate flags)
         self.producer_of = {id(op.out): op for op in self.ops if isinstance(op, ConvOp)}
         for op in reversed(self.ops):
@@ -1727,35 +1589,6 @@ class SegModel:
         self.built = True
         self._init_optimizer_state()
         return self
-
-    def _plan_forward_streams(self):
-        """Two-stream forward schedule.  The deep levels of a UNet (images of 32 x 32 and smaller at 256 x 256 input: 1024-2048
-        channels, 128-256 blocks per launch) cannot fill 256 CUs - measured 350-660 TFLOP/s against 900-1100 on the large
-        levels - and in the UNet++ / UNet decoders they are independent of most full-resolution nodes: X01, X11, X02 ... only
-        need the encoder.  Ops whose output image has at most 1/64 of the input's pixels run on a second stream, ordered
-        against the main stream by one event per cross-stream tensor dependency (computed here from reads() / writes())."""
-        g = self.graph
-        H0, W0, _ = g.nodes[g.inputs[0]].shape
-        limit = (H0 * W0) // 64
-        self.fstream = [0] * len(self.ops)
-        if FWD_TWO_STREAMS and not _DryRun.on and limit >= 64:
-            for i, op in enumerate(self.ops):
-                w = op.writes()
-                if w and not isinstance(op, InputOp) and w[0].H * w[0].W <= limit:
-                    self.fstream[i] = 1
-        producer = {}
-        self.fwait: List[List[int]] = [[] for _ in self.ops]      # producers on the other stream this op has to wait for
-        self.frecord = [False] * len(self.ops)
-        for i, op in enumerate(self.ops):
-            for t in op.reads():
-                j = producer.get(id(t))
-                if j is not None and self.fstream[j] != self.fstream[i] and j not in self.fwait[i]:
-                    self.fwait[i].append(j)
-                    self.frecord[j] = True
-            for t in op.writes():
-                producer[id(t)] = i
-        self._fev: Dict[int, object] = {}
-        self.aux_stream = None
 
     def _build_transpose_table(self):
         """Device table of every derived (transposed) weight operand: refreshed by ONE launch after each optimiser step."""
@@ -1898,41 +1731,13 @@ class SegModel:
         self._enter()
         ev, k = self._param_events, 0          # optimiser slices still being updated on the side stream (forward order)
         main = None if _DryRun.on else torch.cuda.current_stream()
-        two = (not _DryRun.on) and any(self.fstream) and self.side_stream is not None
-        if two:
-            if self.aux_stream is None:
-                self.aux_stream = torch.cuda.Stream()
-            self.aux_stream.wait_stream(main)          # everything before this forward pass (previous step, the packed input)
         for i, op in enumerate(self.ops):
-            while k < len(ev) and ev[k][0] <= i:
+            while k < len(ev) and ev[k][0] <= i:       # the optimiser slice that holds this op's parameters has been updated
                 main.wait_event(ev[k][1])
-                if two:
-                    self.aux_stream.wait_event(ev[k][1])
                 k += 1
-            if two and self.fstream[i]:
-                for j in self.fwait[i]:
-                    self.aux_stream.wait_event(self._fev[j])
-                with torch.cuda.stream(self.aux_stream):
-                    op.forward(training)
-                    if self.frecord[i]:
-                        e = self._fev.get(i)
-                        if e is None:
-                            e = self._fev[i] = torch.cuda.Event()
-                        e.record(self.aux_stream)
-            else:
-                if two:
-                    for j in self.fwait[i]:
-                        main.wait_event(self._fev[j])
-                op.forward(training)
-                if two and self.frecord[i]:
-                    e = self._fev.get(i)
-                    if e is None:
-                        e = self._fev[i] = torch.cuda.Event()
-                    e.record(main)
+            op.forward(training)
         for _first, e in ev[k:]:
             main.wait_event(e)
-        if two:
-            main.wait_stream(self.aux_stream)
         self._param_events = []
         outs = [h.y for h in self.out_heads]
         return [o.squeeze(1) for o in outs] if self.graph.ndim == 1 else outs

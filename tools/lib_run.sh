@@ -1,10 +1,7 @@
 #!/bin/bash
 # run a command against alternative builds of libseg_hip.so: bash tools/lib_run.sh "<command>" lib1.so lib2.so ...
-P=tf-1d-2d-segmentation-end2endpipelines_amd
-cp $P/libseg_hip.so /tmp/cur.so
+# (the build is selected through SEG_LIB, read by _ffi.py; the in-tree file is never touched)
 CMD=$1; shift
 for lib in "$@"; do
-  cp $lib $P/libseg_hip.so
-  echo "== $lib"; eval "$CMD"
+  echo "== $lib"; SEG_LIB=$(realpath $lib) bash -c "$CMD"
 done
-cp /tmp/cur.so $P/libseg_hip.so

@@ -1,10 +1,7 @@
 #!/bin/bash
 # run a pytest selection against alternative builds of libseg_hip.so (bisecting): bash tools/lib_test.sh "<pytest args>" lib1.so lib2.so ...
-P=tf-1d-2d-segmentation-end2endpipelines_amd
-cp $P/libseg_hip.so /tmp/cur.so
+# (the build is selected through SEG_LIB, read by _ffi.py; the in-tree file is never touched)
 ARGS=$1; shift
 for lib in "$@"; do
-  cp $lib $P/libseg_hip.so
-  echo "== $lib: $(timeout 900 python -m pytest $ARGS 2>&1 | tail -1)"
+  echo "== $lib: $(SEG_LIB=$(realpath $lib) timeout 900 python -m pytest $ARGS 2>&1 | tail -1)"
 done
-cp /tmp/cur.so $P/libseg_hip.so
