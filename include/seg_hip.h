@@ -62,9 +62,12 @@ typedef struct seg_geom {
 
 /* ---- implicit-GEMM forward: Conv1D/2D (unet_variants.py:9), Conv1D/2DTranspose (:19), the ConvLSTM input conv
  * (:148) and - with transposed weights - every data gradient of those layers.
- *   out[pix][n] (+)= act( sum_{seg,tap,c} in_seg[pix+tap][c] * w[n][tap_w][woff_seg + c] + bias[n] )
+ *   out[pix][n] (+)= act( ep_scale[n] * sum_{seg,tap,c} in_seg[pix+tap][c] * w[n][tap_w][woff_seg + c] + bias[n] )
  * MFMA v_mfma_f32_32x32x16_f16, fp32 accumulate.  Optional per-channel partial sums of the pre-activation
- * value (sum, sum of squares) for training-mode BatchNormalization (:11).                                       */
+ * value (sum, sum of squares) for training-mode BatchNormalization (:11).  ep_scale (NULL = 1) is the folded
+ * inference-mode BatchNormalization: with ep_scale = gamma / sqrt(var + eps) and bias = beta + (b - mean) * ep_scale
+ * (seg_bn_fold_inference) one launch is the whole Conv_Block of unet_variants.py:7-14 as model.predict runs it
+ * (2DCNN/Test.py:153,161).                                                                                      */
 typedef struct seg_igemm_fwd_args {
   seg_geom g;
   int32_t nseg;
@@ -104,6 +107,7 @@ typedef struct seg_igemm_fwd_args {
   int32_t variant;               /* 0: per-tap kernels (any geometry); 3: halo-tile kernel - fp16, 3x3 taps with
                                     offsets in {-1,0,1}^2, stride 1, 'same'; a block owns a 256-pixel patch, so
                                     tile_m must be 256 (tile_n 64 | 128) and seg_fwd_halo_patch(&g) != 0          */
+  const float* ep_scale;         /* NULL, or [n_rows] per-channel factor applied to the contraction before bias (folded BN) */
 } seg_igemm_fwd_args;
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
 /* patch width (32: 8x32 pixels, 16: 16x16 pixels) the variant-3 kernel uses for this geometry; 0: not eligible   */
@@ -164,6 +168,11 @@ int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, int64_t count
                     const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
                     int32_t unbiased_moving, int32_t training, float* mean, float* invstd, float* scale,
                     float* shift, seg_stream_t stream);
+/* inference-mode BatchNormalization folded into the conv in front of it: scale[c] = gamma / sqrt(moving_var + eps),
+ * shift[c] = beta + (conv_bias[c] - moving_mean[c]) * scale[c]  (conv_bias may be NULL) - the ep_scale / bias operands of
+ * seg_igemm_fwd for a one-launch Conv_Block                                                                     */
+int seg_bn_fold_inference(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                          const float* conv_bias, int32_t C, float* scale, float* shift, seg_stream_t stream);
 /* y = act(x*scale + shift) (channels >= c_valid -> 0); optional fused MaxPooling2D(ph,pw) second output
  * (unet_variants.py:790).                                                                                     */
 int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff,

@@ -91,3 +91,28 @@ def test_masks_bit_exact_fp32_mode(name):
     got = torch.from_numpy(p if len(model.output_names) == 1 else p[0])
     assert float((got - ref).abs().max()) < 1e-4
     assert torch.equal(masks(got), masks(ref))               # bit-exact masks
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("unetpp_ds_mse", "f32", 5e-6), ("unet_w64_bce", "f32", 5e-6), ("unetpp_ds_mse", "f16", 3e-3)])
+def test_fused_inference_equals_the_three_pass_form(name, dtype, tol, monkeypatch):
+    """model.predict runs conv -> BatchNormalization(moving statistics) -> ReLU as ONE launch (the affine folded into the GEMM
+    epilogue, SegModel ConvOp.fwd_args_infer); SEG_FUSE_INFERENCE_BN=0 keeps the conv / bn_finalize / bn_act_apply passes.  Same
+    weights, same input: the two agree to rounding (the fused form skips the storage rounding of the pre-BN tensor)."""
+    M = U.M
+    torch.manual_seed(3)
+    model, x, targets, loss = CASES[name]()
+    model.build(x.shape[0], dtype=dtype)
+    for _ in range(2):
+        model.train_step(x, targets, loss)                 # moving statistics away from their initial values
+    assert any(getattr(op, "fwd_args_infer", None) is not None for op in model.ops)
+    fused = model.predict(x)
+    w = model.get_weights()
+    monkeypatch.setattr(M, "FUSE_INFERENCE_BN", False)
+    m2, _x, _t, _l = CASES[name]()
+    m2.build(x.shape[0], dtype=dtype)
+    m2.set_weights(w)
+    assert all(getattr(op, "fwd_args_infer", None) is None for op in m2.ops)
+    plain = m2.predict(x)
+    fused, plain = (fused if isinstance(fused, list) else [fused]), (plain if isinstance(plain, list) else [plain])
+    for a, b in zip(fused, plain):
+        assert float(np.abs(a - b).max()) < tol * max(1.0, float(np.abs(b).max()))

@@ -48,6 +48,31 @@ def test_unetpp_fusion_counts():
     assert c["seg_igemm_fwd"] == 2 * (convs + nodes) - 1
 
 
+def test_predict_is_one_launch_per_conv_block():
+    """Inference (model.predict, 2DCNN/Test.py:153,161): BatchNormalization with the moving statistics is folded into the conv's
+    epilogue (seg_bn_fold_inference once per weight change -> ep_scale / bias of seg_igemm_fwd), ReLU applied there: one launch per
+    Conv_Block (unet_variants.py:7-14) plus the 2x2 pooling of the encoder levels - no pre-BN tensor pass, no normalisation pass."""
+    d = 3
+    for dtype in ("f16", "f32"):
+        m = B("UNetPP", 32, 32, 16, d, ds=1).build(2, dtype=dtype)
+        x = torch.rand(2, 32, 32, 3)
+        M._DryRun.log.clear()
+        m.forward(x, training=False)
+        c = Counter(n.replace("_f32", "") for n in M._DryRun.log)
+        nodes = d * (d + 1) // 2
+        convs = (d + 1) + 2 + nodes
+        assert c["seg_bn_act_apply"] == 0 and c["seg_bn_finalize"] == 0 and c["seg_bn_stats"] == 0
+        assert c["seg_igemm_fwd"] == convs + nodes and c["seg_bn_fold_inference"] == convs and c["seg_maxpool_fwd"] == d
+        M._DryRun.log.clear()
+        m.forward(x, training=False)                  # the folded coefficients are cached until the weights change
+        c = Counter(n.replace("_f32", "") for n in M._DryRun.log)
+        assert c["seg_bn_fold_inference"] == 0 and c["seg_igemm_fwd"] == convs + nodes
+        step(m, x)
+        M._DryRun.log.clear()
+        m.forward(x, training=False)
+        assert Counter(M._DryRun.log)["seg_bn_fold_inference"] == convs
+
+
 def test_accumulate_flags_follow_consumer_count():
     m = B("UNetPP", 32, 32, 16, 2, ds=0).build(2)
     step(m, torch.rand(2, 32, 32, 3))

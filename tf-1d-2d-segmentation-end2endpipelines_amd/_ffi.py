@@ -46,7 +46,7 @@ class IgemmFwdArgs(C.Structure):
                 ("alpha", C.c_float), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("tile_m", C.c_int32),
                 ("tile_n", C.c_int32), ("nout", C.c_int32), ("out_span", C.c_int32 * MAX_SEG), ("out_cs_o", C.c_int32 * MAX_SEG),
                 ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG), ("out_y", C.c_void_p * MAX_SEG),
-                ("out_dact", C.c_int32 * MAX_SEG), ("out_dalpha", C.c_float * MAX_SEG), ("variant", C.c_int32)]
+                ("out_dact", C.c_int32 * MAX_SEG), ("out_dalpha", C.c_float * MAX_SEG), ("variant", C.c_int32), ("ep_scale", C.c_void_p)]
 
 
 class IgemmWgradArgs(C.Structure):
@@ -76,6 +76,7 @@ _PROTOS = {
     "seg_fwd_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),
+    "seg_bn_fold_inference": ([vp, vp, vp, vp, f32, vp, i32, vp, vp, vp], C.c_int),
     "seg_bn_act_apply": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, vp], C.c_int),
     "seg_bn_act_bwd_reduce": ([vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, f32, vp, i32, vp], C.c_int),
     "seg_bn_bwd_finalize": ([vp, i32, i32, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),

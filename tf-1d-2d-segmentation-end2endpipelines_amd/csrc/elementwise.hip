@@ -181,6 +181,15 @@ __global__ __launch_bounds__(TPB) void bn_finalize_kernel(const float* stats, in
   shift_o[c] = beta[c] - mean * sc;
 }
 
+__global__ __launch_bounds__(TPB) void bn_fold_inference_kernel(const float* gamma, const float* beta, const float* mmean, const float* mvar,
+                                                                float eps, const float* cbias, int C, float* scale_o, float* shift_o) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * rsqrtf(mvar[c] + eps);
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] + ((cbias != nullptr ? cbias[c] : 0.f) - mmean[c]) * sc;
+}
+
 // ------------------------------------------------------------------------------------------------ BN apply (+pool)
 // Streaming kernels below process UNR items per thread and iteration with every load issued before the first
 // store (the output may alias an input element-for-element, so the compiler cannot hoist loads across stores on
@@ -1522,6 +1531,15 @@ extern "C" int seg_bn_finalize(const float* stats, int32_t nparts, int32_t C, in
                      training ? (float)(1.0 / (double)count) : 0.f, unbias, gamma, beta, eps, momentum, moving_mean, moving_var, training,
                      mean, invstd, scale, shift);
   SEG_CHECK_LAUNCH("seg_bn_finalize");
+  return SEG_OK;
+}
+
+extern "C" int seg_bn_fold_inference(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                                     const float* conv_bias, int32_t C, float* scale, float* shift, seg_stream_t stream) {
+  SEG_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0, "seg_bn_fold_inference: bad arguments");
+  hipLaunchKernelGGL(bn_fold_inference_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, ST(stream), gamma, beta, moving_mean, moving_var, eps,
+                     conv_bias, C, scale, shift);
+  SEG_CHECK_LAUNCH("seg_bn_fold_inference");
   return SEG_OK;
 }
 

@@ -200,13 +200,14 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
   T* out = (T*)p.out;
   const bool do_stats = p.stats != nullptr;
   const float act_slope = p.act == SEG_ACT_LEAKY ? p.alpha : 0.f;      // ReLU / LeakyReLU: v > 0 ? v : v * slope
-  float s_sum[TN], s_sq[TN], bvs[TN];
+  float s_sum[TN], s_sq[TN], bvs[TN], svs[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {                // (the bias loads go out first: their latency passes behind the set-up below
     s_sum[b] = 0.f;                             // instead of being waited out in front of every tile)
     s_sq[b] = 0.f;
     const int ncol = n0 + col0 + b * 32 + fr;
     bvs[b] = (bias != nullptr && ncol < p.n_rows) ? bias[ncol] : 0.f;
+    svs[b] = (p.ep_scale != nullptr && ncol < p.n_rows) ? p.ep_scale[ncol] : 1.f;      // folded inference-mode BatchNormalization
   }
   // rows this lane stores: (lane >> 2) + 16 * pass within each 32-row tile, 8 channels (lane & 3) * 8 ..
   const int st_row = lane >> 2, st_ch = lane & 3;
@@ -294,13 +295,13 @@ __device__ __forceinline__ void conv_epilogue(const seg_igemm_fwd_args& p, f16v 
     for (int b = 0; b < TN; ++b) {
       const int nbase = n0 + col0 + b * 32;
       const int ncol = nbase + fr;
-      const float bv = bvs[b];
+      const float bv = bvs[b], sv = svs[b];
       const bool nzero = ncol >= p.n_valid;
       // (block-uniform choices - statistics, kind of activation - are taken once per tile, not once per element: the
       // element loop used to carry ~14 scalar branches, a third of the run time of the short-K layers' blocks)
       float vv[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) vv[q] = acc[a][b][q] + bv;
+      for (int q = 0; q < 16; ++q) vv[q] = acc[a][b][q] * sv + bv;
       if (do_stats) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {

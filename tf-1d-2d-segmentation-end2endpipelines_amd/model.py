@@ -323,6 +323,7 @@ def fwd_halo_patch(g: Geom) -> int:
 
 
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
+FUSE_INFERENCE_BN = os.environ.get("SEG_FUSE_INFERENCE_BN", "1") != "0"     # predict: conv -> BN(moving statistics) -> activation as ONE launch
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
@@ -666,6 +667,19 @@ class ConvOp(Op):
         self.fwd_args = a
         self.fwd_args_eval = IgemmFwdArgs.from_buffer_copy(a)
         self.fwd_args_eval.stats = None
+        # inference (model.predict, 2DCNN/Test.py:153,161): BatchNormalization with the moving statistics is a per-channel affine
+        # known before the conv runs - folded into the GEMM epilogue (ep_scale / bias), activation applied there, the result written
+        # straight to `out`: ONE launch per Conv_Block (unet_variants.py:7-14), no pre-BN tensor, no normalisation pass
+        self.fwd_args_infer = None
+        self._infer_valid = False
+        if self.has_bn and FUSE_INFERENCE_BN:
+            self.inf_scale = torch.zeros(self.n_rows, dtype=torch.float32, device=_dev())
+            self.inf_shift = torch.zeros(self.n_rows, dtype=torch.float32, device=_dev())
+            b = IgemmFwdArgs.from_buffer_copy(self.fwd_args_eval)
+            b.out, b.out_cs, b.out_coff = self.out.buf.data_ptr(), self.out.cs, 0
+            b.bias, b.ep_scale = self.inf_shift.data_ptr(), self.inf_scale.data_ptr()
+            b.act, b.alpha = ACT[self.act], float(self.alpha)
+            self.fwd_args_infer = b
         # wgrad
         wg = IgemmWgradArgs()
         wg.g = self.g_fwd
@@ -711,9 +725,26 @@ class ConvOp(Op):
         return [(self.m.store.ptr(self.wname, self.m.src_buf).value, self.wt.data_ptr(), self.n_rows, self.T, self.Kpad, 0, self.Kpad,
                  self.rows_pad, self.rows_pad, 0)]
 
+    def post_step(self):
+        self._infer_valid = False          # the folded inference-mode BN coefficients follow the weights
+
     def forward(self, training):
         st, s = self.m.store, _stream()
+        if not training and self.fwd_args_infer is not None:
+            bn = self.bn_name
+            if not self._infer_valid:
+                call("seg_bn_fold_inference", st.ptr(bn + "/gamma"), st.ptr(bn + "/beta"), st.ptr(bn + "/moving_mean"),
+                     st.ptr(bn + "/moving_variance"), self.eps, st.ptr(self.bname, "P") if self.bname else None, self.n_rows,
+                     _p(self.inf_scale), _p(self.inf_shift), s)
+                self._infer_valid = True
+            call("seg_igemm_fwd", C.byref(self.fwd_args_infer), s, flops=self.flops_fwd, tag="fwd:" + self.node.name)
+            if self.pooled is not None:
+                call("seg_maxpool_fwd", _p(self.out.buf), _p(self.pooled.buf), self.out.N, self.out.H, self.out.W, self.out.cs,
+                     self.pool_size[0], self.pool_size[1], s)
+            return
         a = self.fwd_args if (training and self.has_bn) else self.fwd_args_eval
+        if training and self.has_bn:
+            self._infer_valid = False      # (this pass updates the moving statistics)
         call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, tag="fwd:" + self.node.name)
         if self.has_bn:
             bn = self.bn_name
