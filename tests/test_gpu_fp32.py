@@ -116,3 +116,26 @@ def test_fused_inference_equals_the_three_pass_form(name, dtype, tol, monkeypatc
     fused, plain = (fused if isinstance(fused, list) else [fused]), (plain if isinstance(plain, list) else [plain])
     for a, b in zip(fused, plain):
         assert float(np.abs(a - b).max()) < tol * max(1.0, float(np.abs(b).max()))
+
+
+def test_range_of_the_split_pair_format_is_loud_not_silent():
+    """The parity mode's storage (csrc/seg_common.h, split_t): ~22 significant bits inside fp16's range, an absolute error floor
+    of ~2^-36 below 2^-14, and NO silent garbage above 65504 - a value that does not fit becomes Inf / NaN in the output (and a
+    non-finite gradient is skipped and counted by the optimiser kernels).  Large-but-representable and tiny operands, measured:"""
+    kern = rng.standard_normal((3, 3, 32, 64)).astype(np.float32)
+    # (a) operands of magnitude 3e4 (representable), weights 1e-4: results ~1e1 .. 1e2, full precision
+    x = torch.randn(2, 16, 32, 32) * 1e4
+    out, _, _ = U.igemm_conv([x], kern * 1e-4, None, "conv", (1, 1), None, 0.0, False, (256, 64), f32=True, variant=3)
+    ref = K.conv2d_same(x, torch.from_numpy(kern * 1e-4), None)
+    assert bool(torch.isfinite(out).all()) and rel(out, ref) < 1e-5
+    # (b) an input element beyond fp16's range: it becomes Inf in the stored operand, every output it touches is non-finite
+    x2 = x.clone()
+    x2[0, 8, 16, 3] = 1.0e5
+    out2, _, _ = U.igemm_conv([x2], kern * 1e-4, None, "conv", (1, 1), None, 0.0, False, (256, 64), f32=True, variant=3)
+    bad = ~torch.isfinite(out2)
+    assert bool(bad[0, 7:10, 15:18].all()) and int(bad.sum()) == 9 * 64
+    # (c) tiny operands (1e-6): below 2^-14 the pair keeps an absolute error of ~2^-36 per element, i.e. ~1e-5 relative here
+    x3 = torch.randn(2, 16, 32, 32) * 1e-6
+    out3, _, _ = U.igemm_conv([x3], kern, None, "conv", (1, 1), None, 0.0, False, (256, 64), f32=True, variant=3)
+    ref3 = K.conv2d_same(x3, torch.from_numpy(kern), None)
+    assert rel(out3, ref3) < 2e-4

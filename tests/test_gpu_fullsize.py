@@ -205,13 +205,19 @@ def test_load_keras_model_walks_the_layer_graph_into_the_engine():
     m = B("UNetPP", 32, 32, 8, 2, num_channels=3, ds=1)
     m.build(2, dtype="f32")
     fake = FakeKerasModel(m.graph, np.random.default_rng(4))
-    for k, v in fake.planted.items():                     # keep BatchNormalization's moving variance positive
-        if k.endswith("moving_variance"):
-            fake.planted[k] = np.abs(v) + 0.5
+    # the fake's weights are N(0, 1) draws: make them a network whose activations stay in range (kernels x 0.05, positive
+    # moving variances) - in the planted dictionary and in the layers alike
+    def tame(k, v):
+        return np.abs(v) + 0.5 if k.endswith("moving_variance") else (v * 0.05 if k.endswith("kernel") else v)
+    fake.planted = {k: tame(k, v).astype(np.float32) for k, v in fake.planted.items()}
     for layer in fake.layers:
         ws = layer.get_weights()
-        if type(layer).__name__ == "BatchNormalization":
-            ws[3] = np.abs(ws[3]) + 0.5
+        cls = type(layer).__name__
+        if cls == "BatchNormalization":
+            ws[3] = (np.abs(ws[3]) + 0.5).astype(np.float32)
+        elif ws:
+            ws[0] = (ws[0] * 0.05).astype(np.float32)
+        if ws:
             layer.set_weights(ws)
     m.load_keras_model(fake)
     got = m.get_weights()
