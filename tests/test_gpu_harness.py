@@ -281,3 +281,26 @@ def test_categorical_metrics_and_multi_output_prefixes():
     per = [float(((pp - t2.numpy()) ** 2).mean()) for pp in m2.predict(x2)]
     assert [logs2[f"{o}_mean_squared_error"] for o in m2.output_names] == pytest.approx(per, rel=1e-5)
     assert logs2["loss"] == pytest.approx(sum(w * v for w, v in zip([1.0, 0.9, 0.8, 0.7], per)), rel=1e-5)
+
+
+def test_nonfinite_counter_is_read_one_step_late_without_joining_the_side_stream():
+    """harness.fit reads the optimiser's skipped-update counter through SegModel.nonfinite_updates_async(): the value of the
+    PREVIOUS step from pinned memory, the device counter reset behind the copy - and a backed-off loss scale grows back."""
+    m = segamd.unet_model_builder("UNetPP", 32, 32, 8, 2, num_channels=3, ds=1, train_mode="from_scratch").ResNet50()
+    m.build(2)
+    m.compile(loss="mse", lr=1e-3)
+    x = torch.rand(2, 32, 32, 3)
+    t = [torch.rand(2, 32, 32, 1)] * len(m.out_heads)
+    m.train_step(x, t)
+    assert m.nonfinite_updates_async() == 0
+    m.store.nonfinite.fill_(7)                      # as if the optimiser had skipped 7 elements in this step
+    assert m.nonfinite_updates_async() == 0         # ... reported one call later
+    assert m.nonfinite_updates_async() == 7 and m.nonfinite_updates() == 0
+    # fit(): back-off on a skipped step, growth after a run of clean ones
+    H.LOSS_SCALE_GROWTH_INTERVAL, keep = 3, H.LOSS_SCALE_GROWTH_INTERVAL
+    try:
+        m.grad_target = 256.0
+        H.fit(m, [(x, t)] * 8, epochs=1)
+        assert m.grad_target > 256.0
+    finally:
+        H.LOSS_SCALE_GROWTH_INTERVAL = keep

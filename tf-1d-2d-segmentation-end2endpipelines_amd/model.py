@@ -1732,6 +1732,28 @@ class SegModel:
             self.store.nonfinite.zero_()
         return n
 
+    def nonfinite_updates_async(self) -> int:
+        """The same counter without stalling the training loop: returns what the PREVIOUS call collected (one step late, 0 the
+        first time) and queues, behind the optimiser slices of the step just issued, a copy of the counter into pinned host memory
+        followed by its reset.  Nothing joins the side stream, so the optimiser keeps running under the next forward pass."""
+        if _DryRun.on:
+            return 0
+        prev = 0
+        pend = getattr(self, "_nf_pending", None)
+        if pend is not None:
+            pend[0].synchronize()                  # (queued a whole step ago: long finished)
+            prev = int(pend[1][0])
+        if getattr(self, "_nf_host", None) is None:
+            self._nf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        stream = self.side_stream if self.side_stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            self._nf_host.copy_(self.store.nonfinite, non_blocking=True)
+            self.store.nonfinite.zero_()
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._nf_pending = (ev, self._nf_host)
+        return prev
+
     def _refresh_copies(self):
         st = self.store
         self._enter()
