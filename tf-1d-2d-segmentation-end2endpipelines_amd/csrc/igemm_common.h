@@ -121,6 +121,24 @@ __device__ __forceinline__ void lds_dma16(i4v rsrc, unsigned lds_addr, unsigned 
 #endif
 }
 
+// ---- the ONLY two places of this code base that execute s_barrier in a ring kernel.
+// ring_release_barrier: a barrier after which other waves may refill the LDS ring slot this wave has just read.  gfx950 puts no
+// implicit wait in front of s_barrier and hipcc is free to leave the last MFMAs of a step - with the wait for their fragment reads -
+// behind it, so the wave's own LDS reads must have RETURNED (s_waitcnt lgkmcnt(0)), not just been issued: with the LDS backed up
+// by a co-resident kernel a queued read otherwise returns the next step's bytes (one 32 x 32 tile a K step off in 1-10 % of the
+// C3 training steps until the end of round 2).  The waits for the wave's LDS-DMA (counted vmcnt) stay with
+// the caller, in front of this call.  with_barrier = false: timing experiments only (tools/op_bench.py --dbg).
+__device__ __forceinline__ void ring_release_barrier(bool with_barrier = true) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (with_barrier) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// loader_barrier: the same rendezvous for pure loader waves of the wave-specialised kernels, which read nothing from LDS
+__device__ __forceinline__ void loader_barrier(bool with_barrier = true) {
+  if (with_barrier) __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int xcd_remap(int b, int n) {
   const int q = n >> 3, r = n & 7, x = b & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);

@@ -339,14 +339,8 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
       if (DIST == 2 && it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // the stage the loads issued below go into is the one this wave read LAST step (two-stage and three-stage ring alike:
-      // the prefetch distance is the ring depth minus one).  The compiler may
-      // leave the final MFMAs of that step - and the wait for their fragment reads - behind this barrier (gfx950 puts no
-      // implicit wait in front of s_barrier), so the reads must have RETURNED, not just been issued, before any wave may
-      // start overwriting the stage: with the LDS backed up by a co-resident kernel a queued read otherwise returns the next
-      // step's bytes (one 32 x 32 tile a K step off in 1-10 % of the training steps, tools/repro_probe.py)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      // the prefetch distance is the ring depth minus one)
+      ring_release_barrier();
       int st2 = stage + DIST;
       if (st2 >= NSTAGE) st2 -= NSTAGE;
       issue(std::integral_constant<int, t2>{}, D[k2], st2);

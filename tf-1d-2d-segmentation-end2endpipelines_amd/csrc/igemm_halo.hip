@@ -263,9 +263,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the fragment reads of the step before must have RETURNED before any wave may overwrite their ring slot: igemm_fwd.hip, two-stage ring)
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      ring_release_barrier();
       if (s + 2 < nsteps) {
         int s2 = slot + 2;
         if (s2 >= 3) s2 -= 3;

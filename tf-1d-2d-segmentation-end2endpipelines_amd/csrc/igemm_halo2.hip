@@ -260,9 +260,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (fragment reads of the step before must have RETURNED before their ring slot is refilled: igemm_fwd.hip, two-stage ring)
-        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        ring_release_barrier(!(dbg & 4));
         if (s + (NSLOT - 1) < nsteps) {
           int s2 = slot + (NSLOT - 1);
           if (s2 >= NSLOT) s2 -= NSLOT;

@@ -583,9 +583,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_kernel(const seg_igem
   int stage = 0;
   issue(q0, 0);
   for (int q = q0; q < q1; ++q) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the fragment reads of the step before must have RETURNED before any wave may overwrite their ring slot: igemm_fwd.hip, two-stage ring)
-    if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_release_barrier(!(dbg & 4));
     if (q + 1 < q1) issue(q + 1, stage ^ 1);
     compute(stage);
     stage ^= 1;
@@ -779,9 +778,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_tc2_kernel(const seg_
     int stage = 0;
     issue(0);
     for (int q = q0; q < q1; ++q) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the fragment reads of the step before must have RETURNED before any wave may overwrite their ring slot: igemm_fwd.hip, two-stage ring)
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ring_release_barrier();
       if (q + 1 < q1) issue(stage ^ 1);
       compute(pyc, stage);
       stage ^= 1;

@@ -206,8 +206,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_halo_ws_kernel(const seg_i
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();          // loader waves: no LDS reads of their own
-      asm volatile("" ::: "memory");
+      loader_barrier(!(dbg & 4));
       if (q + NSTAGE - 1 < q1) issue(q + NSTAGE - 1, slot_next);
       slot_next = slot_next == NSTAGE - 1 ? 0 : slot_next + 1;
     }
@@ -218,9 +217,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wgrad_halo_ws_kernel(const seg_i
     for (int q = q0; q < q1; ++q) {
       // the loaders refill the slot of patch q - 1 right behind this barrier: its transposing reads must have returned
       // (not just been issued) - see the two-stage ring of igemm_fwd.hip
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      ring_release_barrier(!(dbg & 4));
       compute(stage);
       stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }

@@ -165,9 +165,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_ts_kernel(const seg_i
     int stage = 0;
     issue(0);
     for (int q = q0; q < q1; ++q) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the fragment reads of the step before must have RETURNED before any wave may overwrite their ring slot: igemm_fwd.hip, two-stage ring)
-      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ring_release_barrier(!(dbg & 4));
       if (q + 1 < q1) issue(stage ^ 1);
       compute(tgc, stage);
       stage ^= 1;

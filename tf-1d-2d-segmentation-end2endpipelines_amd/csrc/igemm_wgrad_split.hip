@@ -387,11 +387,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
     int stage = 0;
     issue(0);
     for (int q = q0; q < q1; ++q) {
-      // the loads of this patch have landed; the fragment reads of the patch before have RETURNED before any wave may
-      // overwrite their ring slot (gfx950 puts no implicit wait in front of s_barrier)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the loads of this patch have landed
+      ring_release_barrier();
       if (q + 1 < q1) issue(stage ^ 1);
       if constexpr (TC) compute_tc(stage);
       else compute_conv(thc, stage);
