@@ -218,6 +218,18 @@ int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, 
 int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha,
                     seg_stream_t stream);
 /* dx_i (+)= dy * act'(y) for every i with dxs[i] != NULL; accumulate is a bit mask over i                      */
+/* The tail of a MultiResBlock / ResPath, BatchNormalization(ReLU(a + b)) (unet_variants.py:97-99, :118-120), as two fused passes:
+ * forward  y = act(sum_k (x_k * scales[k] + shifts[k])) plus per-channel partial sums of y and y^2 (stats[nparts][2][cs], the
+ *          operand of seg_bn_finalize for the BatchNormalization that follows).  scales / shifts: NULL, or per input NULL (identity)
+ *          or [cs] floats - an input that is itself a BatchNormalization output is normalised on the fly from its pre-BN tensor
+ *          (MultiResBlock: BN(cat[c3,c5,c7]) is never written out).  Tensors are dense [npix][cs].
+ * backward dx_k (+)= [x > 0] * scale * (dy - c1 - xhat * c2) for every input k of the add (x = the BatchNormalization's input = the
+ *          ReLU's output; relu_mask = 0 without the ReLU): replaces seg_bn_act_bwd_apply + seg_add_act_bwd.                        */
+int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y,
+                          int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
+int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
+                            int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
+                            int32_t relu_mask, seg_stream_t stream);
 int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
                     float alpha, int32_t accumulate_mask, seg_stream_t stream);
 
@@ -412,6 +424,11 @@ int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem
                         seg_stream_t stream);
 int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
                         float alpha, int32_t accumulate_mask, seg_stream_t stream);
+int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y,
+                              int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
+int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
+                                int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
+                                int32_t relu_mask, seg_stream_t stream);
 int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs,
                           seg_stream_t stream);
 int seg_mul_bcast_bwd_f32(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs,

@@ -209,7 +209,7 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, or
     res = {"nodes": [], "loss": (float(lv.cpu()), float(ref_loss.detach())), "grads": {}, "outs": [], "agrads": [], "S": S}
     for name, t in model.tensors.items():
         key = name[:-2] if name.endswith(":z") else name
-        if key not in vals:
+        if key not in vals or not getattr(t, "materialised", True):
             continue
         ref = vals[key].detach()
         got = t.values().cpu()

@@ -73,6 +73,28 @@ def test_predict_is_one_launch_per_conv_block():
         assert Counter(M._DryRun.log)["seg_bn_fold_inference"] == convs
 
 
+def test_multires_tails_are_fused_passes(monkeypatch):
+    """BN(ReLU(a + b)) - the tail of a MultiResBlock and of every ResPath iteration (unet_variants.py:97-99, :118-120): the add
+    kernel applies the ReLU, normalises a BatchNormalization input on the fly (BN(cat) is never written) and delivers the statistics
+    of the BN that follows; that BN's backward writes the masked gradient to the add's inputs.  Against the unfused lowering: no
+    seg_add_act_fwd / seg_add_act_bwd, one seg_bn_stats and one seg_bn_act_apply fewer per fused BN / folded BN."""
+    def counts():
+        m = B("MultiResUNet", 32, 32, 16, 2, alpha=1.0).build(2)
+        c = step(m, torch.rand(2, 32, 32, 3))
+        tails = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.fused_add is not None)
+        folded = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.folded_into is not None)
+        return c, tails, folded
+    c1, tails, folded = counts()
+    assert tails > 0 and folded > 0 and c1["seg_add_act_stats_fwd"] == tails and c1["seg_bn_bwd_apply_fanout"] == tails
+    monkeypatch.setattr(M, "FUSE_BN_TAILS", False)
+    c0, t0, f0 = counts()
+    assert t0 == 0 and f0 == 0 and c0["seg_add_act_stats_fwd"] == 0
+    assert c0["seg_add_act_fwd"] - c1["seg_add_act_fwd"] == tails and c0["seg_add_act_bwd"] - c1["seg_add_act_bwd"] == tails
+    assert c0["seg_bn_stats"] - c1["seg_bn_stats"] == tails                    # statistics from the add kernel
+    assert c0["seg_bn_act_apply"] - c1["seg_bn_act_apply"] == folded           # BN(cat) applied inside the add
+    assert c0["seg_bn_act_bwd_apply"] - c1["seg_bn_act_bwd_apply"] == tails    # replaced by the fan-out form
+
+
 def test_accumulate_flags_follow_consumer_count():
     m = B("UNetPP", 32, 32, 16, 2, ds=0).build(2)
     step(m, torch.rand(2, 32, 32, 3))

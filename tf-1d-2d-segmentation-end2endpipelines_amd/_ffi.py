@@ -87,6 +87,8 @@ _PROTOS = {
     "seg_upsample_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_upsample_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_add_act_fwd": ([C.POINTER(vp), i32, vp, i64, i32, f32, vp], C.c_int),
+    "seg_add_act_stats_fwd": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, i64, i32, i32, f32, vp, i32, vp], C.c_int),
+    "seg_bn_bwd_apply_fanout": ([vp, vp, C.POINTER(vp), i32, i32, i64, i32, vp, vp, vp, vp, vp, i32, vp], C.c_int),
     "seg_add_act_bwd": ([vp, vp, C.POINTER(vp), i32, i64, i32, f32, i32, vp], C.c_int),
     "seg_copy_channels": ([vp, i32, i32, vp, i32, i32, i32, i64, i32, vp], C.c_int),
     "seg_mul_bcast_fwd": ([vp, vp, vp, i64, i32, i32, vp], C.c_int),
@@ -121,7 +123,7 @@ _PROTOS = {
 # entry points that touch activation tensors exist twice: fp16 (throughput mode) and *_f32 (exact-fp32 parity mode)
 DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
-        "seg_add_act_bwd", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
+        "seg_add_act_bwd", "seg_add_act_stats_fwd", "seg_bn_bwd_apply_fanout", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
         "seg_head_fwd", "seg_head_bwd", "seg_head_act_fwd", "seg_head_act_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")
 for _n in DUAL:
     _PROTOS[_n + "_f32"] = _PROTOS[_n]

@@ -681,6 +681,125 @@ __global__ __launch_bounds__(TPB) void add_act_bwd_kernel(const T* dy, const T* 
   }
 }
 
+// y = act(sum_k (x_k * scale_k + shift_k)) with the per-channel sums of y and y^2 as per-block partial rows - the tail of a
+// MultiResBlock / ResPath, BN(ReLU(a + b)) (unet_variants.py:97-99, :118-120): the add, the ReLU and the statistics of the
+// BatchNormalization that follows are ONE pass, and an input may itself be a BatchNormalization whose normalisation is applied on
+// the fly (scale_k / shift_k != NULL: MultiResBlock's BN over cat[c3, c5, c7] is never written out).  Layout as bn_stats_kernel.
+struct Aff4 { const float* sc[4]; const float* sh[4]; };
+template <typename T>
+__global__ __launch_bounds__(TPB) void add_act_stats_kernel(Ptr4<T> xs, Aff4 aff, int n, T* y, int64_t npix, int cs, int act, float alpha,
+                                                            float* stats, int nparts, ColLayout L) {
+  __shared__ float sm[TPB * 8];
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int part = blockIdx.x;
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    float acc[2][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
+    if (ch < L.CH) {
+      float sc[4][8], sh[4][8];         // (k loops fully unrolled with a guard: a run-time index would put these in scratch)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          sc[k][t] = (k < n && aff.sc[k] != nullptr) ? aff.sc[k][ch * 8 + t] : 1.f;
+          sh[k][t] = (k < n && aff.sh[k] != nullptr) ? aff.sh[k][ch * 8 + t] : 0.f;
+        }
+      for (int64_t pix = (int64_t)part * L.RP + rowi; pix < npix; pix += (int64_t)L.RP * nparts) {   // interleaved rows
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < n) {
+            float f[8];
+            load8(xs.p[k] + pix * cs + ch * 8, f);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] += f[t] * sc[k][t] + sh[k][t];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = seg_act(o[t], act, alpha);
+        store8(y + pix * cs + ch * 8, o);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float v = stored<T>(o[t]);              // the statistics of what the BatchNormalization will read
+          acc[0][t] += v;
+          acc[1][t] += v * v;
+        }
+      }
+    }
+    block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
+    if (rowi == 0 && ch < L.CH) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        stats[((size_t)part * 2 + 0) * cs + ch * 8 + t] = acc[0][t];
+        stats[((size_t)part * 2 + 1) * cs + ch * 8 + t] = acc[1][t];
+      }
+    }
+  }
+}
+
+// backward of BN(ReLU(a + b + ..)): dx = [x > 0] * sc * (g - c1 - xhat c2) written to EVERY input of the add (the add fans the same
+// gradient out), x = the BatchNormalization's input = the ReLU's output.  Replaces bn_act_bwd_apply + add_act_bwd.
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_fanout_kernel(const T* dy, const T* x, MPtr4<T> dxs, int n, int accmask, int64_t npix, int cs,
+                                                                  const float* scale, const float* mean, const float* invstd, const float* c1,
+                                                                  const float* c2, int relu_mask, ColLayout L) {
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int64_t chunk = (int64_t)L.RP * UNR;
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    if (ch >= L.CH) continue;
+    float sc[8], ka[8], kb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = ch * 8 + t;
+      sc[t] = scale[c];
+      const float k = invstd[c] * c2[c];
+      ka[t] = -sc[t] * k;
+      kb[t] = sc[t] * (mean[c] * k - c1[c]);
+    }
+    for (int64_t pb = blockIdx.x * chunk + rowi; pb < npix; pb += chunk * gridDim.x) {
+      float g[UNR][8], xv[UNR][8];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = pb + (int64_t)u * L.RP;
+        if (pix < npix) {
+          load8(dy + pix * cs + ch * 8, g[u]);
+          load8(x + pix * cs + ch * 8, xv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = pb + (int64_t)u * L.RP;
+        if (pix >= npix) continue;
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float v = g[u][t] * sc[t] + xv[u][t] * ka[t] + kb[t];
+          o[t] = (relu_mask && !(xv[u][t] > 0.f)) ? 0.f : v;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k >= n || dxs.p[k] == nullptr) continue;
+          float w[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) w[t] = o[t];
+          if (accmask & (1 << k)) {
+            float old[8];
+            load8(dxs.p[k] + pix * cs + ch * 8, old);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) w[t] += old[t];
+          }
+          store8(dxs.p[k] + pix * cs + ch * 8, w);
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void mul_bcast_fwd_kernel(const T* a, const T* r, T* y, int64_t npix, int cs, int r_cs) {
   const int CH = cs / 8;
@@ -1702,6 +1821,44 @@ static int seg_add_act_bwd_impl(const void* dy, const void* y, void* const* dxs,
 }
 extern "C" int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<half_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
 extern "C" int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<split_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
+
+template <typename T>
+static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y,
+                                      int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) {
+  SEG_CHECK_ARG(xs && y && stats && n >= 1 && n <= 4 && npix > 0 && cs > 0 && (cs & 7) == 0 && nparts > 0, "seg_add_act_stats_fwd: bad arguments (n=%d cs=%d)", n, cs);
+  Ptr4<T> p;
+  Aff4 a;
+  for (int k = 0; k < 4; ++k) {
+    p.p[k] = k < n ? (const T*)xs[k] : nullptr;
+    a.sc[k] = (k < n && scales != nullptr) ? scales[k] : nullptr;
+    a.sh[k] = (k < n && shifts != nullptr) ? shifts[k] : nullptr;
+    SEG_CHECK_ARG(k >= n || (p.p[k] != nullptr && (a.sc[k] == nullptr) == (a.sh[k] == nullptr)), "seg_add_act_stats_fwd: input %d", k);
+  }
+  hipLaunchKernelGGL((add_act_stats_kernel<T>), dim3(nparts), dim3(TPB), 0, ST(stream), p, a, n, (T*)y, npix, cs, act, alpha, stats, nparts, col_layout(cs));
+  SEG_CHECK_LAUNCH("seg_add_act_stats_fwd");
+  return SEG_OK;
+}
+extern "C" int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y, int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<half_t>(xs, scales, shifts, n, y, npix, cs, act, alpha, stats, nparts, stream); }
+extern "C" int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y, int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<split_t>(xs, scales, shifts, n, y, npix, cs, act, alpha, stats, nparts, stream); }
+
+template <typename T>
+static int seg_bn_bwd_apply_fanout_impl(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs,
+                                        const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
+                                        int32_t relu_mask, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && x && dxs && n >= 1 && n <= 4 && npix > 0 && cs > 0 && (cs & 7) == 0 && scale && mean && invstd && c1 && c2,
+                "seg_bn_bwd_apply_fanout: bad arguments");
+  MPtr4<T> p;
+  for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (T*)dxs[k] : nullptr;
+  const ColLayout L = col_layout(cs);
+  int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL((bn_bwd_apply_fanout_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n, accumulate_mask,
+                     npix, cs, scale, mean, invstd, c1, c2, relu_mask, L);
+  SEG_CHECK_LAUNCH("seg_bn_bwd_apply_fanout");
+  return SEG_OK;
+}
+extern "C" int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<half_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, stream); }
+extern "C" int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<split_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, stream); }
 
 template <typename T>
 static int seg_mul_bcast_fwd_impl(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) {

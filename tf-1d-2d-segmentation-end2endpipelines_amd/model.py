@@ -323,6 +323,7 @@ def fwd_halo_patch(g: Geom) -> int:
 
 
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
+FUSE_BN_TAILS = os.environ.get("SEG_FUSE_BN_TAILS", "1") != "0"             # BN(ReLU(a + b)) tails of MultiResBlock / ResPath as fused passes
 FUSE_INFERENCE_BN = os.environ.get("SEG_FUSE_INFERENCE_BN", "1") != "0"     # predict: conv -> BN(moving statistics) -> activation as ONE launch
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
@@ -443,6 +444,7 @@ class DevTensor:
         self.cs = _r8(Cl)
         self.buf = torch.zeros((N, H, W, self.cs), dtype=DevTensor.dtype, device=_dev())
         self.grad: Optional[torch.Tensor] = None
+        self.materialised = True      # False: a fused consumer computes the values on the fly, `buf` is never written
         self.needs_grad = True
         self.gw = False          # "gradient written" flag used while the static backward schedule is built
         self.claimers: List[Optional[tuple]] = []      # who writes this gradient: (dgrad args, span) for conv data gradients, else None
@@ -1093,20 +1095,32 @@ class BNOp(Op):
         self.bpart = torch.zeros(BN_PARTS_BWD * 2 * self.C, dtype=torch.float32, device=dev)
         self.mean, self.invstd, self.scale, self.shift, self.c1, self.c2 = (
             torch.zeros(self.C, dtype=torch.float32, device=dev) for _ in range(6))
+        # fused tails (FUSE_BN_TAILS, see SegModel._fuse_bn_tail): `fused_add` - this BN follows ReLU(a + b): the add kernel delivers
+        # the statistics and this op's backward writes the masked gradient to the add's inputs; `folded_into` - this BN feeds such an
+        # add and has no other consumer: its normalisation is applied inside the add kernel, `out` is never written
+        self.fused_add: Optional["AddOp"] = None
+        self.folded_into: Optional["AddOp"] = None
 
     def forward(self, training):
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
-        if training:
+        if training and self.fused_add is None:
             call("seg_bn_stats", _p(x.buf), x.npix, x.cs, 0, self.C, _p(self.stats), self.nparts, self.C, 0, s)
         call("seg_bn_finalize", _p(self.stats), self.nparts, self.C, x.npix, st.ptr(bn + "/gamma"), st.ptr(bn + "/beta"),
              self.eps, self.momentum, st.ptr(bn + "/moving_mean"), st.ptr(bn + "/moving_variance"),
              1 if self.m.graph.ndim == 2 else 0, 1 if training else 0, _p(self.mean), _p(self.invstd), _p(self.scale),
              _p(self.shift), s)
+        if self.folded_into is not None:
+            return                            # normalised on the fly by the add that consumes it
         call("seg_bn_act_apply", _p(x.buf), x.cs, 0, _p(self.out.buf), self.out.cs, 0, x.N, x.H, x.W, self.C, self.cl,
              _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha), None, 1, 1, s)
 
     def plan_backward(self):
         self.live = self.out.gw
+        if self.fused_add is not None:
+            self.acc = None
+            if self.live:
+                self.x.gw = True              # the add's output does receive a gradient - handed straight on to the add's inputs
+            return
         self.acc = self.x.claim() if (self.live and self.x.needs_grad) else None
 
     def backward(self):
@@ -1118,6 +1132,11 @@ class BNOp(Op):
              _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha), _p(self.bpart), BN_PARTS_BWD, s)
         call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.C, x.npix, st.ptr(bn + "/gamma", "G"),
              st.ptr(bn + "/beta", "G"), 1.0, C.c_void_p(self.m.gs.data_ptr() + 4), _p(self.c1), _p(self.c2), s)
+        if self.fused_add is not None:
+            a = self.fused_add                # dx = [x > 0] sc (g - c1 - xhat c2) to every input of the add: no add backward pass
+            call("seg_bn_bwd_apply_fanout", _p(dA), _p(x.buf), a.gptrs, len(a.xs), a.mask, x.npix, self.C, _p(self.scale), _p(self.mean),
+                 _p(self.invstd), _p(self.c1), _p(self.c2), 1 if ACT[a.act] == ACT["relu"] else 0, s)
+            return
         if self.acc is None:          # the input needs no gradient (a BN placed on the network input): gamma / beta are done
             return
         call("seg_bn_act_bwd_apply", _p(dA), self.out.cs, 0, _p(x.buf), x.cs, 0, _p(x.grad), x.cs, 0, x.npix, self.C,
@@ -1162,8 +1181,22 @@ class AddOp(Op):
         if len(xs) > 4:
             raise NotImplementedError("add of more than 4 tensors")
         self.ptrs = (C.c_void_p * 4)(*[x.buf.data_ptr() for x in xs])
+        self.fused_bn: Optional[BNOp] = None          # the BatchNormalization that follows (fused tail): gets its statistics from here
+        self.folded: List[Optional[BNOp]] = [None] * len(xs)      # inputs that are BatchNormalizations applied on the fly
+
+    def fuse(self, bn: "BNOp"):
+        self.fused_bn = bn
+        srcs = [(b.x if b is not None else x) for x, b in zip(self.xs, self.folded)]
+        self.fptrs = (C.c_void_p * 4)(*[t.buf.data_ptr() for t in srcs])
+        self.fscales = (C.c_void_p * 4)(*[(b.scale.data_ptr() if b is not None else None) for b in self.folded])
+        self.fshifts = (C.c_void_p * 4)(*[(b.shift.data_ptr() if b is not None else None) for b in self.folded])
 
     def forward(self, training):
+        if self.fused_bn is not None:
+            b = self.fused_bn
+            call("seg_add_act_stats_fwd", self.fptrs, self.fscales, self.fshifts, len(self.xs), _p(self.out.buf), self.out.npix, self.out.cs,
+                 ACT[self.act], float(self.alpha), _p(b.stats), b.nparts, _stream())
+            return
         call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
              float(self.alpha), _stream())
 
@@ -1182,7 +1215,7 @@ class AddOp(Op):
         self.gptrs = (C.c_void_p * 4)(*gp)
 
     def backward(self):
-        if self.live:
+        if self.live and self.fused_bn is None:       # (fused tail: the BatchNormalization's backward wrote the inputs' gradients)
             call("seg_add_act_bwd", _p(self.out.grad), _p(self.out.buf), self.gptrs, len(self.xs), self.out.buf.numel(),
                  ACT[self.act], float(self.alpha), self.mask, _stream())
 
@@ -1561,6 +1594,7 @@ class SegModel:
                 x = self._materialise(val, n.inputs[0])
                 out = DevTensor(last.name, N, *last.shape)
                 self.ops.append(BNOp(self, n, x, act, alpha, out))
+                self._fuse_bn_tail(self.ops[-1], n, cons)
                 val[i] = val[last.idx] = out
                 done.add(last.idx)
             elif k == "add":
@@ -1620,6 +1654,34 @@ class SegModel:
         self.built = True
         self._init_optimizer_state()
         return self
+
+    def _fuse_bn_tail(self, bop: "BNOp", n: Node, cons):
+        """BN(ReLU(a + b)) - the tail of a MultiResBlock and of every ResPath iteration (unet_variants.py:97-99, :118-120) - as two
+        fused passes each way instead of five / seven: the add kernel applies the ReLU and delivers the statistics this BN needs
+        (no seg_bn_stats pass), an input that is itself a BatchNormalization with no other consumer (MultiResBlock: BN(cat)) is
+        normalised on the fly inside the add (its output is never written), and this BN's backward writes [s > 0] * dx to every
+        input of the add (no seg_add_act_bwd pass).  Needs: this BN without an activation of its own, the add's output feeding
+        only this BN, every input of the add feeding only the add."""
+        g = self.graph
+        if not FUSE_BN_TAILS or bop.act is not None:
+            return
+        add = next((o for o in reversed(self.ops[:-1]) if isinstance(o, AddOp) and o.out is bop.x), None)
+        if add is None or len(add.xs) < 2 or add.fused_bn is not None or ACT[add.act] not in (ACT[None], ACT["relu"]):
+            return
+        src = g.nodes[n.inputs[0]]                            # the activation node (or the add itself)
+        addn = g.nodes[src.inputs[0]] if src.kind == "act" else src
+        if addn.kind != "add" or list(cons[src.idx]) != [n.idx] or (src is not addn and list(cons[addn.idx]) != [src.idx]):
+            return
+        if any(list(cons[j]) != [addn.idx] for j in addn.inputs) or not all(x.needs_grad and x.cs == bop.x.cs for x in add.xs):
+            return
+        for k, x in enumerate(add.xs):
+            b1 = next((o for o in self.ops if isinstance(o, BNOp) and o.out is x), None)
+            if b1 is not None and b1.act is None and b1.fused_add is None and b1.folded_into is None:
+                add.folded[k] = b1
+                b1.folded_into = add
+                b1.out.materialised = False                   # (never written: tests / tools must not read it)
+        bop.fused_add = add
+        add.fuse(bop)
 
     def _build_transpose_table(self):
         """Device table of every derived (transposed) weight operand: refreshed by ONE launch after each optimiser step."""
