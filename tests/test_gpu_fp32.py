@@ -139,3 +139,33 @@ def test_range_of_the_split_pair_format_is_loud_not_silent():
     out3, _, _ = U.igemm_conv([x3], kern, None, "conv", (1, 1), None, 0.0, False, (256, 64), f32=True, variant=3)
     ref3 = K.conv2d_same(x3, torch.from_numpy(kern), None)
     assert rel(out3, ref3) < 2e-4
+
+
+@pytest.mark.parametrize("tile", [(256, 64), (512, 64)])
+@pytest.mark.parametrize("case", [
+    dict(kind="conv", shape=(2, 16, 32), cins=[24, 40], cout=72),       # 8x32 patches, virtual concat, two N blocks (the second ragged)
+    dict(kind="conv", shape=(2, 32, 16), cins=[64], cout=64),           # 16x16 patches
+    dict(kind="convT", shape=(2, 16, 32), cins=[40], cout=24),          # four sub-pixel classes of 2x2 taps
+], ids=lambda c: f"{c['kind']}-{c['shape']}-{c['cins']}->{c['cout']}")
+def test_halo_kernels_in_the_parity_mode(case, tile):
+    """variant 3 with split-pair tensors: one patch per block of 4 waves (256 x 64) and two patches per block of 8 waves against
+    one weight stream (512 x 64); bias, ReLU / LeakyReLU, BN partial statistics, accumulate."""
+    N, H, W = case["shape"]
+    xs = [torch.randn(N, H, W, c) for c in case["cins"]]
+    cin, cout = sum(case["cins"]), case["cout"]
+    tconv = case["kind"] == "convT"
+    kshape = (4, 4, cout, cin) if tconv else (3, 3, cin, cout)
+    kern = rng.standard_normal(kshape).astype(np.float32) * 0.1
+    b = rng.standard_normal(cout).astype(np.float32)
+    s = (2, 2) if tconv else (1, 1)
+    f = K.conv2d_transpose_same if tconv else K.conv2d_same
+    pre = f(torch.cat(xs, -1), torch.from_numpy(kern), torch.from_numpy(b), s)
+    act, alpha = ("leaky_relu", 0.3) if tconv else ("relu", 0.0)
+    out, st, pad = U.igemm_conv(xs, kern, b, case["kind"], s, act, alpha, True, tile, f32=True, variant=3)
+    want = torch.nn.functional.leaky_relu(pre, 0.3) if tconv else torch.relu(pre)
+    assert rel(out, want) < 2e-6 and pad == 0.0
+    assert rel(st[:, :cout], torch.stack([pre.sum((0, 1, 2)), (pre * pre).sum((0, 1, 2))])) < 1e-5
+    if not tconv:
+        base = torch.randn(N, H, W, U.r8(cout))
+        out2, _, _ = U.igemm_conv(xs, kern, None, "conv", s, None, 0.0, False, tile, accumulate_into=base, f32=True, variant=3)
+        assert rel(out2, f(torch.cat(xs, -1), torch.from_numpy(kern), None, s) + base[..., :cout]) < 2e-6
