@@ -15,14 +15,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 // Parity mode (SPLIT, BN = 64 only): the tensors are split pairs and the loaders see twice the channels (igemm_common.h), so a
 // "32-channel chunk" is 16 real channels as hi / lo 16-B chunks; per tap and tile pair three MFMAs into two accumulator sets.
-// NP = 2 (tile_m = 512, BN = 64): TWO patches per block of 8 waves - waves 0-3 own patch 2 b, waves 4-7 patch 2 b + 1 - against ONE
-// weight stream (fetched by waves 0-3): the weights are 60 % of the LDS-DMA bytes of the one-patch form, and two co-resident blocks
-// of that form stream the same weights twice.  0.091 instead of 0.134 KB of LDS-DMA per MFMA; same registers per wave, 124 KB of LDS.
-template <int PW, int BN, int NT, int TG, int NPL, bool SPLIT = false, int NP = 1>
-__global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_args p) {
+template <int PW, int BN, int NT, int TG, int NPL, bool SPLIT = false>
+__global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(!SPLIT || BN == 64, "parity mode: 64 x 64 accumulators per wave, twice");
-  static_assert(NP == 1 || (NP == 2 && BN == 64), "two patches per block: the 64-channel tile");
   typedef std::conditional_t<SPLIT, split_t, half_t> TO;
   constexpr int PH = 256 / PW, HC = PW + 2, HROWS = (PH + 2) * HC;
   constexpr int NI_A = (HROWS + 15) / 16;                  // LDS-DMA wave instructions per halo tile (16 rows of 64 B)
@@ -35,13 +31,11 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
   static_assert(NPL == 1 || (NPL == 4 && NT == 4), "parity planes: the data gradient of the 4x4 / stride-2 transposed conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  unsigned char* const Abuf = smem;                         // 2 x NP halo tiles: [buffer][patch of the block]
-  unsigned char* const Bbuf = smem + 2 * NP * A_BYTES;      // 3 weight stages
+  unsigned char* const Abuf = smem;                         // 2 halo tiles
+  unsigned char* const Bbuf = smem + 2 * A_BYTES;           // 3 weight stages
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_b = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave of the block (0 .. 4 NP - 1)
-  const int pg = NP == 1 ? 0 : wave_b >> 2;                         // patch of the block this wave works on
-  const int wave = wave_b & 3;                                      // wave inside its group of four
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNv, wn = wave % WNv;
   const seg_geom& g = p.g;
   // NPL = 4: the input (dY of a 4x4 / stride-2 transposed conv) is read as four parity planes (py, px) of the logical
@@ -52,8 +46,7 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
   const int npatch = g.N * PHn * PWn;
   const int lin0 = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int cls = lin0 / gridDim.x, lin = lin0 - cls * gridDim.x;      // sub-pixel class of a transposed conv (0 otherwise)
-  const int mbp = lin % (npatch / NP), nb = lin / (npatch / NP);    // patch group of the block (one partial-statistics row each)
-  const int mb = mbp * NP + pg;
+  const int mb = lin % npatch, nb = lin / npatch;
   const int n0 = nb * BN;
   const int pn = mb / (PHn * PWn);
   const int prem = mb - pn * (PHn * PWn);
@@ -128,7 +121,7 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
     if (c.seg >= p.nseg) return;
     const int cs2 = p.seg_cs[c.seg] * 2, sc = p.seg_c[c.seg];
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.seg_ptr[c.seg]), 0, __builtin_amdgcn_readfirstlane(imgpix * cs2), 0x00020000);
-    unsigned char* sb = Abuf + (buf * NP + pg) * A_BYTES;
+    unsigned char* sb = Abuf + buf * A_BYTES;
     const int ploff = NPL == 1 ? 0 : (c.pl >> 1) * g.Win + (c.pl & 1);
 #pragma unroll
     for (int k = 0; k < NA_HI; ++k) {
@@ -141,7 +134,7 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
   };
   // weights of step (chunk c, tap group tg): rows [tap-in-group][BN channels] x 32 K columns
   auto issueB = [&](const Cur& c, int tg, int slot) {
-    if (c.seg >= p.nseg || pg != 0) return;          // (two patches per block: one weight stream, fetched by the first group)
+    if (c.seg >= p.nseg) return;
     unsigned char* sb = Bbuf + slot * B_BYTES;
     const int kof = (p.seg_woff[c.seg] + c.c0) * 2;
 #pragma unroll
@@ -188,7 +181,7 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
 
   auto compute = [&](auto tgc, int abuf, int slot) {
     constexpr int tg = decltype(tgc)::value;
-    const unsigned char* A = Abuf + (abuf * NP + pg) * A_BYTES;
+    const unsigned char* A = Abuf + abuf * A_BYTES;
     const unsigned char* B = Bbuf + slot * B_BYTES;
     int lr = lrowA;
     asm volatile("" : "+v"(lr));      // opaque per step: keeps the 36 (tap, tile) row offsets from being hoisted out of the K loop into registers
@@ -260,14 +253,7 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
     static_for<0, NSTEP>([&](auto tgc) {
       constexpr int tg = decltype(tgc)::value;
       // everything older than the newest weight stage (and the halo tile issued after it) must have landed
-      if (NP > 1 && pg != 0) {                         // the second group issues halo tiles only
-        if (s + 1 < nsteps && tg == 1 % NSTEP && ck + 1 < nchunks) {
-          if (NA_REM == 0 || wave < NA_REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_HI) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_HI - 1) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      } else if (s + 1 < nsteps) {
+      if (s + 1 < nsteps) {
         if (tg == 1 % NSTEP && ck + 1 < nchunks) {     // the next chunk's halo tile was issued at the previous step
           if (NA_REM == 0 || wave < NA_REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_W + NA_HI) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_W + NA_HI - 1) : "memory");
@@ -307,7 +293,7 @@ __global__ __launch_bounds__(256 * NP, 2) void igemm_fwd3_kernel(const seg_igemm
   }
   __syncthreads();
   if constexpr (SPLIT) split_combine(acc, accl);
-  conv_epilogue<TO, TMw, 2, WMv * NP, BN, PW, 4 * NP>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, pg * WMv + wm, cls, npatch / NP, mbp, 0, 0, pn, y0, x0);
+  conv_epilogue<TO, TMw, 2, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, cls, npatch, mb, 0, 0, pn, y0, x0);
 #endif
 }
 template __global__ void igemm_fwd3_kernel<32, 128, 9, 1, 1>(const seg_igemm_fwd_args);
@@ -331,13 +317,6 @@ template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 1, true>(const seg_igem
 template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 1, true>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true>(const seg_igemm_fwd_args);
-// ... two patches per block (tile_m = 512)
-template __global__ void igemm_fwd3_kernel<32, 64, 9, 3, 1, true, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 64, 9, 3, 1, true, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 1, true, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 1, true, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true, 2>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true, 2>(const seg_igemm_fwd_args);
 
 }  // namespace
 
@@ -432,12 +411,6 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
 template <int NT, int TG, int NPL>
 static void launch_fwd3_split_nt(const seg_igemm_fwd_args& v, int pw, dim3 grid, hipStream_t st) {
   const int ni_a = pw == 32 ? 22 : 21;
-  if (v.tile_m == 512) {               // two patches per block
-    const size_t lds = (size_t)4 * ni_a * 1024 + 3 * (TG * 4096);
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 64, NT, TG, NPL, true, 2>), grid, dim3(512), lds, st, v);
-    else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 64, NT, TG, NPL, true, 2>), grid, dim3(512), lds, st, v);
-    return;
-  }
   const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (TG * 4096);
   if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 64, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
   else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 64, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
@@ -445,12 +418,11 @@ static void launch_fwd3_split_nt(const seg_igemm_fwd_args& v, int pw, dim3 grid,
 int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st) {
   const int pw = seg_fwd_halo_patch(&v.g);
   SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd_f32: variant 3 needs a stride-1 3x3 'same' conv, a 4x4 / stride-2 transposed conv (or the data gradient of either), and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
-  SEG_CHECK_ARG((v.tile_m == 256 || v.tile_m == 512) && v.tile_n == 64, "seg_igemm_fwd_f32: the variant 3 tiles are 256x64 and 512x64, not %dx%d", v.tile_m, v.tile_n);
-  SEG_CHECK_ARG(v.tile_m == 256 || ((long)v.g.N * v.g.Hl * v.g.Wl / 256) % 2 == 0, "seg_igemm_fwd_f32: the 512x64 tile (two patches per block) needs an even number of 256-pixel patches");
+  SEG_CHECK_ARG(v.tile_m == 256 && v.tile_n == 64, "seg_igemm_fwd_f32: the variant 3 tile is 256x64, not %dx%d", v.tile_m, v.tile_n);
   const long pix = (long)v.g.N * v.g.Hin * v.g.Win;
   for (int s = 0; s < v.nseg; ++s) SEG_CHECK_ARG(pix * v.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
   SEG_CHECK_ARG((long)v.n_rows * v.g.T_total * v.Kpad * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
-  const int npatch = (int)((long)v.g.N * v.g.Hl * v.g.Wl / v.tile_m);      // blocks along M
+  const int npatch = (int)((long)v.g.N * v.g.Hl * v.g.Wl / 256);
   const int nblocks = (v.n_rows + 63) / 64;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)v.g.ncls, 1);
   if (v.g.ntaps == 16) launch_fwd3_split_nt<4, 2, 4>(v, pw, grid, st);

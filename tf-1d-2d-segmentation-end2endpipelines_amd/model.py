@@ -335,8 +335,6 @@ ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
 ADAM_URGENT_FIRST = os.environ.get("SEG_ADAM_URGENT_FIRST", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
-FWD_HALO2 = os.environ.get("SEG_FWD_HALO2", "1") != "0"      # parity mode: the two-patches-per-block form of the halo forward kernel
-FWD_HALO2_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO2_MIN_BLOCKS", "256"))
 
 
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
@@ -345,10 +343,6 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     tile is 256 x 64 only and the per-tap LDS-DMA kernel has no 64-deep K step."""
     if FWD_HALO and fwd_halo_patch(g):
         tn = 64 if (n_rows <= 64 or not f16) else 128
-        # parity mode: two 256-pixel patches per block of 8 waves against ONE weight stream (csrc/igemm_halo.hip, NP = 2) whenever
-        # that still leaves every CU a block
-        if not f16 and FWD_HALO2 and (M // 256) % 2 == 0 and g.ncls * (M // 512) * _cdiv(n_rows, 64) >= FWD_HALO2_MIN_BLOCKS:
-            return 512, 64, 3
         if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
             return 256, tn, 3
     tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
