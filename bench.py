@@ -125,10 +125,27 @@ def pmc_traffic(entry_point, workload, dtype):
         d = json.load(fh)
     n = tot = 0
     for k, v in d.items():
-        if any(pf in k for pf in prefix):
+        if not k.startswith("_") and any(pf in k for pf in prefix):
             n += v["launches"]
             tot += v["launches"] * (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"])
     return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
+
+
+def pmc_step_traffic(workload, dtype):
+    """HBM bytes per optimiser step over ALL kernels from the committed PMC summary of this workload and mode (the file records
+    how many steps its run took): what the HBM-bound configurations actually move, beside their algorithmic bytes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload.lower()}_{dtype}_hbm_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    steps = d.get("_run", {}).get("train_steps")
+    if not steps:
+        return None, None
+    tot = sum(v["launches"] * (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) for k, v in d.items()
+              if not k.startswith("_") and "FillFunctor" not in k and "copyBuffer" not in k)      # (start-up allocations / uploads)
+    return tot / steps, os.path.relpath(files[-1], ROOT)
 
 
 def profiled_step(model, x, targets, rank0=True):
@@ -207,8 +224,11 @@ def short_run(workload, dtype, steps, warmup, profile=True):
         act, wts = model.graph.conv_io_elements()
         esz = 2 if dtype == "f16" else 4
         nbytes = 3.0 * (act * bs + wts) * esz          # fused-forward bytes, ~3x for forward + backward
+        tr, src = pmc_step_traffic(workload.replace("w64", ""), dtype) if workload == "C4" else (None, None)
         res["roofline"] = {"bound": "hbm", "algorithmic_gb_per_step": round(nbytes / 1e9, 3), "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                           "traffic": (round(tr / 1e9, 2) if tr else None), "traffic_unit": "HBM GB per step over all kernels (PMC)",
+                           "traffic_source": src, "traffic_over_algorithmic": (round(tr / nbytes, 2) if tr else None)}
     if profile:
         KP, _ = profiled_steps(model, x, targets)
         gs = gemm_summary(KP, peak)

@@ -30,7 +30,7 @@ fi
 cd $R
 python3 tools/profile_summary.py stats $O/stats ${P}_kernel_stats.csv
 python3 tools/profile_summary.py stats $O/stats1 ${P}_kernel_stats_single_stream.csv
-python3 tools/profile_summary.py hbm $O/fetch $O/write ${P}_hbm_traffic.json
+python3 tools/profile_summary.py hbm $O/fetch $O/write ${P}_hbm_traffic.json 8      # 2 warm-up + 3 timed + 3 profiled steps
 if [ "$MODE" = "full" ]; then
 python3 tools/profile_summary.py pmc $O/sq1 ${P}_pmc_sq1.csv
 python3 tools/profile_summary.py pmc $O/sq2 ${P}_pmc_sq2.csv

@@ -2,7 +2,7 @@
 """Post-processes rocprofv3 output into the summaries kept under profiles/.
 
     python tools/profile_summary.py stats  <dir of --kernel-trace --stats run>   <out.csv>
-    python tools/profile_summary.py hbm    <dir of --pmc FETCH_SIZE run> <dir of --pmc WRITE_SIZE run> <out.json>
+    python tools/profile_summary.py hbm    <dir of --pmc FETCH_SIZE run> <dir of --pmc WRITE_SIZE run> <out.json> [train steps of the run]
     python tools/profile_summary.py pmc    <dir of a --pmc run> <out.csv>
 
 hbm: FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE tallies the 128-B requests of wide
@@ -63,6 +63,8 @@ def main():
                 continue
             out[k] = {"launches": max(n, n2), "fetch_bytes_per_launch_reported": fs * 1024 / max(n, 1),
                       "fetch_bytes_per_launch_corrected": 2 * fs * 1024 / max(n, 1), "write_bytes_per_launch": ws * 1024 / max(n2, 1)}
+        if len(sys.argv) > 5:      # optimiser steps the profiled command ran (warm-up + timed + bench.py's three profiled passes)
+            out["_run"] = {"train_steps": int(sys.argv[5])}
         json.dump(out, open(sys.argv[4], "w"), indent=1)
     elif mode == "pmc":
         acc = counters(sys.argv[2])
