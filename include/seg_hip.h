@@ -110,6 +110,8 @@ typedef struct seg_igemm_fwd_args {
   const float* ep_scale;         /* NULL, or [n_rows] per-channel factor applied to the contraction before bias (folded BN) */
 } seg_igemm_fwd_args;
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
+/* floats of `stats` for these arguments ([ncls * ceil(M / tile_m)][2][n_rows]); the library allocates nothing itself */
+int64_t seg_igemm_fwd_stats_floats(const seg_igemm_fwd_args* a);
 /* patch width (32: 8x32 pixels, 16: 16x16 pixels) the variant-3 kernel uses for this geometry; 0: not eligible   */
 int seg_fwd_halo_patch(const seg_geom* g);
 
@@ -149,6 +151,9 @@ typedef struct seg_igemm_wgrad_args {
                                     NULL: split blocks add into dw with float atomics (order-dependent last bits).            */
 } seg_igemm_wgrad_args;
 int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
+/* bytes of the zero-initialised `partial` workspace for these arguments (splitk * n_rows * T_total * Kpad floats; 0 when
+ * splitk == 1): the caller allocates it once per layer, the library allocates nothing                                   */
+int64_t seg_igemm_wgrad_workspace_bytes(const seg_igemm_wgrad_args* a);
 /* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */
 int seg_wgrad_halo_patch(const seg_geom* g);
 /* blocks along the class axis of the variant-2 kernel (1: conv; 2: transposed conv on the class-pair kernel; 4)     */

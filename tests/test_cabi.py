@@ -115,3 +115,26 @@ def test_no_gpu_no_model():
     m = segamd.unet_model_builder("UNet", 32, 32, 8, 2, train_mode="from_scratch").ResNet50()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.build(1)
+
+
+def test_workspace_queries_agree_with_the_engines_own_sizing(built):
+    """the library allocates nothing - the caller asks how much a launch needs.  The engine's buffers (model.ConvOp:
+    BN partial statistics, the partial tiles of the deterministic pixel split) are exactly what the queries return."""
+    ffi = importlib.import_module(PKG + "._ffi")
+    M = importlib.import_module(PKG + ".model")
+    L = ffi.lib()
+    M._DryRun.on = True
+    try:
+        m = importlib.import_module(PKG).unet_model_builder("UNetPP", 64, 64, 16, 2, ds=1, train_mode="from_scratch").ResNet50().build(2)
+        seen = 0
+        for op in m.ops:
+            if not isinstance(op, M.ConvOp):
+                continue
+            if op.has_bn:
+                assert L.seg_igemm_fwd_stats_floats(ctypes.byref(op.fwd_args)) == op.stats.numel()
+            want = op.wg_partial.numel() * 4 if op.wg_partial is not None else 0
+            assert L.seg_igemm_wgrad_workspace_bytes(ctypes.byref(op.wg_args)) == want
+            seen += 1
+        assert seen > 5
+    finally:
+        M._DryRun.on = False

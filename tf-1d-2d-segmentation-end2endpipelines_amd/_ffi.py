@@ -70,6 +70,8 @@ _PROTOS = {
     "seg_abi_version": ([], C.c_int),
     "seg_igemm_fwd": ([C.POINTER(IgemmFwdArgs), vp], C.c_int),
     "seg_igemm_wgrad": ([C.POINTER(IgemmWgradArgs), vp], C.c_int),
+    "seg_igemm_fwd_stats_floats": ([C.POINTER(IgemmFwdArgs)], C.c_int64),
+    "seg_igemm_wgrad_workspace_bytes": ([C.POINTER(IgemmWgradArgs)], C.c_int64),
     "seg_wgrad_taps_per_block": ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_wgrad_halo_class_groups": ([C.POINTER(Geom)], C.c_int),

@@ -876,6 +876,20 @@ int seg_launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st) {
   return SEG_OK;
 }
 
+// ---- workspace queries (no allocation inside the library - the caller asks, allocates, passes the pointer)
+// floats of the per-block partial BN statistics seg_igemm_fwd / seg_igemm_fwd_f32 write when args->stats != NULL:
+// [ncls * ceil(M / tile_m)][2][n_rows]
+extern "C" int64_t seg_igemm_fwd_stats_floats(const seg_igemm_fwd_args* a) {
+  if (a == nullptr || a->tile_m <= 0) return -1;
+  const int64_t M = (int64_t)a->g.N * a->g.Hl * a->g.Wl;
+  return (int64_t)a->g.ncls * ((M + a->tile_m - 1) / a->tile_m) * 2 * a->n_rows;
+}
+// bytes of the zero-initialised `partial` workspace of the deterministic pixel split of seg_igemm_wgrad / _f32 (0: not needed)
+extern "C" int64_t seg_igemm_wgrad_workspace_bytes(const seg_igemm_wgrad_args* a) {
+  if (a == nullptr) return -1;
+  return a->splitk > 1 ? (int64_t)a->splitk * a->n_rows * a->g.T_total * a->Kpad * (int64_t)sizeof(float) : 0;
+}
+
 // taps handled per block by the weight-gradient kernels (1 = the per-tap kernel); exported so that the host can
 // size the pixel split with the same rule
 extern "C" int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int variant) {
