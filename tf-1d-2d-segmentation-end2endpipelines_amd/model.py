@@ -335,6 +335,7 @@ ADAM_SLICE_ELEMS = int(os.environ.get("SEG_ADAM_SLICE_ELEMS", str(4 << 20)))
 ADAM_URGENT_FIRST = os.environ.get("SEG_ADAM_URGENT_FIRST", "1") != "0"
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers
 FWD_HALO_MIN_BLOCKS = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "384"))
+FWD_HALO_MIN_BLOCKS_F32 = int(os.environ.get("SEG_FWD_HALO_MIN_BLOCKS_F32", os.environ.get("SEG_FWD_HALO_MIN_BLOCKS", "128")))
 
 
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
@@ -343,9 +344,13 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     tile is 256 x 64 only and the per-tap LDS-DMA kernel has no 64-deep K step."""
     if FWD_HALO and fwd_halo_patch(g):
         tn = 64 if (n_rows <= 64 or not f16) else 128
-        if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= FWD_HALO_MIN_BLOCKS:
+        # (parity mode: the halo kernel wins down to half a block per CU - same-box A/B of the threshold, 384 against 128 blocks:
+        # C3 50.05 -> 49.8 ms, C2 17.20 -> 16.78 ms per step)
+        if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= (FWD_HALO_MIN_BLOCKS if f16 else FWD_HALO_MIN_BLOCKS_F32):
             return 256, tn, 3
     tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
+    if not f16 and n_rows > 64 and g.ncls * _cdiv(M, 128) * _cdiv(n_rows, 128) >= 256:
+        tm, tn = 128, 128          # parity mode, per-tap kernel at one block per CU: X41 forward 499 -> 444 us (tools/op_bench.py --dtype f32)
     return tm, tn, 0
 
 
