@@ -1,0 +1,278 @@
+"""GPU: the streaming kernels in the PARITY mode (entry points with the suffix _f32: tensors stored as split fp16 pairs, csrc
+seg_common.h split_t) called one by one through the C ABI and compared with the oracle's primitives / torch autograd on the same
+fp32 inputs.  The pair keeps ~22 significant bits, so every comparison here is held to ~1e-6 relative - three orders of magnitude
+tighter than the fp16-mode operator tests in test_gpu_ops.py, which exercise the same kernel templates with T = fp16.
+(The GEMM entry points in this mode: test_gpu_fp32.py.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import gpu_util as U
+from gpu_util import P, ffi, stream
+from oracle import keras_ref as K
+
+ACT = ffi.ACT
+TOL = 2e-6
+F32 = torch.float32
+
+
+def dev(x):
+    """fp32 NHWC CPU tensor -> split-pair device tensor (channel stride padded to 8)."""
+    return U.to_dev_nhwc(x, F32)
+
+
+def val(t, Cc):
+    return U.dev_values(t)[..., :Cc]
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def zeros_like_dev(N, H, W, Cc):
+    return torch.zeros((N, H, W, U.r8(Cc)), dtype=F32, device="cuda")
+
+
+def fdev(a):
+    return torch.as_tensor(np.asarray(a, np.float32)).cuda().contiguous()
+
+
+@pytest.mark.parametrize("Cc,act,pool", [(64, "relu", None), (24, None, None), (40, "relu", (2, 2)), (8, "sigmoid", None)])
+def test_bn_statistics_apply_and_backward(Cc, act, pool):
+    N, H, W = 2, 12, 16
+    cs, npix = U.r8(Cc), N * H * W
+    z = torch.randn(N, H, W, Cc) * 2.0 + 0.5
+    gamma, beta = torch.rand(Cc) + 0.5, torch.randn(Cc)
+    zd = dev(z)
+    nparts = 7
+    stats = torch.zeros(nparts * 2 * cs, device="cuda")
+    ffi.call("seg_bn_stats_f32", P(zd), npix, cs, 0, cs, P(stats), nparts, cs, 0, stream())
+    pad = lambda v, fill=0.0: fdev(np.concatenate([v.detach().numpy(), np.full(cs - Cc, fill, np.float32)]))
+    g_d, b_d, mm, mv = pad(gamma), pad(beta), pad(torch.zeros(Cc)), pad(torch.ones(Cc), 1.0)
+    mean, invstd, scale, shift = (torch.zeros(cs, device="cuda") for _ in range(4))
+    ffi.call("seg_bn_finalize", P(stats), nparts, cs, npix, P(g_d), P(b_d), 1e-3, 0.99, P(mm), P(mv), 1, 1, P(mean), P(invstd), P(scale), P(shift), stream())
+    y = torch.zeros_like(zd)
+    pooled = torch.zeros((N, H // 2, W // 2, cs), dtype=F32, device="cuda") if pool else None
+    ffi.call("seg_bn_act_apply_f32", P(zd), cs, 0, P(y), cs, 0, N, H, W, cs, Cc, P(scale), P(shift), ACT[act], 0.0, P(pooled) if pool else None,
+             *(pool or (1, 1)), stream())
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref, _nm, _nv = K.batchnorm(zr, gr, br, torch.zeros(Cc), torch.ones(Cc), True, fused_4d=True)
+    ref = K.activation(ref, act)
+    torch.cuda.synchronize()
+    assert rel(val(y, Cc), ref.detach()) < TOL and rel(mean[:Cc].cpu(), z.mean((0, 1, 2))) < TOL
+    if pool:
+        assert torch.equal(val(pooled, Cc), K.maxpool(val(y, Cc), pool))          # the pooled tensor is the max of what was STORED
+    if cs > Cc:
+        assert float(U.dev_values(y)[..., Cc:].abs().max()) == 0.0
+    # ---- backward
+    dA = torch.randn(N, H, W, Cc)
+    (ref * dA).sum().backward()
+    dAd = dev(dA)
+    part = torch.zeros(16 * 2 * cs, device="cuda")
+    c1, c2, dg, db = (torch.zeros(cs, device="cuda") for _ in range(4))
+    ffi.call("seg_bn_act_bwd_reduce_f32", P(dAd), cs, 0, P(zd), cs, 0, npix, cs, P(scale), P(shift), P(mean), P(invstd), ACT[act], 0.0, P(part), 16, stream())
+    ffi.call("seg_bn_bwd_finalize", P(part), 16, cs, npix, P(dg), P(db), 1.0, None, P(c1), P(c2), stream())
+    dz = torch.zeros_like(zd)
+    ffi.call("seg_bn_act_bwd_apply_f32", P(dAd), cs, 0, P(zd), cs, 0, P(dz), cs, 0, npix, cs, P(scale), P(shift), P(mean), P(invstd), P(c1), P(c2),
+             ACT[act], 0.0, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(val(dz, Cc), zr.grad) < 2e-5          # (cancellation in g - mean(g) - xhat mean(g xhat) amplifies the 2^-23 of the stored operands)
+    assert rel(dg[:Cc].cpu(), gr.grad) < 1e-5 and rel(db[:Cc].cpu(), br.grad) < 1e-5
+
+
+def test_fused_tail_add_relu_statistics_and_fanout_backward():
+    """seg_add_act_stats_fwd_f32 / seg_bn_bwd_apply_fanout_f32: BN2(ReLU(a + BN1(b))) with BN1 normalised on the fly."""
+    N, H, W, Cc = 2, 8, 16, 24
+    cs, npix = U.r8(Cc), N * H * W
+    a, b = torch.randn(N, H, W, Cc), torch.randn(N, H, W, Cc) * 3.0 + 1.0
+    s1, h1 = torch.rand(Cc) + 0.5, torch.randn(Cc)
+    ad, bd = dev(a), dev(b)
+    pad = lambda v: fdev(np.concatenate([v.numpy(), np.zeros(cs - Cc, np.float32)]))
+    s1d, h1d = pad(s1), pad(h1)
+    xs = (C.c_void_p * 4)(ad.data_ptr(), bd.data_ptr(), None, None)
+    scs = (C.c_void_p * 4)(None, s1d.data_ptr(), None, None)
+    shs = (C.c_void_p * 4)(None, h1d.data_ptr(), None, None)
+    y = torch.zeros_like(ad)
+    nparts = 5
+    stats = torch.zeros(nparts * 2 * cs, device="cuda")
+    ffi.call("seg_add_act_stats_fwd_f32", xs, scs, shs, 2, P(y), npix, cs, ACT["relu"], 0.0, P(stats), nparts, stream())
+    torch.cuda.synchronize()
+    s = torch.relu(a + b * s1 + h1)
+    assert rel(val(y, Cc), s) < TOL
+    st = stats.reshape(nparts, 2, cs).sum(0).cpu()
+    assert rel(st[0, :Cc], s.sum((0, 1, 2))) < 1e-5 and rel(st[1, :Cc], (s * s).sum((0, 1, 2))) < 1e-5
+    assert float(U.dev_values(y)[..., Cc:].abs().max()) == 0.0 if cs > Cc else True
+    # backward of BN2 over s with the ReLU mask, fanned out to both inputs (the second accumulating)
+    gamma = torch.rand(Cc) + 0.5
+    sr = s.clone().requires_grad_(True)
+    out, _a, _b = K.batchnorm(sr, gamma, torch.zeros(Cc), torch.zeros(Cc), torch.ones(Cc), True, fused_4d=True)
+    dy = torch.randn(N, H, W, Cc)
+    (out * dy).sum().backward()
+    want = sr.grad * (s > 0)
+    mean, var = s.mean((0, 1, 2)), s.var((0, 1, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-3)
+    xhat = (s - mean) * invstd
+    c1, c2 = dy.mean((0, 1, 2)), (dy * xhat).mean((0, 1, 2))
+    d1, prev = torch.zeros_like(ad), torch.randn(N, H, W, Cc)
+    d2 = dev(prev)
+    gp = (C.c_void_p * 4)(d1.data_ptr(), d2.data_ptr(), None, None)
+    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dev(dy)), P(y), gp, 2, 0b10, npix, cs, P(pad(gamma * invstd)), P(pad(mean)), P(pad(invstd)), P(pad(c1)), P(pad(c2)),
+             1, stream())
+    torch.cuda.synchronize()
+    assert rel(val(d1, Cc), want) < 2e-5 and rel(val(d2, Cc), want + prev) < 2e-5
+
+
+@pytest.mark.parametrize("pool", [(2, 2), (1, 2), (4, 4)])
+def test_maxpool(pool):
+    N, H, W, Cc = 2, 8, 16, 24
+    x = torch.randn(N, H, W, Cc, requires_grad=True)
+    y = K.maxpool(x, pool)
+    dy = torch.randn_like(y)
+    (y * dy).sum().backward()
+    xd, yd = dev(x.detach()), torch.zeros((N, H // pool[0], W // pool[1], Cc), dtype=F32, device="cuda")
+    ffi.call("seg_maxpool_fwd_f32", P(xd), P(yd), N, H, W, Cc, *pool, stream())
+    dxd = torch.zeros_like(xd)
+    ffi.call("seg_maxpool_bwd_f32", P(dev(dy)), P(xd), P(yd), P(dxd), N, H, W, Cc, *pool, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(val(yd, Cc), y.detach()) < TOL and rel(val(dxd, Cc), x.grad) < TOL
+
+
+@pytest.mark.parametrize("f,bil", [((2, 2), 1), ((2, 2), 0), ((4, 4), 1), ((1, 2), 0)])
+def test_upsample(f, bil):
+    N, H, W, Cc = 2, 6, 8, 16
+    x = torch.randn(N, H, W, Cc, requires_grad=True)
+    y = K.upsample(x, f, "bilinear" if bil else "nearest")
+    dy = torch.randn_like(y)
+    (y * dy).sum().backward()
+    xd, yd = dev(x.detach()), torch.zeros((N, H * f[0], W * f[1], Cc), dtype=F32, device="cuda")
+    ffi.call("seg_upsample_fwd_f32", P(xd), P(yd), N, H, W, Cc, *f, bil, stream())
+    dxd = torch.zeros_like(xd)
+    ffi.call("seg_upsample_bwd_f32", P(dev(dy)), P(dxd), N, H, W, Cc, *f, bil, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(val(yd, Cc), y.detach()) < TOL and rel(val(dxd, Cc), x.grad) < 4e-6
+
+
+@pytest.mark.parametrize("n,act", [(2, "relu"), (3, None), (1, "leaky_relu")])
+def test_add_act(n, act):
+    shape = (2, 8, 8, 16)
+    xs = [torch.randn(shape, requires_grad=True) for _ in range(n)]
+    y = K.activation(sum(xs), act) if act != "leaky_relu" else F.leaky_relu(sum(xs), 0.3)
+    dy = torch.randn(shape)
+    (y * dy).sum().backward()
+    ds = [dev(x.detach()) for x in xs]
+    ptrs = (C.c_void_p * 4)(*([d.data_ptr() for d in ds] + [None] * (4 - n)))
+    yd = torch.zeros_like(ds[0])
+    ffi.call("seg_add_act_fwd_f32", ptrs, n, P(yd), yd.numel(), ACT[act], 0.3, stream())
+    gs = [torch.zeros_like(d) for d in ds]
+    gp = (C.c_void_p * 4)(*([g.data_ptr() for g in gs] + [None] * (4 - n)))
+    ffi.call("seg_add_act_bwd_f32", P(dev(dy)), P(yd), gp, n, yd.numel(), ACT[act], 0.3, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(val(yd, 16), y.detach()) < TOL
+    for g, x in zip(gs, xs):
+        assert rel(val(g, 16), x.grad) < TOL
+
+
+def test_attention_multiply_and_convlstm_gates():
+    N, H, W, Cc = 2, 8, 8, 24
+    a = torch.randn(N, H, W, Cc, requires_grad=True)
+    r = torch.rand(N, H, W, 1, requires_grad=True)
+    y = a * r
+    dy = torch.randn_like(y)
+    (y * dy).sum().backward()
+    ad, rd = dev(a.detach()), dev(r.detach())
+    yd = torch.zeros_like(ad)
+    ffi.call("seg_mul_bcast_fwd_f32", P(ad), P(rd), P(yd), N * H * W, Cc, 8, stream())
+    da, dr = torch.zeros_like(ad), torch.zeros_like(rd)
+    ffi.call("seg_mul_bcast_bwd_f32", P(dev(dy)), P(ad), P(rd), P(da), P(dr), N * H * W, Cc, 8, 0, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(val(yd, Cc), y.detach()) < TOL and rel(val(da, Cc), a.grad) < TOL and rel(val(dr, 1), r.grad) < 2e-6
+    assert float(U.dev_values(dr)[..., 1:].abs().max()) == 0.0
+    # ConvLSTM (T = 1) gates: h = hs(o) tanh(hs(i) tanh(c)), the forget gate gets a zero gradient
+    Fh = 16
+    z = (torch.randn(N, H, W, 4 * Fh) * 2).requires_grad_(True)
+    h = K.convlstm_gates(z, Fh) if hasattr(K, "convlstm_gates") else None
+    if h is None:
+        hs = lambda v: torch.clamp(0.2 * v + 0.5, 0.0, 1.0)
+        zi, _zf, zc, zo = z[..., :Fh], z[..., Fh:2 * Fh], z[..., 2 * Fh:3 * Fh], z[..., 3 * Fh:]
+        h = hs(zo) * torch.tanh(hs(zi) * torch.tanh(zc))
+    dh = torch.randn_like(h)
+    (h * dh).sum().backward()
+    zd, hd = dev(z.detach()), torch.zeros((N, H, W, Fh), dtype=F32, device="cuda")
+    ffi.call("seg_convlstm_gate_fwd_f32", P(zd), 4 * Fh, P(hd), Fh, N * H * W, Fh, stream())
+    dz = torch.full_like(zd, 9.0)
+    ffi.call("seg_convlstm_gate_bwd_f32", P(dev(dh)), Fh, P(zd), 4 * Fh, P(dz), N * H * W, Fh, stream())
+    torch.cuda.synchronize()
+    assert rel(val(hd, Fh), h.detach()) < 4e-6 and rel(val(dz, 4 * Fh), z.grad) < 1e-5
+    assert float(val(dz, 4 * Fh)[..., Fh:2 * Fh].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Cin,Cout,act", [(64, 1, "sigmoid"), (24, 4, "softmax"), (16, 3, None)])
+def test_output_head(Cin, Cout, act):
+    N, H, W = 2, 8, 16
+    cs = U.r8(Cin)
+    x = torch.randn(N, H, W, Cin, requires_grad=True)
+    kern = (torch.randn(1, 1, Cin, Cout) * 0.2).requires_grad_(True)
+    b = torch.randn(Cout, requires_grad=True)
+    pre = K.conv2d_same(x, kern, b)
+    y = torch.softmax(pre, -1) if act == "softmax" else K.activation(pre, act)
+    dy = torch.randn_like(y)
+    (y * dy).sum().backward()
+    xd = dev(x.detach())
+    E = np.zeros((Cout, cs), np.float32)
+    E[:, :Cin] = kern.detach().numpy().reshape(Cin, Cout).T
+    wd, bd = fdev(E), fdev(b.detach().numpy())
+    yd = torch.zeros((N, H, W, Cout), device="cuda")
+    ffi.call("seg_head_fwd_f32", P(xd), cs, Cin, N, H, W, 1, 1, P(wd), cs, P(bd), Cout, ACT[act], P(yd), stream())
+    dx = torch.zeros_like(xd)
+    dw, db = torch.zeros(Cout * cs, device="cuda"), torch.zeros(Cout, device="cuda")
+    ffi.call("seg_head_bwd_f32", P(dy.cuda().contiguous()), P(yd), P(xd), cs, Cin, N, H, W, 1, 1, P(wd), cs, Cout, ACT[act], P(dx), 0, None,
+             P(dw), P(db), None, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(yd.cpu(), y.detach()) < 2e-6 and rel(val(dx, Cin), x.grad) < 4e-6
+    assert rel(dw.reshape(Cout, cs)[:, :Cin].cpu(), kern.grad.reshape(Cin, Cout).T) < 1e-5 and rel(db.cpu(), b.grad) < 1e-5
+
+
+def test_element_granular_copies_and_the_boundary_conversions():
+    N, H, W = 2, 4, 8
+    parts = [torch.randn(N, H, W, c) for c in (5, 10, 16)]
+    dst = torch.zeros((N, H, W, 32), dtype=F32, device="cuda")
+    off = 0
+    for t in parts:                                   # materialised concatenate at element-granular channel offsets (MultiResBlock)
+        d = dev(t)
+        ffi.call("seg_copy_channels_f32", P(d), d.shape[3], 0, P(dst), 32, off, t.shape[3], N * H * W, 0, stream())
+        off += t.shape[3]
+    torch.cuda.synchronize()
+    got = U.dev_values(dst)
+    assert rel(got[..., :31], torch.cat(parts, -1)) < TOL and float(got[..., 31:].abs().max()) == 0.0
+    back = dev(torch.zeros(N, H, W, 10))
+    ffi.call("seg_copy_channels_f32", P(dst), 32, 5, P(back), 16, 0, 10, N * H * W, 0, stream())
+    x = torch.rand(N * H * W, 3)
+    xd = x.cuda()
+    packed = torch.zeros((N * H * W, 8), dtype=F32, device="cuda")
+    ffi.call("seg_pack_input_f32", P(xd), P(packed), N * H * W, 3, 8, stream())
+    out = torch.zeros((N * H * W, 3), device="cuda")
+    ffi.call("seg_unpack_f32_f32", P(packed), P(out), N * H * W, 3, 8, 0, stream())
+    torch.cuda.synchronize()
+    assert rel(val(back, 10), parts[1]) < TOL
+    assert rel(out.cpu(), x) < TOL and torch.equal(packed, U.SF.split_pack(torch.cat([xd, torch.zeros(N * H * W, 5, device="cuda")], 1)))
+
+
+def test_transposed_weight_operand_is_the_split_image_of_the_transpose():
+    rows, T, K = 24, 9, 64
+    rows_pad = 32
+    w = torch.randn(rows, T, K)
+    wt = torch.zeros(K * T * rows_pad, dtype=F32, device="cuda")
+    ffi.call("seg_transpose_w_f32", P(w.cuda().contiguous()), P(wt), rows, T, K, rows_pad, stream())
+    torch.cuda.synchronize()
+    want = torch.zeros(K, T, rows_pad)
+    want[:, :, :rows] = w.permute(2, 1, 0)
+    assert torch.equal(wt.reshape(K, T, rows_pad).cpu().view(torch.int32), U.SF.split_pack(want).view(torch.int32))
