@@ -125,8 +125,8 @@ def test_fused_tail_add_relu_statistics_and_fanout_backward():
     d1, prev = torch.zeros_like(ad), torch.randn(N, H, W, Cc)
     d2 = dev(prev)
     gp = (C.c_void_p * 4)(d1.data_ptr(), d2.data_ptr(), None, None)
-    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dev(dy)), P(y), gp, 2, 0b10, npix, cs, P(pad(gamma * invstd)), P(pad(mean)), P(pad(invstd)), P(pad(c1)), P(pad(c2)),
-             1, stream())
+    dyd, keep = dev(dy), [pad(v) for v in (gamma * invstd, mean, invstd, c1, c2)]      # (held: P() only takes the address)
+    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dyd), P(y), gp, 2, 0b10, npix, cs, *[P(t) for t in keep], 1, stream())
     torch.cuda.synchronize()
     assert rel(val(d1, Cc), want) < 2e-5 and rel(val(d2, Cc), want + prev) < 2e-5
 
@@ -141,7 +141,8 @@ def test_maxpool(pool):
     xd, yd = dev(x.detach()), torch.zeros((N, H // pool[0], W // pool[1], Cc), dtype=F32, device="cuda")
     ffi.call("seg_maxpool_fwd_f32", P(xd), P(yd), N, H, W, Cc, *pool, stream())
     dxd = torch.zeros_like(xd)
-    ffi.call("seg_maxpool_bwd_f32", P(dev(dy)), P(xd), P(yd), P(dxd), N, H, W, Cc, *pool, 0, stream())
+    dyd = dev(dy)
+    ffi.call("seg_maxpool_bwd_f32", P(dyd), P(xd), P(yd), P(dxd), N, H, W, Cc, *pool, 0, stream())
     torch.cuda.synchronize()
     assert rel(val(yd, Cc), y.detach()) < TOL and rel(val(dxd, Cc), x.grad) < TOL
 
@@ -156,7 +157,8 @@ def test_upsample(f, bil):
     xd, yd = dev(x.detach()), torch.zeros((N, H * f[0], W * f[1], Cc), dtype=F32, device="cuda")
     ffi.call("seg_upsample_fwd_f32", P(xd), P(yd), N, H, W, Cc, *f, bil, stream())
     dxd = torch.zeros_like(xd)
-    ffi.call("seg_upsample_bwd_f32", P(dev(dy)), P(dxd), N, H, W, Cc, *f, bil, 0, stream())
+    dyd = dev(dy)
+    ffi.call("seg_upsample_bwd_f32", P(dyd), P(dxd), N, H, W, Cc, *f, bil, 0, stream())
     torch.cuda.synchronize()
     assert rel(val(yd, Cc), y.detach()) < TOL and rel(val(dxd, Cc), x.grad) < 4e-6
 
@@ -174,7 +176,8 @@ def test_add_act(n, act):
     ffi.call("seg_add_act_fwd_f32", ptrs, n, P(yd), yd.numel(), ACT[act], 0.3, stream())
     gs = [torch.zeros_like(d) for d in ds]
     gp = (C.c_void_p * 4)(*([g.data_ptr() for g in gs] + [None] * (4 - n)))
-    ffi.call("seg_add_act_bwd_f32", P(dev(dy)), P(yd), gp, n, yd.numel(), ACT[act], 0.3, 0, stream())
+    dyd = dev(dy)
+    ffi.call("seg_add_act_bwd_f32", P(dyd), P(yd), gp, n, yd.numel(), ACT[act], 0.3, 0, stream())
     torch.cuda.synchronize()
     assert rel(val(yd, 16), y.detach()) < TOL
     for g, x in zip(gs, xs):
@@ -192,7 +195,8 @@ def test_attention_multiply_and_convlstm_gates():
     yd = torch.zeros_like(ad)
     ffi.call("seg_mul_bcast_fwd_f32", P(ad), P(rd), P(yd), N * H * W, Cc, 8, stream())
     da, dr = torch.zeros_like(ad), torch.zeros_like(rd)
-    ffi.call("seg_mul_bcast_bwd_f32", P(dev(dy)), P(ad), P(rd), P(da), P(dr), N * H * W, Cc, 8, 0, 0, stream())
+    dyd = dev(dy)
+    ffi.call("seg_mul_bcast_bwd_f32", P(dyd), P(ad), P(rd), P(da), P(dr), N * H * W, Cc, 8, 0, 0, stream())
     torch.cuda.synchronize()
     assert rel(val(yd, Cc), y.detach()) < TOL and rel(val(da, Cc), a.grad) < TOL and rel(val(dr, 1), r.grad) < 2e-6
     assert float(U.dev_values(dr)[..., 1:].abs().max()) == 0.0
@@ -209,7 +213,8 @@ def test_attention_multiply_and_convlstm_gates():
     zd, hd = dev(z.detach()), torch.zeros((N, H, W, Fh), dtype=F32, device="cuda")
     ffi.call("seg_convlstm_gate_fwd_f32", P(zd), 4 * Fh, P(hd), Fh, N * H * W, Fh, stream())
     dz = torch.full_like(zd, 9.0)
-    ffi.call("seg_convlstm_gate_bwd_f32", P(dev(dh)), Fh, P(zd), 4 * Fh, P(dz), N * H * W, Fh, stream())
+    dhd = dev(dh)
+    ffi.call("seg_convlstm_gate_bwd_f32", P(dhd), Fh, P(zd), 4 * Fh, P(dz), N * H * W, Fh, stream())
     torch.cuda.synchronize()
     assert rel(val(hd, Fh), h.detach()) < 4e-6 and rel(val(dz, 4 * Fh), z.grad) < 1e-5
     assert float(val(dz, 4 * Fh)[..., Fh:2 * Fh].abs().max()) == 0.0
@@ -234,7 +239,8 @@ def test_output_head(Cin, Cout, act):
     ffi.call("seg_head_fwd_f32", P(xd), cs, Cin, N, H, W, 1, 1, P(wd), cs, P(bd), Cout, ACT[act], P(yd), stream())
     dx = torch.zeros_like(xd)
     dw, db = torch.zeros(Cout * cs, device="cuda"), torch.zeros(Cout, device="cuda")
-    ffi.call("seg_head_bwd_f32", P(dy.cuda().contiguous()), P(yd), P(xd), cs, Cin, N, H, W, 1, 1, P(wd), cs, Cout, ACT[act], P(dx), 0, None,
+    dyd = dy.cuda().contiguous()
+    ffi.call("seg_head_bwd_f32", P(dyd), P(yd), P(xd), cs, Cin, N, H, W, 1, 1, P(wd), cs, Cout, ACT[act], P(dx), 0, None,
              P(dw), P(db), None, 0, stream())
     torch.cuda.synchronize()
     assert rel(yd.cpu(), y.detach()) < 2e-6 and rel(val(dx, Cin), x.grad) < 4e-6
@@ -271,7 +277,8 @@ def test_transposed_weight_operand_is_the_split_image_of_the_transpose():
     rows_pad = 32
     w = torch.randn(rows, T, K)
     wt = torch.zeros(K * T * rows_pad, dtype=F32, device="cuda")
-    ffi.call("seg_transpose_w_f32", P(w.cuda().contiguous()), P(wt), rows, T, K, rows_pad, stream())
+    wd = w.cuda().contiguous()
+    ffi.call("seg_transpose_w_f32", P(wd), P(wt), rows, T, K, rows_pad, stream())
     torch.cuda.synchronize()
     want = torch.zeros(K, T, rows_pad)
     want[:, :, :rows] = w.permute(2, 1, 0)
