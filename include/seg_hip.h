@@ -139,7 +139,8 @@ typedef struct seg_igemm_wgrad_args {
                                     per-block partial column sums of dz (the bias gradient before the 1/S scale),
                                     fp32 [2 * splitk][2][n_rows] - row (py * splitk + z), plane 0 = sum, plane 1 = 0,
                                     the layout seg_bn_bwd_finalize reduces (dgamma = NULL, dbeta = the bias gradient).
-                                    Must be NULL otherwise.                                                   */
+                                    Parity mode (_f32): variant 2 on any 4-class transposed conv, [4 * splitk][2][n_rows],
+                                    row (class * splitk + z).  Must be NULL otherwise.                        */
   int32_t overwrite;             /* variant 2 with splitk == 1 only: dw is known to hold zeros where this call writes (the
                                     engine clears the gradient buffer once per step), so the single writer of each tile
                                     stores instead of read-modify-writing - deep layers (8x8 / 16x16 images, 2048-channel

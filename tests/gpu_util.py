@@ -155,7 +155,7 @@ def igemm_wgrad(xs, dz, kshape, kind="conv", strides=(1, 1), variant=0, splitk=N
         a.partial = ws.data_ptr()
     bp = None
     if bias_parts:
-        bp = torch.full((2 * a.splitk, 2, n_rows), 1e30, dtype=torch.float32, device="cuda")
+        bp = torch.full(((4 if f32 else 2) * a.splitk, 2, n_rows), 1e30, dtype=torch.float32, device="cuda")      # per class (parity mode) / class pair
         a.bias_part = bp.data_ptr()
     ffi.call("seg_igemm_wgrad_f32" if f32 else "seg_igemm_wgrad", C.byref(a), stream())
     torch.cuda.synchronize()

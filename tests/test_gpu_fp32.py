@@ -171,3 +171,21 @@ def test_halo_kernels_in_the_parity_mode(case, tile):
         base = torch.randn(N, H, W, U.r8(cout))
         out2, _, _ = U.igemm_conv(xs, kern, None, "conv", s, None, 0.0, False, tile, accumulate_into=base, f32=True, variant=3)
         assert rel(out2, f(torch.cat(xs, -1), torch.from_numpy(kern), None, s) + base[..., :cout]) < 2e-6
+
+
+@pytest.mark.parametrize("shape,cin,cout,sk", [((2, 16, 32), 40, 24, 1), ((1, 16, 16), 64, 72, 3), ((2, 8, 8), 96, 64, 5)])
+def test_transposed_conv_weight_and_bias_gradient_from_one_launch(shape, cin, cout, sk):
+    """Parity mode, variant 2 on Conv2DTranspose(4x4, stride 2): one sub-pixel class per block, two taps per wave; the blocks of the
+    first input plane also contract dz with a ones operand - the bias gradient leaves the launch as one partial row per class and
+    patch range (seg_bn_bwd_finalize's layout).  Empty patch ranges (sk = 5 on 2 patches) write zero rows."""
+    N, H, W = shape
+    x = torch.randn(N, H, W, cin)
+    kshape = (4, 4, cout, cin)
+    kz = torch.zeros(kshape, requires_grad=True)
+    bz = torch.zeros(cout, requires_grad=True)
+    y = K.conv2d_transpose_same(x, kz, bz, (2, 2))
+    dz = torch.randn_like(y)
+    (y * dz).sum().backward()
+    got, bias = U.igemm_wgrad([x], dz, kshape, "convT", (2, 2), 2, sk, None, f32=True, bias_parts=True, partial=sk > 1)
+    assert rel(torch.from_numpy(got), kz.grad) < 1e-5
+    assert rel(bias[:cout], bz.grad) < 1e-5

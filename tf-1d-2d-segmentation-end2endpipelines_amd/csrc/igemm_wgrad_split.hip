@@ -254,8 +254,19 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
   const int npatch = g.N * PH * PW;
   const int per = (npatch + p.splitk - 1) / p.splitk;
   const int q0 = bz * per, q1 = min(npatch, q0 + per);
-  if (q0 >= q1) return;
   const int cls = TC ? bcls : 0;
+  // transposed conv: the bias gradient (column sums of dz) rides on this launch - the blocks of the first input plane contract their
+  // dz fragments with a ones operand (two more MFMAs per K block in the th = 0 waves) and write one partial row per (class, patch
+  // range), the layout seg_bn_bwd_finalize reduces - instead of a separate pass over the gradient tensor
+  const bool bias_blk = TC && p.bias_part != nullptr && seg == 0 && c0 == 0;
+  if (q0 >= q1) {
+    if (bias_blk && tid < 64 && r0 + tid < p.n_rows) {             // an empty patch range still owns its partial row
+      float* rowp = p.bias_part + ((size_t)(cls * p.splitk + bz) * 2) * p.n_rows;
+      rowp[r0 + tid] = 0.f;
+      rowp[p.n_rows + r0 + tid] = 0.f;
+    }
+    return;
+  }
   // transposed conv: this wave's two taps (halo shift index 3 (dy + 1) + dx + 1 and weight tap) - wave-uniform run-time values
   int tc_t[2] = {0, 0}, tc_w[2] = {0, 0};
   if constexpr (TC) {
@@ -343,6 +354,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; accl[t][q] = 0.f; }
 
+  const bool do_bias = bias_blk && th == 0;
+  f16v accb, accbl;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { accb[q] = 0.f; accbl[q] = 0.f; }
+  const h8 ones = h8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+
   // K block kb of a patch: image row / first column inside the patch
   auto kb_yy = [](int kb) { constexpr int KPR = C >= 16 ? C / 16 : 1; return C >= 16 ? kb / KPR : 2 * kb; };
   auto kb_xx = [](int kb) { constexpr int KPR = C >= 16 ? C / 16 : 1; return C >= 16 ? (kb % KPR) * 16 : 0; };
@@ -372,6 +389,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
     for (int kb = 0; kb < 4; ++kb) {
       const int yy = kb_yy(kb), xx0 = kb_xx(kb);
       const h8 ah = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256), al = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
+      if (do_bias) {                                                 // wave-uniform
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ones, accb, 0, 0, 0);
+        accbl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ones, accbl, 0, 0, 0);
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int t = tc_t[s];
@@ -422,6 +443,17 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
   float* dw = p.dw;
   float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
   const int fr = lane & 31, fh = lane >> 5;
+  if (do_bias && fr == 0) {          // every column of accb holds the same sums: the lanes of column 0 write the partial row
+    float* rowp = p.bias_part + ((size_t)(cls * p.splitk + bz) * 2) * p.n_rows;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+      if (row < p.n_rows) {
+        rowp[row] = accb[q] + accbl[q] * SPLIT_INV;
+        rowp[p.n_rows + row] = 0.f;
+      }
+    }
+  }
   const int kcol = c0 + fr;
   if (kcol < sc) {
     const int stride = g.T_total * p.Kpad, row0 = r0 + wm * 32;
@@ -453,7 +485,8 @@ template __global__ void igemm_wgrad_halo_split_kernel<8, true>(const seg_igemm_
 
 extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
   if (const int rc = check_wgrad_args(a, "seg_igemm_wgrad_f32")) return rc;
-  SEG_CHECK_ARG(a->bias_part == nullptr, "seg_igemm_wgrad_f32: no bias partials in the parity mode");
+  SEG_CHECK_ARG(a->bias_part == nullptr || ((a->variant & 255) == 2 && a->g.ncls == 4),
+                "seg_igemm_wgrad_f32: bias_part needs variant 2 on a 4x4 / stride-2 transposed conv (one partial row per class and patch range)");
   hipStream_t st = (hipStream_t)stream;
   if ((a->variant & 255) == 2) {
     const int pc = seg_wgrad_halo_patch(&a->g);

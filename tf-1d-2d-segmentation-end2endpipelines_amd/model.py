@@ -717,10 +717,10 @@ class ConvOp(Op):
             wg.partial = self.wg_partial.data_ptr()
         # transposed convs on the class-pair kernel: the bias gradient (column sums of dz) comes out of the weight-gradient
         # launch as per-block partial rows instead of a separate pass over dz
-        self.bias_from_wgrad = (BIAS_FROM_WGRAD and f16 and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
-                                and wgrad_halo_class_groups(self.g_fwd) == 2)
+        self.bias_from_wgrad = (BIAS_FROM_WGRAD and variant == 2 and self.bname is not None and not self.has_bn and self.kind == "convT"
+                                and (wgrad_halo_class_groups(self.g_fwd) == 2 if f16 else self.g_fwd.ncls == 4))
         if self.bias_from_wgrad:
-            self.wg_bias_parts = 2 * sk
+            self.wg_bias_parts = (2 if f16 else 4) * sk          # one partial row per class pair (fp16) / class (parity mode) and patch range
             self.wg_bpart = torch.zeros(self.wg_bias_parts * 2 * self.n_rows, dtype=torch.float32, device=_dev())
             wg.bias_part = self.wg_bpart.data_ptr()
         self.wg_args = wg
