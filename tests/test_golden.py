@@ -1,5 +1,5 @@
 """tests/golden/oracle_vectors.npz: regression vectors of the oracle (see tests/golden/make_golden.py - oracle outputs,
-not reference outputs; parity stays unpinned).  CPU: the oracle still reproduces them.  GPU: the HIP path in exact-fp32
+not reference outputs; parity stays unpinned).  CPU: the oracle still reproduces them.  GPU: the HIP path in the parity
 mode reproduces the model-level vectors within the north-star tolerance."""
 import os
 

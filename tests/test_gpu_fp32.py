@@ -32,7 +32,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("tile", [(128, 128), (64, 64), (128, 64), (256, 64)])
-def test_conv_fwd_fp32_is_an_fp32_fma_chain(tile):
+def test_conv_fwd_parity_mode_per_tap_kernels(tile):
     xs = [torch.randn(2, 16, 16, 24), torch.randn(2, 16, 16, 40)]
     kern = rng.standard_normal((3, 3, 64, 72)).astype(np.float32) * 0.1
     b = rng.standard_normal(72).astype(np.float32)

@@ -107,7 +107,7 @@ def test_baseline_config_at_its_own_size(cfg):
     oracle = U.oracle_run(model32.graph, w, x, targets, loss)
     deep = lambda name: any(name.startswith(p) for p in ("latent", "enc6", "enc5", "X41", "X4", "dec0", "bottleneck"))
 
-    # ---- exact mode: the north star as written
+    # ---- parity mode: the north star as written
     r = U.compare_model(model32, x, targets, loss, oracle=oracle)
     worst_node = max(((e / max(1.0, m)), nm) for nm, e, m in r["nodes"])
     _record(cfg, "f32", {"out_err": r["outs"], "out_mag": r["out_mag"], "worst_node_rel": worst_node[0], "worst_node": worst_node[1],
@@ -163,7 +163,7 @@ def test_baseline_config_at_its_own_size(cfg):
     # channels, batch 1, random initialisation) is the fragile one: a third of its tensors lose more than 10 % of the
     # direction to fp16 operand rounding - the CPU oracle run with the same operand rounding differs from the GPU by half as
     # much as either differs from fp32 (tools: gpurun_out/fullsize_report.json) - so only its large tensors are held, loosely;
-    # the exact mode above is the one that carries parity for that configuration
+    # the parity mode above is the one that carries parity for that configuration
     cut, floor = {"C1": (1e-3, 0.70), "C4": (1e-2, 0.50)}.get(cfg, (1e-3, 0.90))
     sizes = {k: int(np.prod(v.shape)) for k, v in w.items()}
     for k, (cos, ratio, mag) in r["gcos"].items():

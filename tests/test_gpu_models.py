@@ -1,7 +1,7 @@
 """GPU parity tests, model level, through the reference's builder API (unet_model_builder / UNet1D) and the C ABI.
 
 Two references per model (both from the oracle's primitives, tests/ir_interp.py):
-  * fp32 oracle  - the north-star comparison, here for the f16-MFMA mode (the exact-fp32 mode is held to 1e-3 /
+  * fp32 oracle  - the north-star comparison, here for the f16-MFMA mode (the parity mode, dtype f32, is held to 1e-3 /
     bit-exact masks in test_gpu_fp32.py).  fp16 has a 2^-11 relative rounding step per stored activation, so the
     bound is 1e-2 x max(1, |ref|) on every output (measured: 1e-3 .. 2e-3 on sigmoid/softmax maps of the 2D
     models, up to 1.3e-2 on un-normalised linear 1D regression heads); masks (threshold 0.5 / channel arg-max,
@@ -30,7 +30,7 @@ from oracle.train_ref import KerasOptimizer, KerasAdam, loss_and_grads
 OUT_TOL = 1e-2
 # MultiRes models stack BatchNormalization on BatchNormalization over 5..16-channel tensors; channels whose batch
 # mean is large against their standard deviation amplify the fp16 rounding of the stored pre-BN value by mean/sigma
-# (DESIGN.md section 3), so the f16-mode bound is looser there.  The exact mode (test_gpu_fp32.py) is unaffected.
+# (DESIGN.md section 3), so the f16-mode bound is looser there.  The parity mode (test_gpu_fp32.py) is unaffected.
 OUT_TOL_CASE = {"multiresunet_ag_bce": 3e-2, "multiresunet_alpha167_ds_mse": 3e-2, "multiresunet1d_mse": 3e-2}
 
 

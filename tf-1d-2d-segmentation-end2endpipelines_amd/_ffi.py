@@ -122,7 +122,7 @@ _PROTOS = {
     "seg_unpack_f32": ([vp, vp, i64, i32, i32, i32, vp], C.c_int),
 }
 
-# entry points that touch activation tensors exist twice: fp16 (throughput mode) and *_f32 (exact-fp32 parity mode)
+# entry points that touch activation tensors exist twice: fp16 (throughput mode) and *_f32 (parity mode: split fp16 pairs, 4 B per element)
 DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
         "seg_add_act_bwd", "seg_add_act_stats_fwd", "seg_bn_bwd_apply_fanout", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",

@@ -90,7 +90,8 @@ class KernelProfile:
 
 
 class _Mode:
-    """Storage / MFMA operand type of the model currently executing: '' = fp16 (throughput mode), '_f32' = exact fp32."""
+    """Storage / MFMA operand type of the model currently executing: '' = fp16 (throughput mode), '_f32' = the parity mode (tensors
+    stored as split fp16 pairs, three MFMAs per product)."""
     sfx = ""
 
 
@@ -1290,8 +1291,9 @@ class PoolOp(Op):
 # ------------------------------------------------------------------------------------------------ model
 class SegModel:
     def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0, dtype: str = "f16"):
-        """dtype: 'f16' = fp16 activations / MFMA operands with fp32 accumulation (throughput mode);
-        'f32' = everything fp32 on v_mfma_f32_32x32x2_f32 (exact parity mode, 1/16 of the MFMA rate)."""
+        """dtype: 'f32' = the parity mode - tensors stored as split fp16 pairs (x ~= hi + lo / 2048, ~22 significant bits), every
+        product three fp16 MFMAs into fp32 accumulators: outputs within 1e-3 of the reference's fp32 arithmetic, equal masks;
+        'f16' = fp16 activations / MFMA operands with fp32 accumulation (throughput mode: 2.3x faster, misses the 1e-3 tolerance)."""
         if dtype not in ("f16", "f32"):
             raise ValueError("dtype must be 'f16' or 'f32'")
         self.graph = graph
