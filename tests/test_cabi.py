@@ -114,7 +114,7 @@ def test_no_gpu_no_model():
     import segamd
     m = segamd.unet_model_builder("UNet", 32, 32, 8, 2, train_mode="from_scratch").ResNet50()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        m.build(1)
+        m.build(1, dtype="f16")
 
 
 def test_workspace_queries_agree_with_the_engines_own_sizing(built):

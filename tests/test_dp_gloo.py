@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
         M._DryRun.on = True
         m = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
         m.seed = rank                                   # different initial weights per rank ...
-        m.build(2)
+        m.build(2, dtype="f16")
         before = m.store.P.clone()
         d = dp.DataParallel(m, bucket_elems=1 << 16, overlap=False)
         gathered = [torch.zeros_like(m.store.P) for _ in range(world)]
@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
         ok3 = bool((m.store.G == 3.0).all()) and m.world_size == world and "seg_adam_step_ex" in M._DryRun.log
         # 3. overlapped exchange: the backward sweep hands over op-aligned slices as they become final
         m2 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
-        m2.build(2)
+        m2.build(2, dtype="f16")
         d2 = dp.DataParallel(m2, bucket_elems=20000, overlap=True, grad_dtype="f32")
         bk = m2.grad_buckets()
         tiles = bk[0][0] == 0 and bk[-1][1] == m2.store.n_train and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
@@ -80,7 +80,7 @@ def _worker(rank, world, port, q):
         #    runs on the bf16 image, the optimiser reads its gradient from there.  The optimiser state of a model that has
         #    already taken steps travels with the weights.
         m3 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
-        m3.build(2)
+        m3.build(2, dtype="f16")
         m3.adam_t, m3.lr = (7, 3e-4) if rank == 0 else (0, 1e-3)
         m3.store.M.fill_(float(rank + 5))
         d3 = dp.DataParallel(m3, bucket_elems=20000)
@@ -139,7 +139,7 @@ def test_bucket_holds_follow_the_queue_model():
     M._DryRun.on = True
     try:
         m = pkg.unet_model_builder("UNetPP", 32, 32, 16, 3, ds=1, train_mode="from_scratch").ResNet50()
-        m.build(2)
+        m.build(2, dtype="f16")
         m.bucket_elems = 20000
         assert m.bucket_holds() == [False] * len(m.grad_buckets())            # one rank: nothing to hold
         m.world_size = 8

@@ -108,7 +108,7 @@ def margin(p):
 def test_model_forward_backward_parity(name):
     torch.manual_seed(7)
     model, x, targets, loss = CASES[name]()
-    model.build(x.shape[0])
+    model.build(x.shape[0], dtype="f16")
     r32 = U.compare_model(model, x, targets, loss, emulate_fp16=False)
     r16 = U.compare_model(model, x, targets, loss, emulate_fp16=True)
     # ---- forward, vs the fp32 oracle
@@ -135,7 +135,7 @@ def test_masks_match_reference_rule(name):
     """2DCNN/Test.py:161-176: predict (inference-mode BN) -> threshold 0.5; multi-class: channel arg-max."""
     torch.manual_seed(3)
     model, x, targets, loss = CASES[name]()
-    model.build(x.shape[0])
+    model.build(x.shape[0], dtype="f16")
     for _ in range(2):                                       # make the moving statistics non-trivial
         model.train_step(x, targets, loss)
     assert model.nonfinite_updates() == 0                    # the optimiser skipped nothing (no fp16 overflow in the backward pass)
@@ -154,7 +154,7 @@ def test_train_steps_follow_the_oracle():
     torch.manual_seed(11)
     kw = dict(ds=1)
     model = B("UNetPP", 32, 32, 16, 2, num_channels=3, **kw)
-    model.build(2)
+    model.build(2, dtype="f16")
     model.compile(loss="mse", lr=1e-3)
     x = torch.rand(2, 32, 32, 3)
     tg = [(torch.rand(2, 32, 32, 1) > 0.5).float()] * 3
@@ -182,7 +182,7 @@ def test_registry_loss_with_loss_weights_follows_the_oracle():
     torch.manual_seed(5)
     kw = dict(ds=1)
     model = B("UNetPP", 32, 32, 16, 2, num_channels=3, **kw)
-    model.build(2)
+    model.build(2, dtype="f16")
     lw = [1.0, 0.9, 0.8]
     model.compile(loss="MeanSquaredLogarithmicError", lr=1e-3, loss_weights=lw)
     x = torch.rand(2, 32, 32, 3)

@@ -32,7 +32,7 @@ def step(m, x):
 
 def test_unetpp_fusion_counts():
     d = 3
-    m = B("UNetPP", 32, 32, 16, d, ds=1).build(2)
+    m = B("UNetPP", 32, 32, 16, d, ds=1).build(2, dtype="f16")
     c = step(m, torch.rand(2, 32, 32, 3))
     nodes = d * (d + 1) // 2
     convs = (d + 1) + 2 + nodes                      # encoder + latent(2) + nested nodes, every one conv+BN+ReLU fused
@@ -79,7 +79,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     of the BN that follows; that BN's backward writes the masked gradient to the add's inputs.  Against the unfused lowering: no
     seg_add_act_fwd / seg_add_act_bwd, one seg_bn_stats and one seg_bn_act_apply fewer per fused BN / folded BN."""
     def counts():
-        m = B("MultiResUNet", 32, 32, 16, 2, alpha=1.0).build(2)
+        m = B("MultiResUNet", 32, 32, 16, 2, alpha=1.0).build(2, dtype="f16")
         c = step(m, torch.rand(2, 32, 32, 3))
         tails = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.fused_add is not None)
         folded = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.folded_into is not None)
@@ -96,7 +96,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
 
 
 def test_accumulate_flags_follow_consumer_count():
-    m = B("UNetPP", 32, 32, 16, 2, ds=0).build(2)
+    m = B("UNetPP", 32, 32, 16, 2, ds=0).build(2, dtype="f16")
     step(m, torch.rand(2, 32, 32, 3))
     acc = {}
     for op in m.ops:
@@ -117,7 +117,7 @@ def test_accumulate_flags_follow_consumer_count():
                                 lambda: segamd.UNet1D(64, 2, 1, 16, 3, ds=1, ag=1).UNet(),
                                 lambda: segamd.BCDUNet(64, 2, 1, 16, 3, lstm=1, dense_loop=2).BCDUNet()])
 def test_weight_layout_roundtrip(mk):
-    m = mk().build(2)
+    m = mk().build(2, dtype="f16")
     w = m.get_weights()
     specs = {p.name: p.shape for p in m.graph.param_specs()}
     assert {k: v.shape for k, v in w.items()} == specs
@@ -161,11 +161,11 @@ def test_pack_gemm_weight_places_segments():
 
 def test_unsupported_layers_say_so():
     m = B("UNet", 32, 32, 8, 2, ae=1, feature_number=16)             # the autoencoder bottleneck lowers to two 1x1-image GEMMs
-    m.build(2)
+    m.build(2, dtype="f16")
     kinds = [type(o).__name__ for o in m.ops]
     assert kinds.count("ReshapeOp") == 2 and m.store.slots["ae/features/kernel"].spec.shape == (8 * 8 * 32, 16)
     with pytest.raises(NotImplementedError, match="ConvLSTM filters"):
-        B("UNet", 32, 32, 8, 2, lstm=1).build(2)
+        B("UNet", 32, 32, 8, 2, lstm=1).build(2, dtype="f16")
 
 
 def test_parity_mode_tiles_have_a_kernel_instance():

@@ -1290,7 +1290,7 @@ class PoolOp(Op):
 
 # ------------------------------------------------------------------------------------------------ model
 class SegModel:
-    def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0, dtype: str = "f16"):
+    def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0, dtype: str = "f32"):
         """dtype: 'f32' = the parity mode - tensors stored as split fp16 pairs (x ~= hi + lo / 2048, ~22 significant bits), every
         product three fp16 MFMAs into fp32 accumulators: outputs within 1e-3 of the reference's fp32 arithmetic, equal masks;
         'f16' = fp16 activations / MFMA operands with fp32 accumulation (throughput mode: 2.3x faster, misses the 1e-3 tolerance)."""

@@ -114,7 +114,7 @@ def sec_wgrad():
 @guard
 def model_case(tag, model, x, targets, loss, fwd_tol=2e-3, grad_tol=3e-2):
     t0 = time.time()
-    model.build(x.shape[0])
+    model.build(x.shape[0], dtype="f16")
     res32 = U.compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False)
     report(f"model {tag} vs FP32 oracle: forward outs", max(res32["outs"]), 5e-3)
     print("   fp32-oracle outs err", ["%.3e" % e for e in res32["outs"]], " worst pgrad rel", "%.3e" % U.grad_rel_err(res32))
