@@ -189,3 +189,38 @@ def test_transposed_conv_weight_and_bias_gradient_from_one_launch(shape, cin, co
     got, bias = U.igemm_wgrad([x], dz, kshape, "convT", (2, 2), 2, sk, None, f32=True, bias_parts=True, partial=sk > 1)
     assert rel(torch.from_numpy(got), kz.grad) < 1e-5
     assert rel(bias[:cout], bz.grad) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["multiresunet_ag_bce", "multiresunet1d_mse"])
+def test_fused_bn_tails_equal_the_separate_passes(name, monkeypatch):
+    """MultiResBlock / ResPath tails BN(ReLU(a + b)) as fused passes (SegModel._fuse_bn_tail) against the separate add / BN passes
+    (SEG_FUSE_BN_TAILS=0): the same training step (loss, every parameter gradient) and the same predictions (inference-mode BN: the
+    folded BatchNormalization takes its coefficients from the moving statistics) to rounding."""
+    M = U.M
+    torch.manual_seed(5)
+    m1, x, targets, loss = CASES[name]()
+    m1.build(x.shape[0], dtype="f32")
+    assert any(isinstance(o, M.BNOp) and o.fused_add is not None for o in m1.ops)
+    w = m1.get_weights()
+    monkeypatch.setattr(M, "FUSE_BN_TAILS", False)
+    m0, _x, _t, _l = CASES[name]()
+    m0.build(x.shape[0], dtype="f32")
+    m0.set_weights(w)
+    assert not any(isinstance(o, M.BNOp) and o.fused_add is not None for o in m0.ops)
+    res = []
+    for m in (m1, m0):
+        m.forward(x, training=True)
+        lv = float(m.compute_loss(targets, loss).cpu())
+        m.backward(None)
+        g = m.get_grads()
+        m.optimizer_step()
+        m._join_side()
+        res.append((lv, g, m.predict(x)))
+    (l1, g1, p1), (l0, g0, p0) = res
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0))
+    gmax = max(float(np.abs(v).max()) for v in g0.values())
+    for k in g0:
+        assert float(np.abs(g1[k] - g0[k]).max()) < 2e-4 * (float(np.abs(g0[k]).max()) + 1e-3 * gmax), k
+    p1, p0 = (p1 if isinstance(p1, list) else [p1]), (p0 if isinstance(p0, list) else [p0])
+    for a, b in zip(p1, p0):
+        assert float(np.abs(a - b).max()) < 1e-5 * max(1.0, float(np.abs(b).max()))
