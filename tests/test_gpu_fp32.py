@@ -141,14 +141,17 @@ def test_range_of_the_split_pair_format_is_loud_not_silent():
     assert rel(out3, ref3) < 2e-4
 
 
-@pytest.mark.parametrize("tile", [(256, 64)])
+@pytest.mark.parametrize("tile", [(256, 64), (256, 32)])
 @pytest.mark.parametrize("case", [
     dict(kind="conv", shape=(2, 16, 32), cins=[24, 40], cout=72),       # 8x32 patches, virtual concat, two N blocks (the second ragged)
     dict(kind="conv", shape=(2, 32, 16), cins=[64], cout=64),           # 16x16 patches
     dict(kind="convT", shape=(2, 16, 32), cins=[40], cout=24),          # four sub-pixel classes of 2x2 taps
+    dict(kind="conv", shape=(2, 16, 32), cins=[8, 17], cout=26),        # MultiResUNet widths: one ragged 32-channel tile
+    dict(kind="conv", shape=(1, 16, 16), cins=[51], cout=8),
 ], ids=lambda c: f"{c['kind']}-{c['shape']}-{c['cins']}->{c['cout']}")
 def test_halo_kernels_in_the_parity_mode(case, tile):
-    """variant 3 with split-pair tensors (256 x 64 tile): bias, ReLU / LeakyReLU, BN partial statistics, accumulate.
+    """variant 3 with split-pair tensors (256 x 64 tile; 256 x 32: one 32-channel tile per wave, what pick_fwd takes for layers of at
+    most 32 output channels - here also on wider ones): bias, ReLU / LeakyReLU, BN partial statistics, accumulate.
     (A two-patches-per-block form - 8 waves against one weight stream, 512 x 64 - was built and measured in round 3: correct, but
     31.9 instead of 30.4 ms over the forward / data-gradient launches of a C3 step and 54.1 instead of 50.9 ms per step: one
     barrier domain of 8 waves loses more than the halved weight traffic gains.  Not kept.)"""

@@ -13,20 +13,25 @@ namespace {
 // traffic per MFMA 2-3x and, with TG = 3, the barriers per MFMA 3x against the per-tap kernel above.
 // Waves: BN = 128: 2 (M) x 2 (N), each 128 px x 64 channels; BN = 64: 4 x 1, each 64 px x 64 channels.
 // ---------------------------------------------------------------------------------------------------------
-// Parity mode (SPLIT, BN = 64 only): the tensors are split pairs and the loaders see twice the channels (igemm_common.h), so a
+// Parity mode (SPLIT, BN = 64 or 32): the tensors are split pairs and the loaders see twice the channels (igemm_common.h), so a
 // "32-channel chunk" is 16 real channels as hi / lo 16-B chunks; per tap and tile pair three MFMAs into two accumulator sets.
+// BN = 32 (parity mode, layers of at most 32 output channels - MultiResUNet's 8 / 17 / 26-filter convs at full resolution): the
+// weight stage keeps its 64 rows (the upper 32 are out of range and cost no memory traffic), a wave owns 64 px x ONE 32-channel
+// tile - half the MFMAs and B-fragment reads of the 64-channel tile, whose upper half would multiply zeros.
 template <int PW, int BN, int NT, int TG, int NPL, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(!SPLIT || BN == 64, "parity mode: 64 x 64 accumulators per wave, twice");
+  static_assert(SPLIT ? (BN == 64 || BN == 32) : (BN == 64 || BN == 128), "parity mode: 64 x 64 (or 64 x 32) accumulators per wave, twice");
   typedef std::conditional_t<SPLIT, split_t, half_t> TO;
   constexpr int PH = 256 / PW, HC = PW + 2, HROWS = (PH + 2) * HC;
   constexpr int NI_A = (HROWS + 15) / 16;                  // LDS-DMA wave instructions per halo tile (16 rows of 64 B)
   constexpr int NA_HI = (NI_A + 3) / 4, NA_REM = NI_A % 4;  // per wave: NA_HI for waves < NA_REM (all when NA_REM == 0), else NA_HI - 1
   constexpr int A_BYTES = NI_A * 1024;
-  constexpr int B_BYTES = TG * BN * 64, NB_W = B_BYTES / 4096;     // weight stage, wave instructions per wave and stage
+  constexpr int BROWS = BN < 64 ? 64 : BN;                 // rows of a weight stage
+  constexpr int B_BYTES = TG * BROWS * 64, NB_W = B_BYTES / 4096;  // weight stage, wave instructions per wave and stage
   constexpr int NSTEP = NT / TG;
-  constexpr int WMv = BN == 64 ? 4 : 2, WNv = 4 / WMv, TMw = 8 / WMv;   // A tiles (32 px) per wave; 2 B tiles (64 channels) per wave
+  constexpr int WMv = BN <= 64 ? 4 : 2, WNv = 4 / WMv, TMw = 8 / WMv;   // A tiles (32 px) per wave
+  constexpr int TNw = BN == 32 ? 1 : 2;                    // B tiles (32 channels) per wave
   static_assert(TG * NSTEP == NT && NSTEP >= 2 && NB_W * 4096 == B_BYTES, "tap groups / weight stage");
   static_assert(NPL == 1 || (NPL == 4 && NT == 4), "parity planes: the data gradient of the 4x4 / stride-2 transposed conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -89,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
 #pragma unroll
     for (int j = 0; j < NB_W; ++j) {
       const int r = (j * 4 + wave) * 16 + lrow;            // row inside the stage: tap-in-group * BN + channel row
-      const int tt = r / BN, row = r - tt * BN;
+      const int tt = r / BROWS, row = r - tt * BROWS;
       b_tap[j] = __builtin_amdgcn_readfirstlane(tt);
       const int gch = lch ^ ((row >> 2) & 3);
-      b_voff[j] = (n0 + row < p.n_rows) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
+      b_voff[j] = (row < BN && n0 + row < p.n_rows) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
     }
   }
   auto uniform_ptr = [](const void* q) -> void* {
@@ -147,19 +152,19 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
     }
   };
 
-  f16v acc[TMw][2];
+  f16v acc[TMw][TNw];
 #pragma unroll
   for (int a = 0; a < TMw; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TNw; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-  f16v accl[SPLIT ? TMw : 1][SPLIT ? 2 : 1];
+  f16v accl[SPLIT ? TMw : 1][SPLIT ? TNw : 1];
   if constexpr (SPLIT) {
 #pragma unroll
     for (int a = 0; a < TMw; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < TNw; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) accl[a][b][q] = 0.f;
   }
@@ -173,9 +178,9 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
     const int yy = PW == 32 ? wm * TMw + a : (wm * TMw + a) * 2;
     arow[a] = (yy + 1) * HC + 1;
   }
-  int boff[2][2];     // weight rows are tile-aligned: the swizzle depends on fr only
+  int boff[TNw][2];     // weight rows are tile-aligned: the swizzle depends on fr only
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < TNw; ++b)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) boff[b][ks] = lds_off(wn * 64 + b * 32 + fr, SPLIT ? 2 * fh + ks : ks * 2 + fh);      // (split: ks = 0 hi, 1 lo)
 
@@ -195,21 +200,21 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
         o0[a] = (row << 6) + (((SPLIT ? 2 * fh : fh) ^ ((row >> 2) & 3)) << 4);
       }
       if constexpr (SPLIT) {
-        h8 ah[TMw], al[TMw], bh[2], bl[2];
+        h8 ah[TMw], al[TMw], bh[TNw], bl[TNw];
 #pragma unroll
         for (int a = 0; a < TMw; ++a) {
           ah[a] = *reinterpret_cast<const h8*>(A + o0[a]);
           al[a] = *reinterpret_cast<const h8*>(A + (o0[a] ^ 16));
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          bh[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][0]);
-          bl[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][1]);
+        for (int b = 0; b < TNw; ++b) {
+          bh[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][0]);
+          bl[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][1]);
         }
 #pragma unroll
         for (int a = 0; a < TMw; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
+          for (int b = 0; b < TNw; ++b) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
             accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], accl[a][b], 0, 0, 0);
             accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
@@ -217,15 +222,15 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
       } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          h8 af[TMw], bf[2];
+          h8 af[TMw], bf[TNw];
 #pragma unroll
           for (int a = 0; a < TMw; ++a) af[a] = *reinterpret_cast<const h8*>(A + (o0[a] ^ (ks * 32)));
 #pragma unroll
-          for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const h8*>(B + tt * (BN * 64) + boff[b][ks]);
+          for (int b = 0; b < TNw; ++b) bf[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][ks]);
 #pragma unroll
           for (int a = 0; a < TMw; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < TNw; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
       }
     }
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   }
   __syncthreads();
   if constexpr (SPLIT) split_combine(acc, accl);
-  conv_epilogue<TO, TMw, 2, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, cls, npatch, mb, 0, 0, pn, y0, x0);
+  conv_epilogue<TO, TMw, TNw, WMv, BN, PW>(p, acc, smem, tid, PW == 32 ? wm * TMw : wm * TMw * 2, wn * 64, n0, wm, cls, npatch, mb, 0, 0, pn, y0, x0);
 #endif
 }
 template __global__ void igemm_fwd3_kernel<32, 128, 9, 1, 1>(const seg_igemm_fwd_args);
@@ -317,6 +322,12 @@ template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 1, true>(const seg_igem
 template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 1, true>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 9, 3, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 9, 3, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 4, 2, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 1, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 4, 2, 4, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 4, true>(const seg_igemm_fwd_args);
 
 }  // namespace
 
@@ -407,23 +418,28 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   return SEG_OK;
 }
 
-// ---- parity mode: `v` is the split view of the arguments (igemm_common.h: the loaders' pseudo-channels); 256 x 64 tiles only
+// ---- parity mode: `v` is the split view of the arguments (igemm_common.h: the loaders' pseudo-channels); 256 x 64 and 256 x 32 tiles
 template <int NT, int TG, int NPL>
 static void launch_fwd3_split_nt(const seg_igemm_fwd_args& v, int pw, dim3 grid, hipStream_t st) {
   const int ni_a = pw == 32 ? 22 : 21;
   const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (TG * 4096);
+  if (v.tile_n == 32) {
+    if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 32, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
+    else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 32, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
+    return;
+  }
   if (pw == 32) hipLaunchKernelGGL((igemm_fwd3_kernel<32, 64, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
   else hipLaunchKernelGGL((igemm_fwd3_kernel<16, 64, NT, TG, NPL, true>), grid, dim3(256), lds, st, v);
 }
 int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st) {
   const int pw = seg_fwd_halo_patch(&v.g);
   SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd_f32: variant 3 needs a stride-1 3x3 'same' conv, a 4x4 / stride-2 transposed conv (or the data gradient of either), and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
-  SEG_CHECK_ARG(v.tile_m == 256 && v.tile_n == 64, "seg_igemm_fwd_f32: the variant 3 tile is 256x64, not %dx%d", v.tile_m, v.tile_n);
+  SEG_CHECK_ARG(v.tile_m == 256 && (v.tile_n == 64 || v.tile_n == 32), "seg_igemm_fwd_f32: the variant 3 tiles are 256x64 and 256x32, not %dx%d", v.tile_m, v.tile_n);
   const long pix = (long)v.g.N * v.g.Hin * v.g.Win;
   for (int s = 0; s < v.nseg; ++s) SEG_CHECK_ARG(pix * v.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
   SEG_CHECK_ARG((long)v.n_rows * v.g.T_total * v.Kpad * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
   const int npatch = (int)((long)v.g.N * v.g.Hl * v.g.Wl / 256);
-  const int nblocks = (v.n_rows + 63) / 64;
+  const int nblocks = (v.n_rows + v.tile_n - 1) / v.tile_n;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)v.g.ncls, 1);
   if (v.g.ntaps == 16) launch_fwd3_split_nt<4, 2, 4>(v, pw, grid, st);
   else if (v.g.ntaps == 9) launch_fwd3_split_nt<9, 3, 1>(v, pw, grid, st);

@@ -345,6 +345,8 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     tile is 256 x 64 only and the per-tap LDS-DMA kernel has no 64-deep K step."""
     if FWD_HALO and fwd_halo_patch(g):
         tn = 64 if (n_rows <= 64 or not f16) else 128
+        if not f16 and n_rows <= 32 and FWD_HALO_NARROW:
+            tn = 32           # parity mode, at most 32 output channels: one 32-channel tile per wave (half the MFMAs of the 64-channel tile)
         # (parity mode: the halo kernel wins down to half a block per CU - same-box A/B of the threshold, 384 against 128 blocks:
         # C3 50.05 -> 49.8 ms, C2 17.20 -> 16.78 ms per step)
         if g.ncls * (M // 256) * _cdiv(n_rows, tn) >= (FWD_HALO_MIN_BLOCKS if f16 else FWD_HALO_MIN_BLOCKS_F32):
@@ -403,6 +405,7 @@ def wgrad_halo_class_groups(g: Geom) -> int:
     return 2
 
 
+FWD_HALO_NARROW = os.environ.get("SEG_FWD_HALO_NARROW", "1") != "0"    # parity mode: the 256 x 32 halo tile for layers of <= 32 output channels
 WGRAD_FORK_EARLY = os.environ.get("SEG_WGRAD_FORK_EARLY", "1") != "0"   # side stream forks when dz is final, before the op's data gradients are enqueued
 HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
