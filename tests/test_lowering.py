@@ -170,16 +170,17 @@ def test_unsupported_layers_say_so():
 
 def test_parity_mode_tiles_have_a_kernel_instance():
     """pick_fwd in the parity mode (split-pair tensors) returns only what csrc has an instance for: the halo tile is 256 x 64
-    (two accumulator sets per wave rule out 128 output channels), everything else the per-tap kernels' tiles."""
+    (two accumulator sets per wave rule out 128 output channels) or, for at most 32 output channels, 256 x 32; everything else the
+    per-tap kernels' tiles."""
     g = M.geom_conv(16, 256, 256, 3, 3, 1, 1)
     tiles0 = {(256, 64), (128, 128), (128, 64), (64, 128), (64, 64)}
     seen = set()
     for Mtot in (1024, 4096, 16384, 65536, 262144, 1048576):
-        for n_rows in (8, 64, 128, 384, 2048):
+        for n_rows in (8, 32, 40, 64, 128, 384, 2048):
             for ktot in (288, 1152, 18432):
                 tm, tn, variant = M.pick_fwd(Mtot, n_rows, g, ktot, False)
-                assert (variant == 3 and (tm, tn) == (256, 64)) or (variant == 0 and (tm, tn) in tiles0)
+                assert (variant == 3 and (tm, tn) == ((256, 32) if n_rows <= 32 else (256, 64))) or (variant == 0 and (tm, tn) in tiles0)
                 seen.add((tm, tn, variant))
-    assert (256, 64, 3) in seen and any(v == 0 for _a, _b, v in seen)       # large levels: halo tiles; small grids: per-tap kernels
+    assert {(256, 64, 3), (256, 32, 3)} <= seen and any(v == 0 for _a, _b, v in seen)       # large levels: halo tiles; small grids: per-tap kernels
     g1 = M.geom_conv(16, 256, 256, 1, 1, 1, 1)                               # 1x1: never the halo kernel
     assert all(M.pick_fwd(Mt, n, g1, 512, False)[2] == 0 for Mt in (4096, 1048576) for n in (8, 64, 384))
