@@ -176,7 +176,28 @@ def test_halo_kernels_in_the_parity_mode(case, tile):
         assert rel(out2, f(torch.cat(xs, -1), torch.from_numpy(kern), None, s) + base[..., :cout]) < 2e-6
 
 
-@pytest.mark.parametrize("shape,cin,cout,sk", [((2, 16, 32), 40, 24, 1), ((1, 16, 16), 64, 72, 3), ((2, 8, 8), 96, 64, 5)])
+@pytest.mark.parametrize("shape,cins,cout,sk,partial", [
+    ((2, 16, 32), [24, 40], 72, 3, True),       # 4x16 patches, two concat segments, two row tiles (the second ragged)
+    ((2, 16, 32), [8, 17], 26, 2, True),        # <= 32 output channels: the four waves split the taps (NARROW)
+    ((1, 8, 32), [51], 8, 1, False),            # ... one patch range, accumulating into dw
+    ((2, 8, 8), [40], 17, 2, True),             # 8x8 patches
+    ((1, 6, 32), [64], 32, 1, False),           # 2x32 patches
+])
+def test_halo_weight_gradient_in_the_parity_mode(shape, cins, cout, sk, partial):
+    """Variant 2 on a 3x3 / stride-1 conv with split-pair tensors: 64 output channels x one 32-channel plane x all taps per block,
+    waves = (row tile) x (tap half); at most 32 output channels: waves = four tap groups, tap 8 shared by K blocks."""
+    N, H, W = shape
+    xs = [torch.randn(N, H, W, c) for c in cins]
+    kshape = (3, 3, sum(cins), cout)
+    kz = torch.zeros(kshape, requires_grad=True)
+    y = K.conv2d_same(torch.cat(xs, -1), kz, None)
+    dz = torch.randn_like(y)
+    (y * dz).sum().backward()
+    got = U.igemm_wgrad(xs, dz, kshape, "conv", (1, 1), 2, sk, None, f32=True, partial=partial, prefill=0.0 if partial else 0.25)
+    assert rel(torch.from_numpy(got), kz.grad + (0.0 if partial else 0.25)) < 1e-5
+
+
+@pytest.mark.parametrize("shape,cin,cout,sk", [((2, 16, 32), 40, 24, 1), ((1, 16, 16), 64, 72, 3), ((2, 8, 8), 96, 64, 5), ((2, 8, 32), 24, 32, 2)])
 def test_transposed_conv_weight_and_bias_gradient_from_one_launch(shape, cin, cout, sk):
     """Parity mode, variant 2 on Conv2DTranspose(4x4, stride 2): one sub-pixel class per block, two taps per wave; the blocks of the
     first input plane also contract dz with a ones operand - the bias gradient leaves the launch as one partial row per class and

@@ -215,20 +215,24 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_split_kernel(const seg_ige
 //   halo rows are half a bank row: the row's parity picks the half, ((r >> 1) & 1) swaps hi and lo chunks (slot s holds chunk
 //     s ^ ((r >> 1) & 1)) - four consecutive rows at any tap shift hit 16 distinct slots.
 // With LDS-DMA the LDS image is lane-linear, so the permutation is applied to the chunk a lane FETCHES and undone on the read.
+// NARROW (layers of at most 32 output channels - MultiResUNet's full-resolution convs): the upper row tile would contract zeros, so
+// the four waves split the TAPS instead: wave w owns taps 2 w and 2 w + 1 and K block w of tap 8 (the four partial sums of tap 8
+// meet in LDS at the end, added in wave order) - 9 MFMA triples per wave and patch instead of 18; a transposed-conv class gives
+// each wave one of its four taps.
 // ---------------------------------------------------------------------------------------------------------
-template <int C, bool TC>
+template <int C, bool TC, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const seg_igemm_wgrad_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int R = 64 / C, HC = C + 2, HROWS = (R + 2) * HC;
   constexpr int NI_IN = (HROWS + 7) / 8;                  // LDS-DMA wave instructions per halo tile (8 rows of 128 B each)
   constexpr int NI_W = (NI_IN + 3) / 4;                   // ... per wave
   constexpr int Z_BYTES = 64 * 256, IN_BYTES = NI_IN * 1024, STAGE = Z_BYTES + IN_BYTES;
-  constexpr int NACC = TC ? 2 : 5;
+  constexpr int NACC = NARROW ? (TC ? 1 : 3) : (TC ? 2 : 5);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, th = wave & 1;
+  const int wm = NARROW ? 0 : wave >> 1, th = NARROW ? 0 : wave & 1;
   const seg_geom& g = p.g;
   const int H = g.Hin, W = g.Win;
 
@@ -268,12 +272,20 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
     return;
   }
   // transposed conv: this wave's two taps (halo shift index 3 (dy + 1) + dx + 1 and weight tap) - wave-uniform run-time values
-  int tc_t[2] = {0, 0}, tc_w[2] = {0, 0};
+  // (NARROW conv: the same table holds this wave's taps 2 w, 2 w + 1 and the shared tap 8)
+  int tc_t[3] = {0, 0, 0}, tc_w[3] = {0, 0, 0};
   if constexpr (TC) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = cls * 4 + 2 * th + i;
+    for (int i = 0; i < (NARROW ? 1 : 2); ++i) {
+      const int e = cls * 4 + (NARROW ? wave : 2 * th + i);
       tc_t[i] = __builtin_amdgcn_readfirstlane((g.tap_dy[e] + 1) * 3 + g.tap_dx[e] + 1);
+      tc_w[i] = __builtin_amdgcn_readfirstlane(g.tap_w[e]);
+    }
+  } else if constexpr (NARROW) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = i < 2 ? 2 * wave + i : 8;                        // (tap e of a 3x3 conv sits at halo shift e: checked by the launcher)
+      tc_t[i] = e;
       tc_w[i] = __builtin_amdgcn_readfirstlane(g.tap_w[e]);
     }
   }
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; accl[t][q] = 0.f; }
 
-  const bool do_bias = bias_blk && th == 0;
+  const bool do_bias = bias_blk && (NARROW ? wave == 0 : th == 0);
   f16v accb, accbl;
 #pragma unroll
   for (int q = 0; q < 16; ++q) { accb[q] = 0.f; accbl[q] = 0.f; }
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
       }
     }
   };
-  auto compute_tc = [&](int stage) {
+  auto compute_tc = [&](int stage) {                                 // taps from the run-time table: transposed conv, NARROW conv
     const unsigned char* Zs = smem + stage * STAGE;
     const unsigned char* Is = Zs + Z_BYTES;
 #pragma unroll
@@ -394,7 +406,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
         accbl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ones, accbl, 0, 0, 0);
       }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NACC; ++s) {
+        if (!TC && NARROW && s == 2 && kb != wave) continue;          // tap 8: K block `wave` only (wave-uniform)
         const int t = tc_t[s];
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // wave-uniform, run time
         const int swz = (((hb & 3) + jr) >> 1) & 1;
@@ -411,19 +424,34 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the loads of this patch have landed
       ring_release_barrier();
       if (q + 1 < q1) issue(stage ^ 1);
-      if constexpr (TC) compute_tc(stage);
+      if constexpr (TC || NARROW) compute_tc(stage);
       else compute_conv(thc, stage);
       stage ^= 1;
     }
   };
-  if (TC || th == 0) run(std::integral_constant<int, 0>{});
+  if (TC || NARROW || th == 0) run(std::integral_constant<int, 0>{});
   else run(std::integral_constant<int, 1>{});
 
 #pragma unroll
   for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] += accl[t][q] * SPLIT_INV;
-  if constexpr (!TC) {      // the two halves of tap 4: th = 1 hands its partial tile to th = 0 through LDS
+  if constexpr (!TC && NARROW) {      // the four K blocks of tap 8: waves 1-3 hand their partial tiles to wave 0 through LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(smem);
+    if (wave != 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xch[((wave - 1) * 16 + q) * 64 + lane] = acc[2][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[2][q] += xch[(w * 16 + q) * 64 + lane];
+    }
+  } else if constexpr (!TC) {      // the two halves of tap 4: th = 1 hands its partial tile to th = 0 through LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     float* xch = reinterpret_cast<float*>(smem) + wm * (16 * 64);
@@ -459,9 +487,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
     const int stride = g.T_total * p.Kpad, row0 = r0 + wm * 32;
     float* const wbase = (part != nullptr ? part : dw) + (size_t)(row0 + 4 * fh) * stride + p.seg_woff[seg] + kcol;
     wgrad_mode_dispatch(wgrad_mode(p), [&](auto mc) {
-      if constexpr (TC) {
+      if constexpr (TC || NARROW) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) wgrad_store_tile<decltype(mc)::value>(wbase + tc_w[s] * p.Kpad, acc[s], p.n_rows - row0, stride, sc_mul);
+        for (int s = 0; s < NACC; ++s) {
+          if (!TC && s == 2 && wave != 0) continue;
+          wgrad_store_tile<decltype(mc)::value>(wbase + tc_w[s] * p.Kpad, acc[s], p.n_rows - row0, stride, sc_mul);
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
@@ -480,6 +511,12 @@ template __global__ void igemm_wgrad_halo_split_kernel<8, false>(const seg_igemm
 template __global__ void igemm_wgrad_halo_split_kernel<32, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<16, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<8, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<32, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<32, true, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, true, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, true, true>(const seg_igemm_wgrad_args);
 
 }  // namespace
 
@@ -501,7 +538,17 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
     dim3 grid((unsigned)(((a->n_rows + 63) / 64) * planes), (unsigned)a->g.ncls, (unsigned)a->splitk);
     const int ni = pc == 32 ? 17 : pc == 16 ? 14 : 13;              // LDS-DMA pieces of the halo tile
     const size_t lds = (size_t)2 * (16384 + ni * 1024);
-    if (a->g.ncls == 1) {
+    static const char* narrow_env = std::getenv("SEG_WGRAD_NARROW");
+    const bool narrow = a->n_rows <= 32 && (narrow_env == nullptr || std::atoi(narrow_env) != 0);
+    if (narrow && a->g.ncls == 1) {
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false, true>), grid, dim3(256), lds, st, *a);
+      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false, true>), grid, dim3(256), lds, st, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, false, true>), grid, dim3(256), lds, st, *a);
+    } else if (narrow) {
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true, true>), grid, dim3(256), lds, st, *a);
+      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true, true>), grid, dim3(256), lds, st, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true, true>), grid, dim3(256), lds, st, *a);
+    } else if (a->g.ncls == 1) {
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false>), grid, dim3(256), lds, st, *a);
       else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, false>), grid, dim3(256), lds, st, *a);
