@@ -108,10 +108,19 @@ typedef struct seg_igemm_fwd_args {
                                     offsets in {-1,0,1}^2, stride 1, 'same'; a block owns a 256-pixel patch, so
                                     tile_m must be 256 (tile_n 64 | 128) and seg_fwd_halo_patch(&g) != 0          */
   const float* ep_scale;         /* NULL, or [n_rows] per-channel factor applied to the contraction before bias (folded BN) */
+  /* split of the reduction (variant 0, tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}): splitk > 1 launches splitk blocks
+   * per output tile, each contracting a range of the K chunks into `partial` (fp32 accumulator images,
+   * seg_igemm_fwd_workspace_bytes() bytes, no initialisation needed), and a second launch that adds the images in order and
+   * runs the epilogue (bias, activation, statistics, spans) - deterministic.  For grids that leave CUs idle: the 8x8 / 16x16
+   * levels of a depth-5 encoder (M = 1 024 .. 4 096 pixels against K = 4 608 .. 18 432).  0 / 1: no split.                       */
+  int32_t splitk;
+  float* partial;
 } seg_igemm_fwd_args;
 int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream);
 /* floats of `stats` for these arguments ([ncls * ceil(M / tile_m)][2][n_rows]); the library allocates nothing itself */
 int64_t seg_igemm_fwd_stats_floats(const seg_igemm_fwd_args* a);
+/* bytes of `partial` for these arguments (0 when splitk <= 1) */
+int64_t seg_igemm_fwd_workspace_bytes(const seg_igemm_fwd_args* a);
 /* patch width (32: 8x32 pixels, 16: 16x16 pixels) the variant-3 kernel uses for this geometry; 0: not eligible   */
 int seg_fwd_halo_patch(const seg_geom* g);
 

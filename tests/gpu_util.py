@@ -60,7 +60,7 @@ def h16(x: torch.Tensor) -> torch.Tensor:
 
 
 def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0, want_stats=False, tile=None,
-               accumulate_into=None, f32=False, variant=0):
+               accumulate_into=None, f32=False, variant=0, splitk=0):
     """xs: list of fp32 NHWC CPU tensors (virtual concat); kern: Keras layout numpy.  Returns (out fp32 NHWC CPU, stats)."""
     N, H, W, _ = xs[0].shape
     kh, kw = kern.shape[:2]
@@ -107,6 +107,13 @@ def igemm_conv(xs, kern, bias, kind="conv", strides=(1, 1), act=None, alpha=0.0,
         nparts = g.ncls * (-(-Mtot // tm))
         stats = torch.zeros((nparts, 2, n_rows), dtype=torch.float32, device="cuda")
         a.stats = stats.data_ptr()
+    ws = None
+    if splitk > 1:                 # split reduction: accumulator images of the slices (garbage-filled: needs no initialisation)
+        a.splitk = splitk
+        nbytes = ffi.lib().seg_igemm_fwd_workspace_bytes(C.byref(a))
+        assert nbytes == splitk * g.ncls * (-(-Mtot // tm)) * (-(-n_rows // tn)) * tm * tn * 4
+        ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")
+        a.partial = ws.data_ptr()
     ffi.call("seg_igemm_fwd_f32" if f32 else "seg_igemm_fwd", C.byref(a), stream())
     torch.cuda.synchronize()
     outv = dev_values(out)

@@ -136,5 +136,11 @@ def test_workspace_queries_agree_with_the_engines_own_sizing(built):
             assert L.seg_igemm_wgrad_workspace_bytes(ctypes.byref(op.wg_args)) == want
             seen += 1
         assert seen > 5
+        for a in m.fwd_ws_users:             # split reductions: accumulator images of the slices
+            assert L.seg_igemm_fwd_workspace_bytes(ctypes.byref(a)) == M.fwd_workspace_bytes(a)
+        a = ffi.IgemmFwdArgs.from_buffer_copy(m.fwd_ws_users[0])
+        a.tile_m, a.tile_n, a.splitk = 128, 128, 4
+        Mtot = a.g.N * a.g.Hl * a.g.Wl
+        assert L.seg_igemm_fwd_workspace_bytes(ctypes.byref(a)) == 4 * a.g.ncls * (-(-Mtot // 128)) * (-(-a.n_rows // 128)) * 128 * 128 * 4
     finally:
         M._DryRun.on = False

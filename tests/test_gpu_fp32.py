@@ -176,6 +176,42 @@ def test_halo_kernels_in_the_parity_mode(case, tile):
         assert rel(out2, f(torch.cat(xs, -1), torch.from_numpy(kern), None, s) + base[..., :cout]) < 2e-6
 
 
+@pytest.mark.parametrize("f32", [True, False], ids=["parity", "fp16"])
+@pytest.mark.parametrize("case", [
+    dict(kind="conv", k=3, shape=(1, 8, 16), cins=[256, 160], cout=136, tile=(128, 64), sk=3),      # deep level: M = 128, K = 3 744
+    dict(kind="conv", k=3, shape=(2, 8, 8), cins=[512], cout=72, tile=(128, 128), sk=4),
+    dict(kind="conv", k=1, shape=(2, 16, 16), cins=[96, 40], cout=64, tile=(256, 64), sk=2),
+    dict(kind="convT", k=4, shape=(1, 8, 8), cins=[192], cout=96, tile=(128, 64), sk=5),            # four classes; 6 chunks over 5 slices: an empty slice
+], ids=lambda c: f"{c['kind']}{c['k']}-{c['shape']}-{c['cins']}->{c['cout']}-sk{c['sk']}")
+def test_split_reduction_of_the_per_tap_kernel(case, f32):
+    """seg_igemm_fwd(_f32) with splitk > 1 (variant 0, LDS-DMA kernel): slices of the K chunks leave accumulator images in the
+    workspace (NaN-filled here: no initialisation needed), a second launch adds them in order and runs the epilogue - bias,
+    activation, BN partial statistics, accumulate - with the same result as the unsplit launch, bit for bit between runs."""
+    N, H, W = case["shape"]
+    xs = [torch.randn(N, H, W, c) for c in case["cins"]]
+    cin, cout, k = sum(case["cins"]), case["cout"], case["k"]
+    tconv = case["kind"] == "convT"
+    kern = rng.standard_normal((k, k, cout, cin) if tconv else (k, k, cin, cout)).astype(np.float32) * 0.05
+    b = rng.standard_normal(cout).astype(np.float32)
+    s = (2, 2) if tconv else (1, 1)
+    kw = dict(f32=f32, variant=0)
+    ref, st0, _ = U.igemm_conv(xs, kern, b, case["kind"], s, "relu", 0.0, True, case["tile"], **kw)
+    out, st, pad = U.igemm_conv(xs, kern, b, case["kind"], s, "relu", 0.0, True, case["tile"], splitk=case["sk"], **kw)
+    out2, _, _ = U.igemm_conv(xs, kern, b, case["kind"], s, "relu", 0.0, True, case["tile"], splitk=case["sk"], **kw)
+    assert torch.equal(out, out2) and pad == 0.0
+    tol = 2e-6 if f32 else 2e-3
+    assert rel(out, ref) < tol and rel(st, st0) < 1e-5
+    if f32:
+        f = K.conv2d_transpose_same if tconv else K.conv2d_same
+        want = torch.relu(f(torch.cat(xs, -1), torch.from_numpy(kern), torch.from_numpy(b), s))
+        assert rel(out, want) < 5e-6          # (K = 4 608: the fp32 CPU reference's own summation order is in this figure)
+    if not tconv:
+        base = torch.randn(N, H, W, U.r8(cout))
+        acc, _, _ = U.igemm_conv(xs, kern, None, "conv", s, None, 0.0, False, case["tile"], accumulate_into=base, splitk=case["sk"], **kw)
+        acc0, _, _ = U.igemm_conv(xs, kern, None, "conv", s, None, 0.0, False, case["tile"], accumulate_into=base, **kw)
+        assert rel(acc, acc0) < tol
+
+
 @pytest.mark.parametrize("shape,cins,cout,sk,partial", [
     ((2, 16, 32), [24, 40], 72, 3, True),       # 4x16 patches, two concat segments, two row tiles (the second ragged)
     ((2, 16, 32), [8, 17], 26, 2, True),        # <= 32 output channels: the four waves split the taps (NARROW)

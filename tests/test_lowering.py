@@ -184,3 +184,21 @@ def test_parity_mode_tiles_have_a_kernel_instance():
     assert {(256, 64, 3), (256, 32, 3)} <= seen and any(v == 0 for _a, _b, v in seen)       # large levels: halo tiles; small grids: per-tap kernels
     g1 = M.geom_conv(16, 256, 256, 1, 1, 1, 1)                               # 1x1: never the halo kernel
     assert all(M.pick_fwd(Mt, n, g1, 512, False)[2] == 0 for Mt in (4096, 1048576) for n in (8, 64, 384))
+
+
+def test_under_filled_grids_split_the_reduction():
+    """plan_fwd: forward / data-gradient grids of at most one block per CU are split along K towards two blocks per CU (128-row tiles
+    of the per-tap LDS-DMA kernel, seg_igemm_fwd_args.splitk) while a slice keeps >= 3 072 of the reduction - the 8x8 / 16x16
+    levels of the depth-5 configurations; the large levels and short reductions are left alone.  The slices' accumulator images
+    share ONE workspace (every such launch runs on the main stream)."""
+    g8, g16, g256 = M.geom_conv(16, 8, 8, 3, 3, 1, 1), M.geom_conv(16, 16, 16, 3, 3, 1, 1), M.geom_conv(16, 256, 256, 3, 3, 1, 1)
+    assert M.plan_fwd(1024, 1024, g8, 9 * 2048, False) == (128, 128, 0, 4)         # enc6 data gradient: 64 blocks, slices of 4 608
+    assert M.plan_fwd(1024, 2048, g8, 9 * 2048, False) == (128, 128, 0, 4)         # latent convs: 128 blocks
+    assert M.plan_fwd(4096, 512, g16, 9 * 1024, False) == (128, 128, 0, 2)         # enc5 data gradient (otherwise the halo kernel at 128 blocks)
+    assert M.plan_fwd(4096, 1024, g16, 9 * 512, False)[3] == 1                     # enc5 forward: 256 blocks, K = 4 608 - no gain measured
+    assert M.plan_fwd(1048576, 64, g256, 9 * 384, False) == (256, 64, 3, 1)        # the large levels: halo tiles, no split
+    assert M.plan_fwd(1024, 1024, g8, 9 * 2048, True)[3] in (1, 2)                 # throughput mode: twice the floor on a slice
+    m = segamd.unet_model_builder("UNetPP", 256, 256, 64, 5, ds=1, train_mode="from_scratch").ResNet50().build(2, dtype="f32")
+    split = [a for a in m.fwd_ws_users if a.splitk > 1]
+    assert split and all(a.variant == 0 and a.tile_m == 128 for a in split)
+    assert max(M.fwd_workspace_bytes(a) for a in split) > 0

@@ -46,7 +46,8 @@ class IgemmFwdArgs(C.Structure):
                 ("alpha", C.c_float), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("tile_m", C.c_int32),
                 ("tile_n", C.c_int32), ("nout", C.c_int32), ("out_span", C.c_int32 * MAX_SEG), ("out_cs_o", C.c_int32 * MAX_SEG),
                 ("out_acc", C.c_int32 * MAX_SEG), ("out_ptr", C.c_void_p * MAX_SEG), ("out_y", C.c_void_p * MAX_SEG),
-                ("out_dact", C.c_int32 * MAX_SEG), ("out_dalpha", C.c_float * MAX_SEG), ("variant", C.c_int32), ("ep_scale", C.c_void_p)]
+                ("out_dact", C.c_int32 * MAX_SEG), ("out_dalpha", C.c_float * MAX_SEG), ("variant", C.c_int32), ("ep_scale", C.c_void_p),
+                ("splitk", C.c_int32), ("partial", C.c_void_p)]
 
 
 class IgemmWgradArgs(C.Structure):
@@ -71,6 +72,7 @@ _PROTOS = {
     "seg_igemm_fwd": ([C.POINTER(IgemmFwdArgs), vp], C.c_int),
     "seg_igemm_wgrad": ([C.POINTER(IgemmWgradArgs), vp], C.c_int),
     "seg_igemm_fwd_stats_floats": ([C.POINTER(IgemmFwdArgs)], C.c_int64),
+    "seg_igemm_fwd_workspace_bytes": ([C.POINTER(IgemmFwdArgs)], C.c_int64),
     "seg_igemm_wgrad_workspace_bytes": ([C.POINTER(IgemmWgradArgs)], C.c_int64),
     "seg_wgrad_taps_per_block": ([C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),

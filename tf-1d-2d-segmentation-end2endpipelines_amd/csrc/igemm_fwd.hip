@@ -92,7 +92,16 @@ static int fwd2_bk(const seg_igemm_fwd_args& a, long nblocks) {
 }
 
 static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hipStream_t st) {
-  dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a.g.ncls, 1);
+  const int ksl = a.splitk > 1 ? a.splitk : 1;
+  dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a.g.ncls, (unsigned)ksl);
+  auto finish = [&](const char* what) -> int {
+    SEG_CHECK_LAUNCH(what);
+    if (ksl > 1) {
+      launch_fwd2_splitk_epilogue<false>(a, grid, st);
+      SEG_CHECK_LAUNCH("seg_igemm_fwd (split reduction, epilogue)");
+    }
+    return SEG_OK;
+  };
   // deep-and-small layers: with ~1 block per CU nothing else hides a block's barriers and load latency, so take both
   // the 64-deep K step (8 instead of 4 MFMAs per wave and barrier) and two steps of loads in flight (72 KB of LDS)
   static const bool no_deep = std::getenv("SEG_NO_DEEP_RING") != nullptr;
@@ -105,8 +114,7 @@ static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hi
       const size_t lds = (size_t)3 * (128 + 64) * 128;
       if (a.g.ntaps == 9) hipLaunchKernelGGL((igemm_fwd2_kernel<128, 64, 9, 64, 3>), grid, dim3(256), lds, st, a);
       else hipLaunchKernelGGL((igemm_fwd2_kernel<128, 64, 16, 64, 3>), grid, dim3(256), lds, st, a);
-      SEG_CHECK_LAUNCH("seg_igemm_fwd (LDS-DMA, deep ring)");
-      return SEG_OK;
+      return finish("seg_igemm_fwd (LDS-DMA, deep ring)");
     }
   }
   if (fwd2_bk(a, (long)mblocks * nblocks * a.g.ncls) == 64) {
@@ -120,8 +128,16 @@ static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hi
     else if (a.tile_m == 128) launch_fwd2_nt<128, 64, 32, 3>(a, grid, lds, st);
     else launch_fwd2_nt<256, 64, 32, 3>(a, grid, lds, st);
   }
-  SEG_CHECK_LAUNCH("seg_igemm_fwd (LDS-DMA)");
-  return SEG_OK;
+  return finish("seg_igemm_fwd (LDS-DMA)");
+}
+
+// bytes of the `partial` workspace of a split reduction (seg_hip.h): one accumulator image per slice, class and output tile
+extern "C" int64_t seg_igemm_fwd_workspace_bytes(const seg_igemm_fwd_args* a) {
+  if (a == nullptr || a->tile_m <= 0 || a->tile_n <= 0) return -1;
+  if (a->splitk <= 1) return 0;
+  const int64_t M = (int64_t)a->g.N * a->g.Hl * a->g.Wl;
+  const int64_t tiles = ((M + a->tile_m - 1) / a->tile_m) * ((a->n_rows + a->tile_n - 1) / a->tile_n) * a->g.ncls;
+  return (int64_t)a->splitk * tiles * a->tile_m * a->tile_n * (int64_t)sizeof(float);
 }
 
 extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) {
@@ -132,6 +148,7 @@ extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   const int mblocks = (int)((M + a->tile_m - 1) / a->tile_m);
   const int nblocks = (a->n_rows + a->tile_n - 1) / a->tile_n;
   if (fwd2_eligible(*a, 2)) return launch_fwd2(*a, mblocks, nblocks, st);
+  SEG_CHECK_ARG(a->splitk <= 1, "seg_igemm_fwd: splitk needs the LDS-DMA kernel (tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
   SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (taps in {1,2,3,4,9,16}, operands < 1 GiB)");
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a->g.ncls, 1), block(256, 1, 1);
   const int lds_main = 2 * (a->tile_m + a->tile_n) * ROW_BYTES;

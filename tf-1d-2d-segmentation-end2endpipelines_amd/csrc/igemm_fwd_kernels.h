@@ -273,13 +273,19 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
 
   int nchunks = 0;
   for (int s = 0; s < p.nseg; ++s) nchunks += (p.seg_c[s] + BKE - 1) / BKE;
-  const int niter = nchunks * NT;
+  // split of the reduction: slice blockIdx.z of p.splitk contracts the chunks [ck0, ck1) and leaves its accumulators in p.partial
+  const int ksl = p.splitk > 1 ? p.splitk : 1;
+  const int kz = ksl > 1 ? (int)blockIdx.z : 0;
+  const int kper = (nchunks + ksl - 1) / ksl;
+  const int ck0 = min(kz * kper, nchunks), ck1 = min(nchunks, ck0 + kper);
+  const int nloc = ck1 - ck0;
+  const int niter = nloc * NT;
   const int pixbytes = g.N * g.Hin * g.Win;
 
-  auto setup = [&](ChunkDesc<AL>& d, int seg, int c0) {
+  auto setup = [&](ChunkDesc<AL>& d, int seg, int c0, int cidx) {
     d.seg = seg;
     d.c0 = c0;
-    d.valid = seg < p.nseg;
+    d.valid = seg < p.nseg && cidx < ck1;
     if (d.valid) {
       const int cs = p.seg_cs[seg], sc = p.seg_c[seg];
       d.ptr = p.seg_ptr[seg];
@@ -320,11 +326,12 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
 
   ChunkDesc<AL> D[3];
   int cseg = 0, cc0 = 0;
-  setup(D[0], cseg, cc0);
+  for (int i = 0; i < ck0; ++i) advance(cseg, cc0);
+  setup(D[0], cseg, cc0, ck0);
   advance(cseg, cc0);
-  setup(D[1], cseg, cc0);
+  setup(D[1], cseg, cc0, ck0 + 1);
   advance(cseg, cc0);
-  setup(D[2], cseg, cc0);
+  setup(D[2], cseg, cc0, ck0 + 2);
 
   // prologue: the first DIST K steps
   issue(std::integral_constant<int, 0>{}, D[0], 0);
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
 
   const int fr = lane & 31, fh = lane >> 5;
   int it = 0, stage = 0;
-  for (int ck = 0; ck < nchunks; ++ck) {
+  for (int ck = 0; ck < nloc; ++ck) {
     static_for<0, NT>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       constexpr int t2 = (t + DIST) % NT, k2 = (t + DIST) / NT;
@@ -354,12 +361,70 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
     D[0] = D[1];
     D[1] = D[2];
     advance(cseg, cc0);
-    setup(D[2], cseg, cc0);
+    setup(D[2], cseg, cc0, ck0 + ck + 3);
   }
   __syncthreads();
   if constexpr (SPLIT) split_combine(acc, accl);
+  if (ksl > 1) {          // this slice's accumulator image: [slice][class][tile][2 x TNw x 16 values][256 threads], coalesced
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float* img = p.partial + ((size_t)(kz * gridDim.y + cls) * gridDim.x + bx) * (size_t)(256 * 2 * TNw * 16) + tid;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TNw; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) img[((a * TNw + b) * 16 + q) * 256] = acc[a][b][q];
+    return;
+  }
   conv_epilogue<TO, 2, TNw, WMv, BN>(p, acc, smem, tid, m0 + wm * 64, wn * (32 * TNw), n0, wm, cls, mblocks, mb, M, HW);
 #endif
+}
+
+// second launch of a split reduction: one block per output tile adds the slices' accumulator images in order (deterministic) and
+// runs the epilogue of the kernel above - bias, activation, BN partial statistics, spans, accumulate, fused activation backward
+template <int BM, int BN, bool SPLIT>
+__global__ __launch_bounds__(256) void igemm_fwd2_splitk_epilogue_kernel(const seg_igemm_fwd_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WMv = BM / 64, WNv = 4 / WMv, TNw = BN / (32 * WNv);
+  typedef std::conditional_t<SPLIT, split_t, half_t> TO;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNv, wn = wave % WNv;
+  const seg_geom& g = p.g;
+  const int HW = g.Hl * g.Wl;
+  const int M = g.N * HW;
+  const int mblocks = (M + BM - 1) / BM;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int cls = lin / gridDim.x, bx = lin - cls * gridDim.x;
+  const int mb = bx % mblocks, nb = bx / mblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+  f16v acc[2][TNw];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TNw; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  for (int kz = 0; kz < p.splitk; ++kz) {
+    const float* img = p.partial + ((size_t)(kz * gridDim.y + cls) * gridDim.x + bx) * (size_t)(256 * 2 * TNw * 16) + tid;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TNw; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][b][q] += img[((a * TNw + b) * 16 + q) * 256];
+  }
+  conv_epilogue<TO, 2, TNw, WMv, BN>(p, acc, smem, tid, m0 + wm * 64, wn * (32 * TNw), n0, wm, cls, mblocks, mb, M, HW);
+#endif
+}
+template <bool SPLIT>
+inline void launch_fwd2_splitk_epilogue(const seg_igemm_fwd_args& a, dim3 grid, hipStream_t st) {
+  const size_t lds = STG_BYTES + 4 * 128 * 2 * sizeof(float);
+  dim3 g2(grid.x, grid.y, 1);
+  if (a.tile_m == 128 && a.tile_n == 128) hipLaunchKernelGGL((igemm_fwd2_splitk_epilogue_kernel<128, 128, SPLIT>), g2, dim3(256), lds, st, a);
+  else if (a.tile_m == 128) hipLaunchKernelGGL((igemm_fwd2_splitk_epilogue_kernel<128, 64, SPLIT>), g2, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((igemm_fwd2_splitk_epilogue_kernel<256, 64, SPLIT>), g2, dim3(256), lds, st, a);
 }
 
 
@@ -387,6 +452,8 @@ inline int check_fwd_args(const seg_igemm_fwd_args* a) {
   SEG_CHECK_ARG((a->Kpad & 31) == 0, "seg_igemm_fwd: Kpad=%d not a multiple of 32", a->Kpad);
   SEG_CHECK_ARG((a->variant & 255) == 0 || (a->variant & 255) == 3, "seg_igemm_fwd: variant=%d", a->variant);
   SEG_CHECK_ARG(a->act >= SEG_ACT_NONE && a->act <= SEG_ACT_SIGMOID, "seg_igemm_fwd: act=%d", a->act);
+  SEG_CHECK_ARG(a->splitk <= 1 || ((a->variant & 255) == 0 && a->partial != nullptr && a->splitk <= 64),
+                "seg_igemm_fwd: splitk=%d needs variant 0 and the partial workspace (seg_igemm_fwd_workspace_bytes)", a->splitk);
   if ((a->variant & 255) != 3)
     SEG_CHECK_ARG((a->tile_m == 256 && a->tile_n == 64) || ((a->tile_m == 128 || a->tile_m == 64) && (a->tile_n == 128 || a->tile_n == 64)),
                   "seg_igemm_fwd: tile %dx%d", a->tile_m, a->tile_n);

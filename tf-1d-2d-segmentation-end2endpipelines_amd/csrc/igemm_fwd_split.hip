@@ -27,12 +27,18 @@ extern "C" int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t strea
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a->g.ncls, 1), block(256, 1, 1);
   if (fwd2_eligible(*a, 4)) {
     const size_t lds = (size_t)3 * (a->tile_m + a->tile_n) * 64;          // >= the epilogue's staging (20.5 KB)
+    if (a->splitk > 1) grid.z = (unsigned)a->splitk;
     if (a->tile_m == 128 && a->tile_n == 128) launch_fwd2_split_nt<128, 128>(v, grid, lds, st);
     else if (a->tile_m == 128) launch_fwd2_split_nt<128, 64>(v, grid, lds, st);
     else launch_fwd2_split_nt<256, 64>(v, grid, lds, st);
     SEG_CHECK_LAUNCH("seg_igemm_fwd_f32 (LDS-DMA)");
+    if (a->splitk > 1) {
+      launch_fwd2_splitk_epilogue<true>(v, grid, st);
+      SEG_CHECK_LAUNCH("seg_igemm_fwd_f32 (split reduction, epilogue)");
+    }
     return SEG_OK;
   }
+  SEG_CHECK_ARG(a->splitk <= 1, "seg_igemm_fwd_f32: splitk needs the LDS-DMA kernel (tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
   SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd_f32: a 256-row tile needs the LDS-DMA kernel (taps in {1,2,3,4,9,16}, operands < 1 GiB)");
   const int lds_main = 2 * (a->tile_m + a->tile_n) * ROW_BYTES * 2;      // two sub-tiles per K step
   const int lds_epi = STG_BYTES + 2 * a->tile_n * 2 * 4;

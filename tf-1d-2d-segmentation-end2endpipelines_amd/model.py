@@ -357,6 +357,43 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     return tm, tn, 0
 
 
+FWD_SPLITK = os.environ.get("SEG_FWD_SPLITK", "1") != "0"              # split reduction of under-filled forward / data-gradient grids
+FWD_SPLITK_MAX_BLOCKS = int(os.environ.get("SEG_FWD_SPLITK_MAX_BLOCKS", "256"))     # ... grids of at most one block per CU
+FWD_SPLITK_TARGET = int(os.environ.get("SEG_FWD_SPLITK_TARGET", "512"))             # ... are split towards two blocks per CU
+FWD_SPLITK_MIN_K = int(os.environ.get("SEG_FWD_SPLITK_MIN_K", "3072"))              # ... while a slice keeps this much of the reduction
+
+
+def plan_fwd(M, n_rows, g: Geom, ktot, f16: bool):
+    """(tile_m, tile_n, variant, splitk) of a forward / data-gradient launch: pick_fwd, then the split of the reduction
+    (seg_igemm_fwd_args.splitk) for grids that leave CUs idle - the 8x8 / 16x16 levels of a depth-5 encoder: M = 1 024 .. 4 096
+    pixels against K = 4 608 .. 18 432.  Measured on MI355X, parity mode (tools/op_bench.py --splitk, 128x128 tile): enc6 data
+    gradient (64 blocks) 291 -> 129 us, latent convs (128 blocks) 308 -> 220, X41 transposed conv 318 -> 212, enc5 data gradient
+    (the halo kernel at 128 blocks: 194) -> 124, X31 transposed-conv data gradient (halo, 256 blocks: 278) -> 214; a 256-block
+    grid with K = 4 608 (enc5 forward) does not gain, hence the floor on the slice."""
+    tm, tn, variant = pick_fwd(M, n_rows, g, ktot, f16)
+    if not FWD_SPLITK or g.ntaps not in (1, 2, 3, 4, 9, 16):
+        return tm, tn, variant, 1
+    ctn = 128 if n_rows > 64 else 64
+    blocks = g.ncls * _cdiv(M, 128) * _cdiv(n_rows, ctn)
+    if blocks > FWD_SPLITK_MAX_BLOCKS:
+        return tm, tn, variant, 1
+    sk = max(1, FWD_SPLITK_TARGET // blocks)
+    kmin = FWD_SPLITK_MIN_K * (2 if f16 else 1)
+    while sk > 1 and ktot // sk < kmin:
+        sk //= 2
+    if sk <= 1:
+        return tm, tn, variant, 1
+    return 128, ctn, 0, min(sk, 64)
+
+
+def fwd_workspace_bytes(a) -> int:
+    """Mirror of seg_igemm_fwd_workspace_bytes(): accumulator images of a split reduction."""
+    if a.splitk <= 1:
+        return 0
+    Mtot = a.g.N * a.g.Hl * a.g.Wl
+    return a.splitk * a.g.ncls * _cdiv(Mtot, a.tile_m) * _cdiv(a.n_rows, a.tile_n) * a.tile_m * a.tile_n * 4
+
+
 def wgrad_halo_patch(g: Geom) -> int:
     """Mirror of seg_wgrad_halo_patch() (csrc/igemm_wgrad.hip): patch width of the LDS-DMA halo-tile weight-gradient kernel
     (variant 2) for this geometry, 0 when it is neither a 3x3 / stride-1 / 'same' convolution nor a 4x4 / stride-2
@@ -636,7 +673,7 @@ class ConvOp(Op):
             self.bn_name = bn.name
             self.eps, self.momentum = float(bn.attrs["eps"]), float(bn.attrs["momentum"])
         # ---- tiles and scratch
-        self.tm, self.tn, self.fwd_variant = pick_fwd(self.M, n_rows, self.g_fwd, self.g_fwd.ntaps * self.Kpad, m.dtype == "f16")
+        self.tm, self.tn, self.fwd_variant, self.fwd_splitk = plan_fwd(self.M, n_rows, self.g_fwd, self.g_fwd.ntaps * self.Kpad, m.dtype == "f16")
         self.nparts = self.g_fwd.ncls * _cdiv(self.M, self.tm)
         dev = _dev()
         if self.has_bn:
@@ -674,10 +711,11 @@ class ConvOp(Op):
         a.act, a.alpha = (ACT[self.act] if fused_act else 0), float(self.alpha)
         a.accumulate = 0
         a.stats = self.stats.data_ptr() if self.has_bn else None
-        a.tile_m, a.tile_n, a.variant = self.tm, self.tn, self.fwd_variant
+        a.tile_m, a.tile_n, a.variant, a.splitk = self.tm, self.tn, self.fwd_variant, self.fwd_splitk
         self.fwd_args = a
         self.fwd_args_eval = IgemmFwdArgs.from_buffer_copy(a)
         self.fwd_args_eval.stats = None
+        self.m.fwd_ws_users += [a, self.fwd_args_eval]
         # inference (model.predict, 2DCNN/Test.py:153,161): BatchNormalization with the moving statistics is a per-channel affine
         # known before the conv runs - folded into the GEMM epilogue (ep_scale / bias), activation applied there, the result written
         # straight to `out`: ONE launch per Conv_Block (unet_variants.py:7-14), no pre-BN tensor, no normalisation pass
@@ -691,6 +729,7 @@ class ConvOp(Op):
             b.bias, b.ep_scale = self.inf_shift.data_ptr(), self.inf_scale.data_ptr()
             b.act, b.alpha = ACT[self.act], float(self.alpha)
             self.fwd_args_infer = b
+            self.m.fwd_ws_users.append(b)
         # wgrad
         wg = IgemmWgradArgs()
         wg.g = self.g_fwd
@@ -834,7 +873,8 @@ class ConvOp(Op):
                 if self.strided and not acc:
                     zero_first.append(t)
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
-            a.tile_m, a.tile_n, a.variant = pick_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
+            a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
+            self.m.fwd_ws_users.append(a)
             self.dg_args.append((a, zero_first, fl))
             s_i = e_i
         for grp in self.gather_launch:       # gathered data gradients this op launches (it is their last-running consumer)
@@ -941,7 +981,8 @@ class GatherDgrad:
         a.out, a.out_cs, a.out_coff, a.accumulate = self.t.grad.data_ptr(), self.t.cs, 0, acc
         a.bias, a.act, a.alpha, a.stats, a.nout = None, 0, 0.0, None, 0
         Md = op0.N * op0.g_dgrad.Hl * op0.g_dgrad.Wl
-        a.tile_m, a.tile_n, a.variant = pick_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16")
+        a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16")
+        self.m.fwd_ws_users.append(a)
         self.args = a
         self.flops = sum(op.flops_seg[si] for op, si in self.members)
 
@@ -1471,6 +1512,7 @@ class SegModel:
         DevTensor.registry = self.tensors
         self.store = ParamStore()
         self.ops: List[Op] = []
+        self.fwd_ws_users: list = []           # argument blocks of forward / data-gradient launches (split reductions share one workspace)
         self.heads: List[HeadOp] = []
         self.gs = torch.ones(2, dtype=torch.float32, device=_dev())        # [grad scale S, 1/S]
         self.amax = torch.zeros(1, dtype=torch.float32, device=_dev())
@@ -1657,6 +1699,12 @@ class SegModel:
         self.producer_of = {id(op.out): op for op in self.ops if isinstance(op, ConvOp)}
         for op in reversed(self.ops):
             op.plan_backward()
+        # ONE workspace for every split reduction: forward and data-gradient launches all run on the main stream, in order
+        need = max([fwd_workspace_bytes(a) for a in self.fwd_ws_users] + [0])
+        self.fwd_ws = torch.empty(need // 4, dtype=torch.float32, device=_dev()) if need and not _DryRun.on else None
+        for a in self.fwd_ws_users:
+            if a.splitk > 1:
+                a.partial = self.fwd_ws.data_ptr() if self.fwd_ws is not None else None
         DevTensor.registry = None
         DevTensor.dtype = torch.float16
         if self.use_side_stream and not _DryRun.on:

@@ -88,9 +88,10 @@ def main():
                 if sk0 is not None:
                     a.splitk, a.partial = sk0, part0
                 continue
+            v0, sk_f0, part_f0 = a.variant, (a.splitk if ph != "wgrad" else None), (a.partial if ph != "wgrad" else None)
             for tile in tiles:
                 for bk in (bks if ph != "wgrad" else [None]):
-                    for sk in (sks if ph == "wgrad" else [None]):
+                    for sk in sks:
                         if tile is not None:
                             a.tile_m, a.tile_n = tile
                             if ph == "fwd" and tile[0] < t0[0]:
@@ -99,19 +100,29 @@ def main():
                             a.splitk = sk
                             if ph == "wgrad":
                                 a.partial = None          # (the layer's partial workspace is sized for its planned split)
+                            else:                         # split reduction of the per-tap kernel (variant 0)
+                                a.variant = 0
+                                if tile is None and a.tile_m == 256 and a.tile_n != 64:
+                                    a.tile_n = 64
+                                nb = M._ffi.lib().seg_igemm_fwd_workspace_bytes(C.byref(a))
+                                ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device="cuda")
+                                a.partial = ws.data_ptr() if sk > 1 else None
                         if bk is None:
                             os.environ.pop("SEG_V2_BK", None)
                         else:
                             os.environ["SEG_V2_BK"] = bk
                         try:
                             us = timeit(fn)
-                            print(f"{name:16s} {ph:6s} tile {a.tile_m}x{a.tile_n} bk {bk or 'auto':4s} splitk {a.splitk if ph == 'wgrad' else '-':>4} "
-                                  f"M={op.M} n_rows={a.n_rows} Kpad={a.Kpad}: {us:8.1f} us  {fl / us / 1e6:7.0f} TF", flush=True)
+                            print(f"{name:16s} {ph:6s} tile {a.tile_m}x{a.tile_n} bk {bk or 'auto':4s} splitk {a.splitk:>4} "
+                                  f"M={op.M} n_rows={a.n_rows} Kpad={a.Kpad} v{a.variant & 255}: {us:8.1f} us  {fl / us / 1e6:7.0f} TF", flush=True)
                         except Exception as e:
                             print(f"{name:16s} {ph:6s} tile {tile} bk {bk}: {e}", flush=True)
             a.tile_m, a.tile_n = t0
+            a.variant = v0
             if sk0 is not None:
                 a.splitk, a.partial = sk0, part0
+            if sk_f0 is not None:
+                a.splitk, a.partial = sk_f0, part_f0
             os.environ.pop("SEG_V2_BK", None)
 
 
