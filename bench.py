@@ -126,7 +126,8 @@ def pmc_traffic(entry_point, workload, dtype):
     n = tot = 0
     for k, v in d.items():
         if not k.startswith("_") and any(pf in k for pf in prefix):
-            n += v["launches"]
+            if "splitk_epilogue" not in k:        # (the second kernel of a split reduction belongs to the same entry-point launch)
+                n += v["launches"]
             tot += v["launches"] * (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"])
     return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
 
