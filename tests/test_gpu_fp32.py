@@ -284,3 +284,40 @@ def test_fused_bn_tails_equal_the_separate_passes(name, monkeypatch):
     p1, p0 = (p1 if isinstance(p1, list) else [p1]), (p0 if isinstance(p0, list) else [p0])
     for a, b in zip(p1, p0):
         assert float(np.abs(a - b).max()) < 1e-5 * max(1.0, float(np.abs(b).max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16", 2e-2)])
+def test_split_reductions_in_a_training_step(dtype, tol, monkeypatch):
+    """A wide, small-image UNet (256 .. 2 048 channels at 32x32 .. 4x4) puts its deep levels on split reductions
+    (model.plan_fwd) - forward convs with BN statistics, transposed convs (four classes), data gradients with several output
+    spans and fused activation backward.  Same training step and predictions as with SEG_FWD_SPLITK=0 up to summation order."""
+    from test_gpu_models import B, _with_targets
+    M = U.M
+    torch.manual_seed(11)
+    x = torch.rand(2, 32, 32, 3)
+    m1, _x, targets, loss = _with_targets(B("UNet", 32, 32, 256, 3, num_channels=3, ds=1), x, "mse")
+    m1.build(2, dtype=dtype)
+    split = [a for a in m1.fwd_ws_users if a.splitk > 1]
+    assert any(a.nout > 1 for a in split) and any(a.g.ncls == 4 for a in split) and any(a.stats for a in split)
+    w = m1.get_weights()
+    monkeypatch.setattr(M, "FWD_SPLITK", False)
+    m0 = B("UNet", 32, 32, 256, 3, num_channels=3, ds=1)
+    m0.build(2, dtype=dtype)
+    assert not any(a.splitk > 1 for a in m0.fwd_ws_users)
+    m0.set_weights(w)
+    res = []
+    for m in (m1, m0):
+        m.forward(x, training=True)
+        lv = float(m.compute_loss(targets, loss).cpu())
+        m.backward(None)
+        g = m.get_grads()
+        m.optimizer_step()
+        m._join_side()
+        res.append((lv, g, m.predict(x)))
+    (l1, g1, p1), (l0, g0, p0) = res
+    assert abs(l1 - l0) < tol * max(1.0, abs(l0))
+    gmax = max(float(np.abs(v).max()) for v in g0.values())
+    for k in g0:
+        assert float(np.abs(g1[k] - g0[k]).max()) < 10 * tol * (float(np.abs(g0[k]).max()) + 1e-3 * gmax), k
+    for a, b in zip(p1, p0):
+        assert float(np.abs(a - b).max()) < tol * max(1.0, float(np.abs(b).max()))
