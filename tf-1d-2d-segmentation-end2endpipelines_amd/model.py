@@ -39,7 +39,7 @@ from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, Igemm
 from .graph import Graph, Node, ParamSpec
 from .splitfmt import split_pack, split_unpack
 
-BN_PARTS_BWD = int(os.environ.get("SEG_BN_PARTS_BWD", "1024"))
+BN_PARTS_BWD = int(os.environ.get("SEG_BN_PARTS_BWD", "512"))     # partial rows of the BN-backward reductions: 2 blocks per CU (same-box A/B against 1024: C4 47.4 -> 46.8 ms, C3 -0.1, C2 -0.06; 256 and 2048 lose)
 GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before the fp16 backward pass
 WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
 WGRAD_OVERWRITE = os.environ.get("SEG_WGRAD_OVERWRITE", "1") != "0"   # single-writer weight-gradient tiles store into the cleared buffer
