@@ -1,0 +1,80 @@
+"""Numeric examples PUBLISHED in the tf.keras (TF 2.x) API documentation for layers on this path - known answers that neither the
+oracle nor the engine had a hand in.  The reference ships no vectors and TensorFlow cannot run here, so these,
+the Keras docstring answers of the losses (tests/test_oracle_losses.py) and the hand-worked cases of
+tests/test_oracle_primitives.py are what the oracle is pinned by; the `-m gpu` half runs the same vectors through the C-ABI.
+
+Sources (docstring examples of the TF 2.x API docs):
+  tf.keras.layers.MaxPooling2D   - pool (2, 2), strides (2, 2), 'valid' on a 3 x 4 image
+  tf.keras.layers.UpSampling2D   - size (1, 2) on arange(12).reshape(2, 2, 1, 3)
+  tf.keras.layers.LeakyReLU      - default alpha 0.3 and alpha = 0.1 on [-3, -1, 0, 2]
+  tf.keras.layers.ReLU / activations.relu, activations.sigmoid, activations.tanh, activations.hard_sigmoid (0.2 x + 0.5)
+  tf.keras.layers.Concatenate / Add - the documented shapes / values"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ref as K
+
+MAXPOOL_X = np.array([[1., 2., 3., 4.], [5., 6., 7., 8.], [9., 10., 11., 12.]], np.float32).reshape(1, 3, 4, 1)
+MAXPOOL_Y = np.array([6., 8.], np.float32).reshape(1, 1, 2, 1)
+UPS_X = np.arange(12, dtype=np.float32).reshape(2, 2, 1, 3)
+UPS_Y = np.array([[[[0, 1, 2], [0, 1, 2]], [[3, 4, 5], [3, 4, 5]]], [[[6, 7, 8], [6, 7, 8]], [[9, 10, 11], [9, 10, 11]]]], np.float32)
+ACT_X = np.array([-3.0, -1.0, 0.0, 2.0], np.float32)
+SIG_X = np.array([-20, -1.0, 0.0, 1.0, 20], np.float32)
+SIG_Y = np.array([2.0611537e-09, 2.6894143e-01, 5.0000000e-01, 7.3105860e-01, 1.0000000e+00], np.float32)
+HS_X = np.array([-3.0, -1.0, 0.0, 1.0, 3.0], np.float32)
+HS_Y = np.array([0., 0.3, 0.5, 0.7, 1.], np.float32)
+TANH_Y = np.array([-0.9950547, -0.7615942, 0., 0.7615942, 0.9950547], np.float32)
+
+
+def test_oracle_reproduces_the_documented_examples():
+    T = torch.from_numpy
+    assert torch.equal(K.maxpool(T(MAXPOOL_X), (2, 2)), T(MAXPOOL_Y))          # the odd third row is dropped ('valid')
+    assert torch.equal(K.upsample(T(UPS_X), (1, 2), "nearest"), T(UPS_Y))
+    assert K.activation(T(ACT_X), "leaky_relu", K.LEAKY_ALPHA).tolist() == pytest.approx([-0.9, -0.3, 0.0, 2.0])
+    assert K.activation(T(ACT_X), "leaky_relu", 0.1).tolist() == pytest.approx([-0.3, -0.1, 0.0, 2.0])
+    assert K.activation(T(ACT_X), "relu").tolist() == [0.0, 0.0, 0.0, 2.0]
+    assert np.allclose(K.activation(T(SIG_X), "sigmoid").numpy(), SIG_Y, rtol=1e-6, atol=0)
+    assert np.allclose(K.hard_sigmoid(T(HS_X)).numpy(), HS_Y, atol=1e-7)
+    assert np.allclose(torch.tanh(T(HS_X)).numpy(), TANH_Y, atol=1e-7)
+    sm = K.activation(torch.tensor([[1.0, 2.0, 3.0]]), "softmax")
+    assert abs(float(sm.sum()) - 1.0) < 1e-6 and np.allclose(sm.numpy(), np.exp([1, 2, 3]) / np.exp([1, 2, 3]).sum(), atol=1e-7)
+    # Concatenate docs: arange(20).reshape(2, 2, 5) with arange(20, 30).reshape(2, 1, 5) along axis 1 -> (2, 3, 5); Add docs: element-wise
+    a, b = np.arange(20).reshape(2, 2, 5), np.arange(20, 30).reshape(2, 1, 5)
+    assert np.concatenate([a, b], 1).shape == (2, 3, 5) and np.concatenate([a, b], 1)[0, 2].tolist() == [20, 21, 22, 23, 24]
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_documented_examples():
+    """The same vectors through the HIP kernels (C-ABI, both storage modes): max-pool with an odd row, nearest up-sampling by
+    (1, 2), LeakyReLU / ReLU / sigmoid through the add-activation and head-activation kernels."""
+    import ctypes as C
+    import gpu_util as U
+    ffi, SF = U.ffi, U.SF
+    for f32 in (True, False):
+        sfx = "_f32" if f32 else ""
+        dt = torch.float32 if f32 else torch.float16
+        # MaxPooling2D((2, 2)) on the 3 x 4 image
+        x = U.to_dev_nhwc(torch.from_numpy(MAXPOOL_X), dt)
+        y = torch.zeros((1, 1, 2, 8), dtype=dt, device="cuda")
+        if f32:
+            y = SF.split_pack(y)
+        ffi.call("seg_maxpool_fwd" + sfx, U.P(x), U.P(y), 1, 3, 4, 8, 2, 2, U.stream())
+        assert torch.equal(U.dev_values(y)[..., :1], torch.from_numpy(MAXPOOL_Y))
+        # UpSampling2D(size=(1, 2)), nearest
+        x = U.to_dev_nhwc(torch.from_numpy(UPS_X), dt)
+        y = torch.zeros((2, 2, 2, 8), dtype=dt, device="cuda")
+        if f32:
+            y = SF.split_pack(y)
+        ffi.call("seg_upsample_fwd" + sfx, U.P(x), U.P(y), 2, 2, 1, 8, 1, 2, 0, U.stream())
+        assert torch.equal(U.dev_values(y)[..., :3], torch.from_numpy(UPS_Y))
+        # LeakyReLU / ReLU / sigmoid as Activation layers (an add of one input)
+        for xs, act, alpha, want, tol in ((ACT_X, "leaky_relu", 0.3, [-0.9, -0.3, 0.0, 2.0], 1e-3), (ACT_X, "leaky_relu", 0.1, [-0.3, -0.1, 0.0, 2.0], 1e-3),
+                                          (ACT_X, "relu", 0.0, [0.0, 0.0, 0.0, 2.0], 0.0), (SIG_X, "sigmoid", 0.0, SIG_Y.tolist(), 1e-3)):
+            n = len(xs)
+            x = U.to_dev_nhwc(torch.from_numpy(xs).reshape(1, 1, n, 1).expand(1, 1, n, 8).contiguous(), dt)
+            y = torch.zeros_like(x)
+            ptrs = (C.c_void_p * 4)(x.data_ptr(), None, None, None)
+            ffi.call("seg_add_act_fwd" + sfx, ptrs, 1, U.P(y), n * 8, ffi.ACT[act], alpha, U.stream())
+            got = U.dev_values(y)[0, 0, :, 0].tolist()
+            assert got == pytest.approx(want, rel=(tol if not f32 else 1e-6), abs=1e-6 if f32 else 1e-3), (act, f32, got)
