@@ -8,7 +8,9 @@ Sources (docstring examples of the TF 2.x API docs):
   tf.keras.layers.UpSampling2D   - size (1, 2) on arange(12).reshape(2, 2, 1, 3)
   tf.keras.layers.LeakyReLU      - default alpha 0.3 and alpha = 0.1 on [-3, -1, 0, 2]
   tf.keras.layers.ReLU / activations.relu, activations.sigmoid, activations.tanh, activations.hard_sigmoid (0.2 x + 0.5)
-  tf.keras.layers.Concatenate / Add - the documented shapes / values"""
+  tf.keras.layers.Concatenate / Add - the documented shapes / values
+  tf.keras.optimizers.Adam / SGD / RMSprop - "opt.minimize(lambda: var ** 2 / 2, [var])" with learning_rate 0.1: 10 -> 9.9
+                                   (Adam: "the first step is -learning_rate * sign(grad)"), 1 -> 0.9 (SGD), 10 -> 9.683772 (RMSprop)"""
 import numpy as np
 import pytest
 import torch
@@ -42,6 +44,41 @@ def test_oracle_reproduces_the_documented_examples():
     # Concatenate docs: arange(20).reshape(2, 2, 5) with arange(20, 30).reshape(2, 1, 5) along axis 1 -> (2, 3, 5); Add docs: element-wise
     a, b = np.arange(20).reshape(2, 2, 5), np.arange(20, 30).reshape(2, 1, 5)
     assert np.concatenate([a, b], 1).shape == (2, 3, 5) and np.concatenate([a, b], 1)[0, 2].tolist() == [20, 21, 22, 23, 24]
+
+
+def test_oracle_optimizers_reproduce_the_documented_first_steps():
+    from oracle import train_ref as TR
+    w = {"w": torch.tensor([10.0])}
+    TR.KerasAdam(w, lr=0.1).step({"w": w["w"].clone()})                 # d(var^2 / 2) / dvar = var
+    assert float(w["w"]) == pytest.approx(9.9, abs=1e-6)
+    w = {"w": torch.tensor([1.0])}
+    TR.KerasOptimizer("SGD", w, lr=0.1).step({"w": w["w"].clone()})
+    assert float(w["w"]) == pytest.approx(0.9, abs=1e-7)
+    w = {"w": torch.tensor([10.0])}
+    TR.KerasOptimizer("RMSprop", w, lr=0.1).step({"w": w["w"].clone()})
+    assert float(w["w"]) == pytest.approx(9.683772, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_engine_optimizers_reproduce_the_documented_first_steps():
+    """seg_adam_step_ex / seg_optimizer_step_ex on a flat buffer holding the documented variable (the rest of the slice: zeros)."""
+    import gpu_util as U
+    M = U.M
+    segamd = __import__("segamd")
+    for name, w0, want in (("Adam", 10.0, 9.9), ("SGD", 1.0, 0.9), ("RMSprop", 10.0, 9.683772)):
+        m = segamd.unet_model_builder("UNet", 32, 32, 8, 1, num_channels=1, train_mode="from_scratch").ResNet50()
+        m.build(1, dtype="f32")
+        m.compile(loss="mse", optimizer=name, lr=0.1)
+        st = m.store
+        st.P.fill_(w0)
+        m._refresh_copies()
+        m._init_optimizer_state()
+        st.G.copy_(st.P)                                                 # gradient of var^2 / 2, unscaled (grad scale 1)
+        m.gs.fill_(1.0)
+        m.optimizer_step()
+        m._join_side()
+        torch.cuda.synchronize()
+        assert float(st.P.max()) == pytest.approx(want, abs=2e-6) and float(st.P.min()) == pytest.approx(want, abs=2e-6), name
 
 
 @pytest.mark.gpu
