@@ -115,3 +115,48 @@ def test_engine_reproduces_the_documented_examples():
             ffi.call("seg_add_act_fwd" + sfx, ptrs, 1, U.P(y), n * 8, ffi.ACT[act], alpha, U.stream())
             got = U.dev_values(y)[0, 0, :, 0].tolist()
             assert got == pytest.approx(want, rel=(tol if not f32 else 1e-6), abs=1e-6 if f32 else 1e-3), (act, f32, got)
+
+
+@pytest.mark.gpu
+def test_engine_metrics_reproduce_the_documented_examples():
+    """tf.keras.metrics docstring examples through metrics.MetricSet (the device counters / value-only loss launches): the example
+    is tiled over the whole output (ratios and means do not change, counts scale with the number of tiles).
+      BinaryAccuracy ([[1],[1],[0],[0]], [[0.98],[1],[0],[0.6]]) -> 0.75          Precision / Recall ([0,1,1,1], [1,0,1,1]) -> 0.6666667
+      TruePositives ([0,1,1,1],[1,0,1,1]) -> 2   FalsePositives ([0,1,0,0],[0,0,1,1]) -> 2   TrueNegatives ([0,1,0,0],[1,1,0,0]) -> 2
+      FalseNegatives ([0,1,1,1],[0,1,0,0]) -> 2   MeanSquaredError ([[0,1],[0,0]], [[1,1],[0,0]]) -> 0.25   RootMeanSquaredError -> 0.5
+      MeanAbsoluteError -> 0.25   CategoricalAccuracy ([[0,0,1],[0,1,0]], [[0.1,0.9,0.8],[0.05,0.95,0]]) -> 0.5"""
+    import importlib
+    import gpu_util as U
+    segamd = __import__("segamd")
+    MS = importlib.import_module(U.M.__name__.rsplit(".", 1)[0] + ".metrics")
+
+    def run(cout, names, y_true, y_pred):
+        m = segamd.unet_model_builder("UNet", 16, 16, 8, 1, num_channels=1, output_nums=cout, train_mode="from_scratch",
+                                      final_activation="softmax" if cout > 1 else "sigmoid").ResNet50()
+        m.build(1, dtype="f32")
+        y = m.out_heads[0].y
+        n = y.numel()
+        yt, yp = np.asarray(y_true, np.float32).reshape(-1), np.asarray(y_pred, np.float32).reshape(-1)
+        assert n % yp.size == 0
+        tiles = n // yp.size
+        y.copy_(torch.from_numpy(np.tile(yp, tiles)).reshape(y.shape))
+        ms = MS.MetricSet(m, names)
+        ms.update([torch.from_numpy(np.tile(yt, tiles)).reshape(y.shape)])
+        return ms.result(), tiles
+
+    r, _ = run(1, ["BinaryAccuracy"], [1, 1, 0, 0], [0.98, 1, 0, 0.6])
+    assert r["binary_accuracy"] == pytest.approx(0.75)
+    r, k = run(1, ["Precision", "Recall", "TruePositives"], [0, 1, 1, 1], [1, 0, 1, 1])
+    assert r["precision"] == pytest.approx(0.6666667) and r["recall"] == pytest.approx(0.6666667) and r["true_positives"] == 2 * k
+    r, k = run(1, ["FalsePositives"], [0, 1, 0, 0], [0, 0, 1, 1])
+    assert r["false_positives"] == 2 * k
+    r, k = run(1, ["TrueNegatives"], [0, 1, 0, 0], [1, 1, 0, 0])
+    assert r["true_negatives"] == 2 * k
+    r, k = run(1, ["FalseNegatives"], [0, 1, 1, 1], [0, 1, 0, 0])
+    assert r["false_negatives"] == 2 * k
+    r, _ = run(1, ["MeanSquaredError", "RootMeanSquaredError", "MeanAbsoluteError"], [0, 1, 0, 0], [1, 1, 0, 0])
+    assert r["mean_squared_error"] == pytest.approx(0.25) and r["root_mean_squared_error"] == pytest.approx(0.5)
+    assert r["mean_absolute_error"] == pytest.approx(0.25)
+    # (one-hot targets; 2 of 256 pixels per tile pair: 16 x 16 pixels x 3 classes = 768 values = 128 tiles of the 6-value example)
+    r, _ = run(3, ["CategoricalAccuracy"], [[0, 0, 1], [0, 1, 0]], [[0.1, 0.9, 0.8], [0.05, 0.95, 0]])
+    assert r["categorical_accuracy"] == pytest.approx(0.5)
