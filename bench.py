@@ -502,9 +502,20 @@ def main():
                 "roofline": roofline, "cpu_baseline": cpu, ("throughput_mode" if args.dtype == "f32" else "parity_mode"): parity,
                 "inference": inference, "rccl": rccl,
                 "extra_workloads": extras}
-        print(json.dumps(line), flush=True)
+        result = json.dumps(line)
+    # the JSON line is the LAST thing on stdout: tear the process group down and flush what C libraries (RCCL's version banner)
+    # still hold in their stdio buffers first
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(result, flush=True)
 
 
 if __name__ == "__main__":
