@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   const int PWn = W / PW, PHn = H / PH;
   const int npatch = g.N * PHn * PWn;
   const int lin0 = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-  const int cls = lin0 / gridDim.x, lin = lin0 - cls * gridDim.x;      // sub-pixel class of a transposed conv (0 otherwise)
+  // sub-pixel class of a transposed conv (0 otherwise).  Parity mode: class-fastest - the four classes of a patch run next to each
+  // other on one XCD and share the halo tile in its L2 (as igemm_halo2.hip does for the fp16 mode)
+  const int ncls_ = (int)gridDim.y;
+  const int cls = SPLIT ? lin0 % ncls_ : lin0 / (int)gridDim.x, lin = SPLIT ? lin0 / ncls_ : lin0 - cls * (int)gridDim.x;
   const int mb = lin % npatch, nb = lin / npatch;
   const int n0 = nb * BN;
   const int pn = mb / (PHn * PWn);
