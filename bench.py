@@ -317,6 +317,56 @@ def cpu_baseline(workload, gpu_batch):
                       f"workload, {cores} threads = the best of the recorded sweep on a box with {nproc} hardware threads, {dt:.1f} s"}
 
 
+def launch_plan(gpus, env, argv, free_port=None):
+    """What `python bench.py --gpus N ...` has to do BEFORE anything touches the GPU (pure host logic; tests/test_bench_launcher.py):
+      ("run", None)      this process is the (only / torchrun-started) rank: carry on;
+      ("spawn", cmd)     --gpus N > 1 without a torchrun environment: start `cmd` - one fresh child
+                         `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one rank per
+                         GPU - relay its output and exit with its code (a child process, never an exec: no HIP call has been made yet
+                         here, and none will be);
+      ("error", text)    WORLD_SIZE is set and differs from --gpus: the line would report a job that was not run."""
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            return "error", f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus} (or drop WORLD_SIZE)"
+        return "run", None
+    if gpus <= 1:
+        return "run", None
+    port = free_port() if free_port is not None else 29500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(cmd):
+    """Run the torchrun child, pass its stdout through, and keep the contract: the rank-0 JSON line is the LAST line of stdout."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    last_json, last_line = None, None
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        st = line.strip()
+        if st:
+            last_line = st
+            if st.startswith("{") and '"metric"' in st:
+                last_json = st
+    rc = proc.wait()
+    if last_json is not None and last_line != last_json:
+        print(last_json, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,16 +386,28 @@ def main():
     ap.add_argument("--dump-launches", default="", help="write the per-launch event timings of the profiled step to this JSON file")
     args = ap.parse_args()
 
+    # --gpus N is the job size.  N > 1 without torchrun's environment: this process becomes the launcher of N ranks (before any
+    # torch.cuda call); with it, WORLD_SIZE must agree - a scaling run must never silently measure another job.
+    what, payload = launch_plan(args.gpus, os.environ, sys.argv[1:], _free_port)
+    if what == "error":
+        raise SystemExit(payload)
+    if what == "spawn":
+        sys.exit(spawn_ranks(payload))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # (more ranks than GPUs - e.g. two gloo ranks on a one-GPU box to exercise the exchange path - share devices)
-    local_rank %= max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("SEG_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+    ndev = max(torch.cuda.device_count(), 1)
+    if world > ndev and backend == "nccl":
+        raise SystemExit(f"bench.py: --gpus {world} on a node with {ndev} GPU(s): RCCL needs one device per rank "
+                         "(SEG_DIST_BACKEND=gloo lets ranks share a device to exercise the exchange path)")
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dp = importlib.import_module(PKG + ".dp")
-    backend = os.environ.get("SEG_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1 or args.force_exchange:
         os.environ["LOCAL_RANK"] = str(local_rank)
         dp.init_process_group_from_env(backend)

@@ -40,7 +40,7 @@ enum { SEG_LOSS_MSE = 0, SEG_LOSS_BCE = 1, SEG_LOSS_CCE = 2, SEG_LOSS_MAE = 3, S
 #define SEG_MAX_CLS 4
 
 const char* seg_last_error(void);
-int seg_abi_version(void);
+int seg_abi_version(void);      /* 28 bits of sha256(this header), compiled in by build_ext.py; the loader recomputes and compares */
 
 /* Geometry of one (transposed / strided) convolution as an implicit GEMM over "logical pixels" (n, i, j),
  * i < Hl, j < Wl, evaluated for ncls output classes (1 for a convolution, 4 = sub-pixel parity classes of a
@@ -389,8 +389,10 @@ int seg_transpose_w_multi(const seg_transpose_desc* descs_dev, int32_t n, int32_
 int seg_cast_f32_f16(const float* x, void* y, int64_t n, seg_stream_t stream);
 /* flat fp32 buffer -> its split image (parity mode's GEMM weight operand): n a multiple of 8, 32-byte aligned  */
 int seg_cast_f32_split(const float* x, void* y, int64_t n, seg_stream_t stream);
-/* fp32 NHWC [npix][C] -> fp16 [npix][cs] zero padded (model input)                                             */
-int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
+/* fp32 NHWC [npix][C] -> fp16 [npix][cs] zero padded (model input).  overflow (device int32, may be NULL): += the
+ * number of input elements that are NaN, +-Inf or |x| >= 65504 - values the reference's fp32 tensors hold and an fp16 /
+ * split-pair element cannot (they turn into Inf / NaN downstream; the engine raises on a non-zero count)          */
+int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, int32_t* overflow, seg_stream_t stream);
 /* fp16 [npix][cs] columns [coff, coff+C) -> fp32 [npix][C]                                                     */
 int seg_unpack_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
 
@@ -464,7 +466,7 @@ int seg_copy_channels_f32(const void* src, int32_t src_cs, int32_t src_coff, voi
 int seg_transpose_w_f32(const float* w, void* wt, int32_t rows, int32_t T, int32_t K, int32_t rows_pad,
                         seg_stream_t stream);
 int seg_transpose_w_multi_f32(const seg_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, seg_stream_t stream);
-int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream);
+int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, int32_t* overflow, seg_stream_t stream);
 int seg_unpack_f32_f32(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream);
 
 

@@ -146,6 +146,47 @@ def test_graphed_train_step_matches_eager():
     same_training(p0, p1, l0, l1)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_predict_after_graph_replays_uses_the_updated_weights(dtype):
+    """predict -> N graph replays -> predict: the replays move gamma / beta / the moving statistics on the device, so the folded
+    inference-mode BN coefficients cached by the first predict (ConvOp.inf_scale / inf_shift) must be re-derived - the second
+    predict has to equal the one of a model that took the same steps eagerly (advisor finding, round 3)."""
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.rand((4, 32, 32, 3), generator=g).cuda() for _ in range(3)]
+
+    def run(graphed):
+        m = build(dtype, loss="mse")
+        tgs = [[(x[..., :1] > 0.5).float() for _ in m.out_heads] for x in xs]
+        step = m.graphed_train_step(xs[0], tgs[0]) if graphed else m.train_step
+        before = m.predict(xs[0])[0].copy()               # caches the folded coefficients of the initial weights
+        for x, tg in zip(xs, tgs):
+            step(x, tg)
+        return before, m.predict(xs[0])[0]
+
+    b0, a0 = run(False)
+    b1, a1 = run(True)
+    assert np.array_equal(b0, b1)
+    assert float(np.abs(a0 - b0).max()) > 1e-3            # three steps at lr 2e-3 do change the prediction ...
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    assert float(np.abs(a1 - a0).max()) < tol, float(np.abs(a1 - a0).max())      # ... and the replayed model predicts with the NEW weights
+
+
+def test_input_outside_the_storage_range_is_reported():
+    """|x| >= 65504 / NaN / Inf in the input: the reference's fp32 path computes with it, this engine's storage cannot hold it -
+    predict() and fit() raise instead of returning NaN masks silently (advisor finding, round 3)."""
+    m = build("f32", loss="mse")
+    x = torch.rand(4, 32, 32, 3)
+    m.predict(x)                                   # in range: fine
+    x[1, 3, 4, 2] = 1e5
+    x[2, 0, 0, 0] = float("nan")
+    with pytest.raises(ValueError, match="2 input element"):
+        m.predict(x)
+    m.predict(torch.rand(4, 32, 32, 3))            # the counter was reset by the report
+    t = [torch.rand(4, 32, 32, 1)] * len(m.out_heads)
+    with pytest.raises(ValueError, match="input element"):
+        H.fit(m, [(x, t)], epochs=1)
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_rccl_exchange_path_single_rank(overlap):
     """The data-parallel exchange through real RCCL launches (group of one rank, force_exchange): the all-reduces are
@@ -296,6 +337,23 @@ def test_nonfinite_counter_is_read_one_step_late_without_joining_the_side_stream
     m.store.nonfinite.fill_(7)                      # as if the optimiser had skipped 7 elements in this step
     assert m.nonfinite_updates_async() == 0         # ... reported one call later
     assert m.nonfinite_updates_async() == 7 and m.nonfinite_updates() == 0
+    # nothing is lost at the end of an epoch: the drain returns the queued value plus what was counted since
+    m.store.nonfinite.fill_(3)
+    assert m.nonfinite_updates_async() == 0
+    m.store.nonfinite.fill_(2)
+    assert m.nonfinite_drain() == 5 and m.nonfinite_drain() == 0
+    # a one-batch epoch with a skipped update is logged in THAT epoch and backs the scale off
+    real_step = m.train_step
+    def step_with_overflow(x_, t_):
+        lv = real_step(x_, t_)
+        m._join_side()
+        m.store.nonfinite.fill_(11)
+        return lv
+    m.train_step = step_with_overflow
+    m.grad_target = 1024.0
+    hist = H.fit(m, [(x, t)], epochs=1)
+    m.train_step = real_step
+    assert hist["nonfinite_grads"] == [11.0] and m.grad_target == 512.0
     # fit(): back-off on a skipped step, growth after a run of clean ones
     H.LOSS_SCALE_GROWTH_INTERVAL, keep = 3, H.LOSS_SCALE_GROWTH_INTERVAL
     try:

@@ -1098,7 +1098,14 @@ def test_pack_unpack_input():
     x = torch.rand(3, 5, 7, 3)
     y = torch.zeros((3, 5, 7, 8), dtype=torch.float16, device="cuda")
     xd = x.cuda()
-    ffi.call("seg_pack_input", P(xd), P(y), 3 * 5 * 7, 3, 8, stream())
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ffi.call("seg_pack_input", P(xd), P(y), 3 * 5 * 7, 3, 8, P(cnt), stream())
+    assert int(cnt.cpu()) == 0
+    bad = x.clone()
+    bad[0, 0, 0, 0], bad[1, 1, 1, 1], bad[2, 2, 2, 2], bad[2, 4, 6, 2] = 65504.0, float("inf"), float("nan"), -7e4
+    ffi.call("seg_pack_input", P(bad.cuda()), P(torch.zeros_like(y)), 3 * 5 * 7, 3, 8, P(cnt), stream())
+    assert int(cnt.cpu()) == 4               # NaN, Inf and |x| >= 65504 are counted; the padding channels never are
+    ffi.call("seg_pack_input", P(xd), P(y), 3 * 5 * 7, 3, 8, None, stream())
     back = torch.zeros(3, 5, 7, 3, device="cuda")
     ffi.call("seg_unpack_f32", P(y), P(back), 3 * 5 * 7, 3, 8, 0, stream())
     torch.cuda.synchronize()

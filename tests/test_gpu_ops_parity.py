@@ -264,7 +264,7 @@ def test_element_granular_copies_and_the_boundary_conversions():
     x = torch.rand(N * H * W, 3)
     xd = x.cuda()
     packed = torch.zeros((N * H * W, 8), dtype=F32, device="cuda")
-    ffi.call("seg_pack_input_f32", P(xd), P(packed), N * H * W, 3, 8, stream())
+    ffi.call("seg_pack_input_f32", P(xd), P(packed), N * H * W, 3, 8, None, stream())
     out = torch.zeros((N * H * W, 3), device="cuda")
     ffi.call("seg_unpack_f32_f32", P(packed), P(out), N * H * W, 3, 8, 0, stream())
     torch.cuda.synchronize()

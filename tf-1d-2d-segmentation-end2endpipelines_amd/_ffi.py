@@ -120,7 +120,7 @@ _PROTOS = {
     "seg_transpose_w_multi": ([vp, i32, i32, vp], C.c_int),
     "seg_cast_f32_f16": ([vp, vp, i64, vp], C.c_int),
     "seg_cast_f32_split": ([vp, vp, i64, vp], C.c_int),
-    "seg_pack_input": ([vp, vp, i64, i32, i32, vp], C.c_int),
+    "seg_pack_input": ([vp, vp, i64, i32, i32, vp, vp], C.c_int),
     "seg_unpack_f32": ([vp, vp, i64, i32, i32, i32, vp], C.c_int),
 }
 
@@ -161,8 +161,13 @@ def lib():
         L.seg_last_error.restype = C.c_char_p
         L.seg_wgrad_taps_per_block.restype = C.c_int
         L.seg_wgrad_halo_patch.restype = C.c_int
-        if L.seg_abi_version() != 1:
-            raise ImportError("libseg_hip.so ABI version mismatch; rebuild")
+        from .build_ext import abi_version
+        if os.environ.get("SEG_LIB"):
+            print(f"[seg_hip] SEG_LIB: loading {LIB_PATH}", flush=True)
+        have, want = L.seg_abi_version(), abi_version()
+        if have != want:
+            raise ImportError(f"{LIB_PATH}: built against another include/seg_hip.h (ABI {have:#x}, this tree {want:#x}); rebuild "
+                              "(python -c 'import __graft_entry__ as g; g.build()')")
         _lib = L
     return _lib
 

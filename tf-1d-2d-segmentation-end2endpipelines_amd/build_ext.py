@@ -16,7 +16,24 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_build")
 OUT = os.path.join(HERE, "libseg_hip.so")
 STAMP = OUT + ".srchash"          # fingerprint of the sources the shipped .so was built from
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
+BASE_CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
+ABI_HEADER = os.path.join(ROOT, "include", "seg_hip.h")
+
+
+def abi_version() -> int:
+    """The C ABI's version = 28 bits of the content hash of include/seg_hip.h: every signature or struct change is a new version
+    without anybody remembering to bump a number.  Compiled into the library (-DSEG_ABI_VERSION, returned by seg_abi_version())
+    and recomputed from the header by _ffi.lib(), which refuses a library built against another header (a SEG_LIB=<older build>
+    used for an A/B would otherwise resolve every symbol and read shifted arguments)."""
+    with open(ABI_HEADER, "rb") as fh:
+        return int(hashlib.sha256(fh.read()).hexdigest()[:7], 16)
+
+
+def _cflags():
+    return BASE_CFLAGS + [f"-DSEG_ABI_VERSION={abi_version()}"]
+
+
+CFLAGS = _cflags()
 
 
 def sources():
@@ -39,7 +56,7 @@ def _obj_key(src, hdrs) -> str:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(CFLAGS).encode())
+    h.update(" ".join(_cflags()).encode())
     return h.hexdigest()
 
 
@@ -58,7 +75,7 @@ def _fingerprint() -> str:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(CFLAGS).encode())
+    h.update(" ".join(_cflags()).encode())
     return h.hexdigest()
 
 
@@ -82,7 +99,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if force or _stale(_obj(s), key):
             if os.path.exists(_obj(s) + ".key"):
                 os.remove(_obj(s) + ".key")
-            cmd = [hipcc] + CFLAGS + inc + ["-c", s, "-o", _obj(s)]
+            cmd = [hipcc] + _cflags() + inc + ["-c", s, "-o", _obj(s)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((s, key, subprocess.Popen(cmd)))

@@ -17,7 +17,10 @@ void seg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* seg_last_error(void) { return g_err; }
-extern "C" int seg_abi_version(void) { return 1; }
+#ifndef SEG_ABI_VERSION
+#error "build through build_ext.py: SEG_ABI_VERSION (28 bits of the content hash of include/seg_hip.h) must be defined"
+#endif
+extern "C" int seg_abi_version(void) { return SEG_ABI_VERSION; }
 
 namespace {
 
@@ -1579,12 +1582,19 @@ __global__ __launch_bounds__(TPB) void cast_split_kernel(const float* x, split_t
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void pack_input_kernel(const float* x, T* y, int64_t npix, int C, int cs) {
+__global__ __launch_bounds__(TPB) void pack_input_kernel(const float* x, T* y, int64_t npix, int C, int cs, int* overflow) {
   const int64_t n = npix * cs;
+  int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
     const int c = (int)(i % cs);
     const int64_t pix = i / cs;
-    store_elem(y + pix * cs, c, (c < C) ? x[pix * C + c] : 0.f);
+    const float v = (c < C) ? x[pix * C + c] : 0.f;
+    bad += !(fabsf(v) < 65504.f);          // NaN, Inf, or beyond what an fp16 / split-pair element can hold: it would become Inf downstream
+    store_elem(y + pix * cs, c, v);
+  }
+  if (overflow != nullptr && __any(bad != 0)) {      // (rare: one atomic per wave that saw such an element)
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(overflow, bad);
   }
 }
 
@@ -2109,14 +2119,14 @@ extern "C" int seg_cast_f32_split(const float* x, void* y, int64_t n, seg_stream
 }
 
 template <typename T>
-static int seg_pack_input_impl(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) {
+static int seg_pack_input_impl(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, int32_t* overflow, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && npix > 0 && C > 0 && C <= cs, "seg_pack_input: bad arguments");
-  hipLaunchKernelGGL((pack_input_kernel<T>), dim3(grid_for(npix * cs)), dim3(TPB), 0, ST(stream), x, (T*)y, npix, C, cs);
+  hipLaunchKernelGGL((pack_input_kernel<T>), dim3(grid_for(npix * cs)), dim3(TPB), 0, ST(stream), x, (T*)y, npix, C, cs, overflow);
   SEG_CHECK_LAUNCH("seg_pack_input");
   return SEG_OK;
 }
-extern "C" int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<half_t>(x, y, npix, C, cs, stream); }
-extern "C" int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, seg_stream_t stream) { return seg_pack_input_impl<split_t>(x, y, npix, C, cs, stream); }
+extern "C" int seg_pack_input(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, int32_t* overflow, seg_stream_t stream) { return seg_pack_input_impl<half_t>(x, y, npix, C, cs, overflow, stream); }
+extern "C" int seg_pack_input_f32(const float* x, void* y, int64_t npix, int32_t C, int32_t cs, int32_t* overflow, seg_stream_t stream) { return seg_pack_input_impl<split_t>(x, y, npix, C, cs, overflow, stream); }
 
 template <typename T>
 static int seg_unpack_f32_impl(const void* x, float* y, int64_t npix, int32_t C, int32_t cs, int32_t coff, seg_stream_t stream) {

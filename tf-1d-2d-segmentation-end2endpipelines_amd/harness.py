@@ -249,6 +249,16 @@ def fit(model, train_batches, epochs: int, val_batches=None,
                     if clean >= LOSS_SCALE_GROWTH_INTERVAL and model.grad_target < GRAD_TARGET:
                         model.grad_target = min(model.grad_target * 2.0, GRAD_TARGET)
                         clean = 0
+        if hasattr(model, "nonfinite_drain"):
+            # what the one-step-late counter has not reported yet (the epoch's last step, or all of it when the loader had one
+            # batch): this epoch's log and the loss-scale back-off see every step
+            bad = model.nonfinite_drain()
+            if bad:
+                skipped += bad
+                clean = 0
+                model.grad_target = max(model.grad_target / 2.0, 1.0)
+        if hasattr(model, "check_input_range"):
+            model.check_input_range()            # raises on input elements the fp16 / split-pair storage cannot hold
         if hasattr(train_batches, "on_epoch_end"):
             train_batches.on_epoch_end()
         logs = {"loss": tot / max(n, 1)}

@@ -602,7 +602,7 @@ class InputOp(Op):
 
     def forward(self, training):
         x = self.m._x
-        call("seg_pack_input", _p(x), _p(self.t.buf), self.t.npix, self.Cin, self.t.cs, _stream())
+        call("seg_pack_input", _p(x), _p(self.t.buf), self.t.npix, self.Cin, self.t.cs, _p(self.m.input_overflow), _stream())
 
 
 class ConvOp(Op):
@@ -1337,7 +1337,10 @@ class SegModel:
     def __init__(self, graph: Graph, batch_size: Optional[int] = None, seed: int = 0, dtype: str = "f32"):
         """dtype: 'f32' = the parity mode - tensors stored as split fp16 pairs (x ~= hi + lo / 2048, ~22 significant bits), every
         product three fp16 MFMAs into fp32 accumulators: outputs within 1e-3 of the reference's fp32 arithmetic, equal masks;
-        'f16' = fp16 activations / MFMA operands with fp32 accumulation (throughput mode: 2.3x faster, misses the 1e-3 tolerance)."""
+        'f16' = fp16 activations / MFMA operands with fp32 accumulation (throughput mode: 2.3x faster, misses the 1e-3 tolerance).
+        RANGE: both modes keep fp16's dynamic range - an input, activation or gradient with |x| >= 65504 becomes Inf / NaN (the
+        reference's fp32 does not).  Inputs are checked (check_input_range: predict / fit raise), non-finite gradients are skipped and
+        counted by the optimiser (nonfinite_updates); activations are bounded by BatchNormalization in every model of the reference."""
         if dtype not in ("f16", "f32"):
             raise ValueError("dtype must be 'f16' or 'f32'")
         self.graph = graph
@@ -1442,6 +1445,8 @@ class SegModel:
             set_alpha()
             graph.replay()
             self._g_clean = True          # the replayed step ended by clearing the gradient buffer
+            for op in self.ops:           # the replay moved the weights and the moving statistics on the device: whatever the host
+                op.post_step()            # caches about them (the folded inference-mode BN coefficients) is stale
             return lv
         step.graph = graph
         return step
@@ -1517,6 +1522,7 @@ class SegModel:
         self.gs = torch.ones(2, dtype=torch.float32, device=_dev())        # [grad scale S, 1/S]
         self.amax = torch.zeros(1, dtype=torch.float32, device=_dev())
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=_dev())
+        self.input_overflow = torch.zeros(1, dtype=torch.int32, device=_dev())     # input elements no fp16 / split-pair element can hold (seg_pack_input)
         cons = g.consumers()
         live = g.live_nodes()
         outset = set(g.outputs)
@@ -1855,7 +1861,9 @@ class SegModel:
     def nonfinite_updates_async(self) -> int:
         """The same counter without stalling the training loop: returns what the PREVIOUS call collected (one step late, 0 the
         first time) and queues, behind the optimiser slices of the step just issued, a copy of the counter into pinned host memory
-        followed by its reset.  Nothing joins the side stream, so the optimiser keeps running under the next forward pass."""
+        followed by its reset.  Nothing joins the side stream, so the optimiser keeps running under the next forward pass; the side
+        stream first catches up with the current one (an optimiser that ran there - a graph replay, the single-stream schedule -
+        must have finished counting before the counter is copied and cleared).  `nonfinite_drain()` collects what is still pending."""
         if _DryRun.on:
             return 0
         prev = 0
@@ -1865,7 +1873,10 @@ class SegModel:
             prev = int(pend[1][0])
         if getattr(self, "_nf_host", None) is None:
             self._nf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        stream = self.side_stream if self.side_stream is not None else torch.cuda.current_stream()
+        cur = torch.cuda.current_stream()
+        stream = self.side_stream if self.side_stream is not None else cur
+        if stream is not cur:
+            stream.wait_stream(cur)
         with torch.cuda.stream(stream):
             self._nf_host.copy_(self.store.nonfinite, non_blocking=True)
             self.store.nonfinite.zero_()
@@ -1873,6 +1884,32 @@ class SegModel:
             ev.record(stream)
         self._nf_pending = (ev, self._nf_host)
         return prev
+
+    def nonfinite_drain(self) -> int:
+        """Everything the asynchronous counter has not reported yet - the value queued by the last nonfinite_updates_async() plus
+        what the optimiser counted since - with one blocking read (end of an epoch / of fit: the logs and the loss-scale back-off
+        see every step, also the last one)."""
+        if _DryRun.on:
+            return 0
+        n = 0
+        pend = getattr(self, "_nf_pending", None)
+        if pend is not None:
+            pend[0].synchronize()
+            n += int(pend[1][0])
+            self._nf_pending = None
+        return n + self.nonfinite_updates(reset=True)
+
+    def check_input_range(self):
+        """Raises when an input element handed to forward() since the last check was NaN, +-Inf or |x| >= 65504: the reference's fp32
+        tensors hold such values, this engine's fp16 / split-pair elements do not - they would turn into Inf / NaN downstream.
+        (Reads a device counter: synchronises.  predict() and harness.fit call it where they synchronise anyway.)"""
+        if _DryRun.on or not self.built:
+            return
+        n = int(self.input_overflow.cpu())
+        if n:
+            self.input_overflow.zero_()
+            raise ValueError(f"{n} input element(s) are NaN / Inf or outside |x| < 65504, the range of this engine's fp16 / split-pair storage "
+                             "(DESIGN.md section 2); normalise the input (the reference's loaders divide images by 255)")
 
     def _refresh_copies(self):
         st = self.store
@@ -1936,6 +1973,7 @@ class SegModel:
                     xb = torch.cat([xb, torch.zeros((N - k,) + tuple(xb.shape[1:]), dtype=xb.dtype, device=xb.device)], 0)
                 parts.append([o[:k].cpu().numpy() for o in self.forward(xb, training=False)])
             outs = [np.concatenate([p[i] for p in parts], 0) for i in range(len(parts[0]))]
+        self.check_input_range()
         return outs if len(outs) > 1 else outs[0]
 
     def adam_slices(self) -> List[Tuple[int, int, int]]:
