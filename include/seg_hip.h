@@ -233,20 +233,43 @@ int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, 
 int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha,
                     seg_stream_t stream);
 /* dx_i (+)= dy * act'(y) for every i with dxs[i] != NULL; accumulate is a bit mask over i                      */
-/* The tail of a MultiResBlock / ResPath, BatchNormalization(ReLU(a + b)) (unet_variants.py:97-99, :118-120), as two fused passes:
- * forward  y = act(sum_k (x_k * scales[k] + shifts[k])) plus per-channel partial sums of y and y^2 (stats[nparts][2][cs], the
- *          operand of seg_bn_finalize for the BatchNormalization that follows).  scales / shifts: NULL, or per input NULL (identity)
- *          or [cs] floats - an input that is itself a BatchNormalization output is normalised on the fly from its pre-BN tensor
- *          (MultiResBlock: BN(cat[c3,c5,c7]) is never written out).  Tensors are dense [npix][cs].
- * backward dx_k (+)= [x > 0] * scale * (dy - c1 - xhat * c2) for every input k of the add (x = the BatchNormalization's input = the
- *          ReLU's output; relu_mask = 0 without the ReLU): replaces seg_bn_act_bwd_apply + seg_add_act_bwd.                        */
-int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y,
-                          int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
-int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
-                            int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
-                            int32_t relu_mask, seg_stream_t stream);
 int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
                     float alpha, int32_t accumulate_mask, seg_stream_t stream);
+/* The tail of a MultiResBlock / ResPath, BatchNormalization(ReLU(a + b)) (unet_variants.py:97-99, :118-120), as fused passes.
+ * A VIRTUAL CONCATENATION (seg_cat_desc) names up to four tensors whose channel counts need not be multiples of 8 - MultiResBlock's
+ * cat[c3x3, c5x5, c7x7] (unet_variants.py:95): 5 + 10 + 16 channels at W = 32 -; piece k supplies channels [coff, coff + C) of the
+ * concatenation (coff = the sum of the C before it).  The kernels fetch the pieces' 8-channel groups whole and assemble the rows of
+ * the concatenation in LDS; the concatenated tensor never exists in memory.
+ * forward  y = act(sum_k pre_k(x_k) + [cat * cat_scale + cat_shift]), zero beyond c_valid, plus per-channel partial sums of y and
+ *          y^2 (stats[nparts][2][cs], the operand of seg_bn_finalize for the BatchNormalization that follows).
+ *          pre_k(x) = x, or relus[k] ? max(x * scales[k] + shifts[k], 0) : x * scales[k] + shifts[k] ([cs] floats each): an input
+ *          that is a Conv_Block's output (conv -> BN -> ReLU, unet_variants.py:7-14) with no other consumer is normalised on load
+ *          from the conv's raw output and never written.  cat_scale / cat_shift = the BatchNormalization over the concatenation
+ *          (MultiResBlock's BN(cat): unet_variants.py:96), NULL = identity.  n = 0 and y = NULL with a cat: only the statistics of
+ *          the concatenation (the operand of THAT BatchNormalization's seg_bn_finalize).  Tensors are dense [npix][cs], cs <= 2048.
+ * backward dx_k (+)= [x > 0] * scale * (dy - c1 - xhat * c2) for every input k of the add with dxs[k] != NULL (x = the
+ *          BatchNormalization's input = the ReLU's output; relu_mask = 0 without the ReLU): replaces seg_bn_act_bwd_apply +
+ *          seg_add_act_bwd.  With a cat: additionally cat_partial[nparts][2][cs] = per-block sums of dx and dx * xhat_cat
+ *          (xhat_cat from cat_mean / cat_invstd) - the operand of seg_bn_bwd_finalize for the BatchNormalization over the
+ *          concatenation, whose input gradient seg_cat_bn_bwd_scatter then writes to the pieces:
+ *          piece.dx (+)= scale * (g - c1 - xhat_cat * c2) restricted to the piece's channels, whole groups, padding zero.      */
+typedef struct {
+  const void* x;      /* piece [npix][cs]: its first C channels belong to the concatenation                                 */
+  void* dx;           /* seg_cat_bn_bwd_scatter: gradient of the piece, same layout (NULL: not wanted)                      */
+  int32_t cs, C;
+  int32_t coff;       /* first channel of the piece inside the concatenation                                                */
+  int32_t acc;        /* seg_cat_bn_bwd_scatter: add to dx instead of storing                                               */
+} seg_cat_piece;
+typedef struct { int32_t n; seg_cat_piece p[4]; } seg_cat_desc;
+int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n,
+                          const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,
+                          int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
+int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
+                            int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
+                            int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
+                            float* cat_partial, int32_t nparts, seg_stream_t stream);
+int seg_cat_bn_bwd_scatter(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,
+                           const float* invstd, const float* c1, const float* c2, seg_stream_t stream);
 
 /* ---- channel-slice copy (materialised concatenate(axis=-1), unet_variants.py:95, when a consumer cannot walk the
  * pieces: BatchNormalization over cat[c3x3,c5x5,c7x7] in MultiResBlock).  dst[p][dst_coff+c] (+)= src[p][src_coff+c],
@@ -441,11 +464,15 @@ int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem
                         seg_stream_t stream);
 int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
                         float alpha, int32_t accumulate_mask, seg_stream_t stream);
-int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y,
-                              int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
+int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus,
+                              int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix,
+                              int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
 int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
                                 int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
-                                int32_t relu_mask, seg_stream_t stream);
+                                int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
+                                float* cat_partial, int32_t nparts, seg_stream_t stream);
+int seg_cat_bn_bwd_scatter_f32(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,
+                               const float* invstd, const float* c1, const float* c2, seg_stream_t stream);
 int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs,
                           seg_stream_t stream);
 int seg_mul_bcast_bwd_f32(const void* dy, const void* a, const void* r, void* da, void* dr, int64_t npix, int32_t cs,

@@ -1103,7 +1103,8 @@ def test_pack_unpack_input():
     assert int(cnt.cpu()) == 0
     bad = x.clone()
     bad[0, 0, 0, 0], bad[1, 1, 1, 1], bad[2, 2, 2, 2], bad[2, 4, 6, 2] = 65504.0, float("inf"), float("nan"), -7e4
-    ffi.call("seg_pack_input", P(bad.cuda()), P(torch.zeros_like(y)), 3 * 5 * 7, 3, 8, P(cnt), stream())
+    badd, y2 = bad.cuda(), torch.zeros_like(y)            # (held: P() only takes the address)
+    ffi.call("seg_pack_input", P(badd), P(y2), 3 * 5 * 7, 3, 8, P(cnt), stream())
     assert int(cnt.cpu()) == 4               # NaN, Inf and |x| >= 65504 are counted; the padding channels never are
     ffi.call("seg_pack_input", P(xd), P(y), 3 * 5 * 7, 3, 8, None, stream())
     back = torch.zeros(3, 5, 7, 3, device="cuda")

@@ -104,7 +104,7 @@ def test_fused_tail_add_relu_statistics_and_fanout_backward():
     y = torch.zeros_like(ad)
     nparts = 5
     stats = torch.zeros(nparts * 2 * cs, device="cuda")
-    ffi.call("seg_add_act_stats_fwd_f32", xs, scs, shs, 2, P(y), npix, cs, ACT["relu"], 0.0, P(stats), nparts, stream())
+    ffi.call("seg_add_act_stats_fwd_f32", xs, scs, shs, None, 2, None, None, None, P(y), npix, cs, Cc, ACT["relu"], 0.0, P(stats), nparts, stream())
     torch.cuda.synchronize()
     s = torch.relu(a + b * s1 + h1)
     assert rel(val(y, Cc), s) < TOL
@@ -126,9 +126,129 @@ def test_fused_tail_add_relu_statistics_and_fanout_backward():
     d2 = dev(prev)
     gp = (C.c_void_p * 4)(d1.data_ptr(), d2.data_ptr(), None, None)
     dyd, keep = dev(dy), [pad(v) for v in (gamma * invstd, mean, invstd, c1, c2)]      # (held: P() only takes the address)
-    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dyd), P(y), gp, 2, 0b10, npix, cs, *[P(t) for t in keep], 1, stream())
+    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dyd), P(y), gp, 2, 0b10, npix, cs, *[P(t) for t in keep], 1, None, None, None, None, 0, stream())
     torch.cuda.synchronize()
     assert rel(val(d1, Cc), want) < 2e-5 and rel(val(d2, Cc), want + prev) < 2e-5
+
+
+@pytest.mark.parametrize("f32", [True, False])
+@pytest.mark.parametrize("chans,W", [((5, 10, 16), 16), ((10, 21, 32), 24), ((3, 9), 8), ((85, 170, 256), 4)])
+def test_multires_tail_over_a_virtual_concatenation(chans, W, f32):
+    """BN2(ReLU(ReLU(za * sa + ha) + BN1(cat[p1, p2, p3]))) - MultiResBlock's tail (unet_variants.py:95-99) with the shortcut
+    Conv_Block normalised on load and the concatenation never materialised (seg_cat_desc): the statistics of the concatenation,
+    the fused forward, the fan-out backward with BN1's sums riding along, and the scatter of d cat onto the pieces, against autograd.
+    Channel counts as in the MultiResUNet at W = 32 (level 0: 5 + 10 + 16; level 1: 10 + 21 + 32; level 4: 85 + 170 + 256)."""
+    sfx = "_f32" if f32 else ""
+    dt = F32 if f32 else torch.float16
+    tol = 2e-5 if f32 else 6e-3
+    N, H = 2, 6
+    Cc = sum(chans)
+    cs, npix = U.r8(Cc), N * H * W
+    g = torch.Generator().manual_seed(7)
+    pieces = [torch.randn(N, H, W, c, generator=g) * 1.5 + 0.3 for c in chans]
+    za = torch.randn(N, H, W, Cc, generator=g)
+    sa, ha = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    gamma1, beta1 = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
+    gamma2 = torch.rand(Cc, generator=g) + 0.5
+    dy = torch.randn(N, H, W, Cc, generator=g)
+    rd = (lambda t: t) if f32 else U.h16                    # the values the kernels see
+    pieces, za, dy = [rd(t) for t in pieces], rd(za), rd(dy)
+    pdev = [U.to_dev_nhwc(t, dt) for t in pieces]
+    pgrad = [torch.full_like(t, 3.0) for t in pdev]         # (stale contents: the scatter must overwrite whole groups, padding included)
+    zad = U.to_dev_nhwc(za, dt)
+    pad = lambda v, fill=0.0: fdev(np.concatenate([v.detach().numpy(), np.full(cs - Cc, fill, np.float32)]))
+    cat = ffi.CatDesc()
+    cat.n, off = len(chans), 0
+    for k, (t, c) in enumerate(zip(pdev, chans)):
+        cat.p[k].x, cat.p[k].dx, cat.p[k].cs, cat.p[k].C, cat.p[k].coff, cat.p[k].acc = t.data_ptr(), pgrad[k].data_ptr(), t.shape[3], c, off, 0
+        off += c
+    # ---- statistics of the concatenation (the operand of BN1's finalize)
+    nparts = 6
+    st1 = torch.full((nparts * 2 * cs,), 9.0, device="cuda")
+    ffi.call("seg_add_act_stats_fwd" + sfx, None, None, None, None, 0, C.byref(cat), None, None, None, npix, cs, Cc, 0, 0.0, P(st1), nparts, stream())
+    catv = torch.cat(pieces, -1)
+    s1 = st1.reshape(nparts, 2, cs).sum(0).cpu()
+    assert rel(s1[0, :Cc], catv.sum((0, 1, 2))) < 1e-5 and rel(s1[1, :Cc], (catv * catv).sum((0, 1, 2))) < 1e-5
+    assert float(s1[:, Cc:].abs().max()) == 0.0 if cs > Cc else True
+    # ---- reference graph
+    prs = [t.clone().requires_grad_(True) for t in pieces]
+    zar = za.clone().requires_grad_(True)
+    catr = torch.cat(prs, -1)
+    mean1, var1 = catr.mean((0, 1, 2)), catr.var((0, 1, 2), unbiased=False)
+    invstd1 = torch.rsqrt(var1 + 1e-3)
+    bn1 = (catr - mean1) * invstd1 * gamma1 + beta1
+    a = torch.relu(zar * sa + ha)
+    a.retain_grad()
+    s = torch.relu(a + bn1)
+    mean2, var2 = s.mean((0, 1, 2)), s.var((0, 1, 2), unbiased=False)
+    invstd2 = torch.rsqrt(var2 + 1e-3)
+    out = (s - mean2) * invstd2 * gamma2
+    (out * dy).sum().backward()
+    # ---- fused forward
+    sc1, sh1 = (gamma1 * invstd1).detach(), (beta1 - mean1 * gamma1 * invstd1).detach()
+    keep = [pad(sa), pad(ha), pad(sc1), pad(sh1)]
+    xs = (C.c_void_p * 4)(zad.data_ptr(), None, None, None)
+    scs = (C.c_void_p * 4)(keep[0].data_ptr(), None, None, None)
+    shs = (C.c_void_p * 4)(keep[1].data_ptr(), None, None, None)
+    relus = (C.c_int32 * 4)(1, 0, 0, 0)
+    y = torch.full_like(zad, 5.0)
+    st2 = torch.zeros(nparts * 2 * cs, device="cuda")
+    ffi.call("seg_add_act_stats_fwd" + sfx, xs, scs, shs, relus, 1, C.byref(cat), P(keep[2]), P(keep[3]), P(y), npix, cs, Cc, ACT["relu"], 0.0, P(st2), nparts, stream())
+    torch.cuda.synchronize()
+    yv = U.dev_values(y)
+    assert rel(yv[..., :Cc], s.detach()) < (2e-6 if f32 else 2e-3)
+    assert float(yv[..., Cc:].abs().max()) == 0.0 if cs > Cc else True
+    s2 = st2.reshape(nparts, 2, cs).sum(0).cpu()
+    assert rel(s2[0, :Cc], yv[..., :Cc].sum((0, 1, 2))) < 1e-5 and rel(s2[1, :Cc], (yv[..., :Cc] ** 2).sum((0, 1, 2))) < 1e-5
+    # ---- fan-out backward of BN2 (+ ReLU mask) with BN1's two sums, from the exact s (so that only the backward kernels are measured)
+    sd, dyd = U.to_dev_nhwc(rd(s.detach()), dt), U.to_dev_nhwc(dy, dt)
+    sv = U.dev_values(sd)[..., :Cc]
+    m2, v2 = sv.mean((0, 1, 2)), sv.var((0, 1, 2), unbiased=False)
+    is2 = torch.rsqrt(v2 + 1e-3)
+    xh2 = (sv - m2) * is2
+    c1, c2 = dy.mean((0, 1, 2)), (dy * xh2).mean((0, 1, 2))
+    want_g = (gamma2 * is2 * (dy - c1 - xh2 * c2)) * (sv > 0)
+    k2 = [pad(v) for v in (gamma2 * is2, m2, is2, c1, c2)]
+    k1 = [pad(mean1.detach()), pad(invstd1.detach())]
+    gbuf = torch.full_like(zad, 4.0)
+    gp = (C.c_void_p * 4)(gbuf.data_ptr(), None, None, None)
+    nb = 5
+    part = torch.full((nb * 2 * cs,), 9.0, device="cuda")
+    ffi.call("seg_bn_bwd_apply_fanout" + sfx, P(dyd), P(sd), gp, 2, 0, npix, cs, *[P(t) for t in k2], 1, C.byref(cat), P(k1[0]), P(k1[1]), P(part), nb, stream())
+    torch.cuda.synchronize()
+    gv = U.dev_values(gbuf)[..., :Cc]
+    assert rel(gv, want_g) < tol
+    xh1 = ((catv - mean1) * invstd1).detach()
+    ps = part.reshape(nb, 2, cs).sum(0).cpu()
+    assert rel(ps[0, :Cc], gv.sum((0, 1, 2))) < 1e-4 and rel(ps[1, :Cc], (gv * xh1).sum((0, 1, 2))) < 1e-4
+    # ---- BN1's backward onto the pieces
+    b1c1, b1c2 = gv.mean((0, 1, 2)), (gv * xh1).mean((0, 1, 2))
+    k3 = [pad(v) for v in ((gamma1 * invstd1).detach(), mean1.detach(), invstd1.detach(), b1c1, b1c2)]
+    ffi.call("seg_cat_bn_bwd_scatter" + sfx, P(gbuf), C.byref(cat), npix, cs, *[P(t) for t in k3], stream())
+    torch.cuda.synchronize()
+    want_cat = (gamma1 * invstd1).detach() * (gv - b1c1 - xh1 * b1c2)
+    off = 0
+    for t, c, gt in zip(pgrad, chans, prs):
+        got = U.dev_values(t)
+        assert rel(got[..., :c], want_cat[..., off:off + c]) < tol
+        if t.shape[3] > c:
+            assert float(got[..., c:].abs().max()) == 0.0          # the padding channels of a freshly written gradient are zero
+        off += c
+    # the whole chain against autograd (the masks of s agree: s was handed over exactly)
+    if f32:
+        assert rel(gv, a.grad) < 5e-5
+        off = 0
+        for t, c, gt in zip(pgrad, chans, prs):
+            assert rel(U.dev_values(t)[..., :c], gt.grad) < 1e-4
+            off += c
+    # accumulate form of the scatter
+    for k in range(cat.n):
+        cat.p[k].acc = 1
+    before = [U.dev_values(t).clone() for t in pgrad]
+    ffi.call("seg_cat_bn_bwd_scatter" + sfx, P(gbuf), C.byref(cat), npix, cs, *[P(t) for t in k3], stream())
+    torch.cuda.synchronize()
+    for t, bf in zip(pgrad, before):
+        assert rel(U.dev_values(t), 2 * bf) < (1e-6 if f32 else 2e-3)
 
 
 @pytest.mark.parametrize("pool", [(2, 2), (1, 2), (4, 4)])

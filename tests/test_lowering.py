@@ -77,22 +77,47 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     """BN(ReLU(a + b)) - the tail of a MultiResBlock and of every ResPath iteration (unet_variants.py:97-99, :118-120): the add
     kernel applies the ReLU, normalises a BatchNormalization input on the fly (BN(cat) is never written) and delivers the statistics
     of the BN that follows; that BN's backward writes the masked gradient to the add's inputs.  Against the unfused lowering: no
-    seg_add_act_fwd / seg_add_act_bwd, one seg_bn_stats and one seg_bn_act_apply fewer per fused BN / folded BN."""
+    seg_add_act_fwd / seg_add_act_bwd, one seg_bn_stats and one seg_bn_act_apply fewer per fused BN / folded BN.
+    Round 4 on top (each behind its own switch): the Conv_Blocks that feed only the add are normalised ON LOAD there (no
+    seg_bn_act_apply for them), cat[c3, c5, c7] is never materialised (no seg_copy_channels, its statistics from one gathering
+    launch, its backward = finalize + seg_cat_bn_bwd_scatter), and the add's gradient is written once."""
     def counts():
         m = B("MultiResUNet", 32, 32, 16, 2, alpha=1.0).build(2, dtype="f16")
         c = step(m, torch.rand(2, 32, 32, 3))
         tails = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.fused_add is not None)
         folded = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.folded_into is not None)
-        return c, tails, folded
-    c1, tails, folded = counts()
-    assert tails > 0 and folded > 0 and c1["seg_add_act_stats_fwd"] == tails and c1["seg_bn_bwd_apply_fanout"] == tails
+        lazy = sum(1 for o in m.ops if isinstance(o, M.ConvOp) and o.lazy)
+        virt = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.pieces is not None)
+        return c, tails, folded, lazy, virt, m
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT"):
+        monkeypatch.setattr(M, sw, False)
+    c1, tails, folded, lazy, virt, _m = counts()                                # the round-3 form
+    assert tails > 0 and folded > 0 and lazy == 0 and virt == 0
+    assert c1["seg_add_act_stats_fwd"] == tails and c1["seg_bn_bwd_apply_fanout"] == tails
     monkeypatch.setattr(M, "FUSE_BN_TAILS", False)
-    c0, t0, f0 = counts()
+    c0, t0, f0, _l, _v, _m = counts()
     assert t0 == 0 and f0 == 0 and c0["seg_add_act_stats_fwd"] == 0
     assert c0["seg_add_act_fwd"] - c1["seg_add_act_fwd"] == tails and c0["seg_add_act_bwd"] - c1["seg_add_act_bwd"] == tails
     assert c0["seg_bn_stats"] - c1["seg_bn_stats"] == tails                    # statistics from the add kernel
     assert c0["seg_bn_act_apply"] - c1["seg_bn_act_apply"] == folded           # BN(cat) applied inside the add
     assert c0["seg_bn_act_bwd_apply"] - c1["seg_bn_act_bwd_apply"] == tails    # replaced by the fan-out form
+    # ---- round 4
+    monkeypatch.setattr(M, "FUSE_BN_TAILS", True)
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT"):
+        monkeypatch.setattr(M, sw, True)
+    c2, tails2, folded2, lazy, virt, m = counts()
+    assert (tails2, folded2) == (tails, folded) and virt == folded            # every BN(cat) of this model is a virtual concatenation
+    assert lazy == 2 * (tails - folded) + folded                                # ResPath: shortcut + conv; MultiResBlock: the shortcut
+    assert c1["seg_bn_act_apply"] - c2["seg_bn_act_apply"] == lazy
+    assert c2["seg_copy_channels"] == 0 and c1["seg_copy_channels"] == 2 * 3 * folded      # three pieces, forward and backward
+    assert c2["seg_bn_stats"] == c1["seg_bn_stats"] - folded and c2["seg_add_act_stats_fwd"] == tails + folded
+    assert c2["seg_cat_bn_bwd_scatter"] == folded
+    assert c1["seg_bn_act_bwd_reduce"] - c2["seg_bn_act_bwd_reduce"] == folded  # BN(cat)'s sums ride on the fan-out launch
+    assert c1["seg_bn_act_bwd_apply"] - c2["seg_bn_act_bwd_apply"] == folded    # ... and its input gradient is the scatter
+    assert not any(isinstance(o, M.ConcatOp) and not o.virtual for o in m.ops)
+    # the add's gradient is written once: every second input reads the first one's buffer
+    shared = [o for o in m.ops if isinstance(o, M.ConvOp) and o.grad_src is not None]
+    assert len(shared) == tails - folded and all(o.lazy for o in shared)
 
 
 def test_accumulate_flags_follow_consumer_count():

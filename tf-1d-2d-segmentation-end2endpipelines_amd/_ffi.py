@@ -65,6 +65,15 @@ class TransposeDesc(C.Structure):
                 ("dst_coff", C.c_int32), ("tile0", C.c_int32), ("src16", C.c_int32)]
 
 
+class CatPiece(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dx", C.c_void_p), ("cs", C.c_int32), ("C", C.c_int32), ("coff", C.c_int32), ("acc", C.c_int32)]
+
+
+class CatDesc(C.Structure):
+    """seg_cat_desc: a virtual concatenation of up to four tensors (MultiResBlock's cat[c3, c5, c7])."""
+    _fields_ = [("n", C.c_int32), ("p", CatPiece * 4)]
+
+
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 _PROTOS = {
@@ -91,8 +100,9 @@ _PROTOS = {
     "seg_upsample_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_upsample_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_add_act_fwd": ([C.POINTER(vp), i32, vp, i64, i32, f32, vp], C.c_int),
-    "seg_add_act_stats_fwd": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, i64, i32, i32, f32, vp, i32, vp], C.c_int),
-    "seg_bn_bwd_apply_fanout": ([vp, vp, C.POINTER(vp), i32, i32, i64, i32, vp, vp, vp, vp, vp, i32, vp], C.c_int),
+    "seg_add_act_stats_fwd": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(CatDesc), vp, vp, vp, i64, i32, i32, i32, f32, vp, i32, vp], C.c_int),
+    "seg_bn_bwd_apply_fanout": ([vp, vp, C.POINTER(vp), i32, i32, i64, i32, vp, vp, vp, vp, vp, i32, C.POINTER(CatDesc), vp, vp, vp, i32, vp], C.c_int),
+    "seg_cat_bn_bwd_scatter": ([vp, C.POINTER(CatDesc), i64, i32, vp, vp, vp, vp, vp, vp], C.c_int),
     "seg_add_act_bwd": ([vp, vp, C.POINTER(vp), i32, i64, i32, f32, i32, vp], C.c_int),
     "seg_copy_channels": ([vp, i32, i32, vp, i32, i32, i32, i64, i32, vp], C.c_int),
     "seg_mul_bcast_fwd": ([vp, vp, vp, i64, i32, i32, vp], C.c_int),
@@ -127,7 +137,7 @@ _PROTOS = {
 # entry points that touch activation tensors exist twice: fp16 (throughput mode) and *_f32 (parity mode: split fp16 pairs, 4 B per element)
 DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
-        "seg_add_act_bwd", "seg_add_act_stats_fwd", "seg_bn_bwd_apply_fanout", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
+        "seg_add_act_bwd", "seg_add_act_stats_fwd", "seg_bn_bwd_apply_fanout", "seg_cat_bn_bwd_scatter", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
         "seg_head_fwd", "seg_head_bwd", "seg_head_act_fwd", "seg_head_act_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")
 for _n in DUAL:
     _PROTOS[_n + "_f32"] = _PROTOS[_n]

@@ -684,121 +684,301 @@ __global__ __launch_bounds__(TPB) void add_act_bwd_kernel(const T* dy, const T* 
   }
 }
 
-// y = act(sum_k (x_k * scale_k + shift_k)) with the per-channel sums of y and y^2 as per-block partial rows - the tail of a
-// MultiResBlock / ResPath, BN(ReLU(a + b)) (unet_variants.py:97-99, :118-120): the add, the ReLU and the statistics of the
-// BatchNormalization that follows are ONE pass, and an input may itself be a BatchNormalization whose normalisation is applied on
-// the fly (scale_k / shift_k != NULL: MultiResBlock's BN over cat[c3, c5, c7] is never written out).  Layout as bn_stats_kernel.
-struct Aff4 { const float* sc[4]; const float* sh[4]; };
+// ---- the tails of MultiResBlock / ResPath: BatchNormalization(ReLU(a + b)) (unet_variants.py:97-99, :118-120) ---------------------
+// forward   y = act(sum_k pre_k(x_k) [+ cat_scale * cat + cat_shift]) with the per-channel sums of y and y^2 as per-block partial
+//           rows (the statistics of the BatchNormalization that follows): the add, the ReLU and those statistics are ONE pass.
+//           pre_k = identity, or relu?(x * scale_k + shift_k): an input that is the output of a Conv_Block (conv -> BN -> ReLU)
+//           with no other consumer is normalised ON LOAD from the conv's raw output and never written (no bn_act_apply pass).
+//           cat = the VIRTUAL concatenation of up to four tensors whose channel counts are not multiples of 8 (MultiResBlock's
+//           cat[c3, c5, c7] = 5 + 10 + 16 channels at W = 32, unet_variants.py:95), normalised on the fly by the BatchNormalization
+//           over it: the pieces' 8-channel groups are fetched with whole-group loads (coalesced) and laid into an LDS tile
+//           [pixel][cat channel] element by element - the concatenation exists only there.
+// backward  dx = [x > 0] * sc * (g - c1 - xhat c2), x = the BatchNormalization's input = the ReLU's output, written ONCE per distinct
+//           destination (the add fans the same gradient out to its inputs); with a cat input the launch also delivers the two sums of
+//           the BatchNormalization over the cat (sum dx, sum dx * xhat_cat) as partial rows, and seg_cat_bn_bwd_scatter turns
+//           (dx, cat) into the gradients of the pieces (whole groups, padding channels zero) through the same LDS tile.
+struct Aff4 { const float* sc[4]; const float* sh[4]; int relu[4]; };
+struct CatDev {
+  int n, ngroups, ctotal;
+  const void* x[4];
+  void* dx[4];
+  int cs[4], C[4], coff[4], g0[4], acc[4];
+};
+
+// Lay the pieces' values for the pixels [p0, p0 + TP) into sm[TP][cs] at their channel positions of the concatenation (positions
+// >= ctotal are never written: the caller zero-fills the tile once).  Four whole-group loads per thread in flight.
 template <typename T>
-__global__ __launch_bounds__(TPB) void add_act_stats_kernel(Ptr4<T> xs, Aff4 aff, int n, T* y, int64_t npix, int cs, int act, float alpha,
-                                                            float* stats, int nparts, ColLayout L) {
-  __shared__ float sm[TPB * 8];
-  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
-  const int part = blockIdx.x;
-  for (int grp = 0; grp < L.ngrp; ++grp) {
-    const int ch = grp * L.CHP + col;
-    float acc[2][8];
+__device__ __forceinline__ void cat_gather(const CatDev* cd, int64_t p0, int TP, int64_t npix, float* sm, int cs) {
+  const int ng = cd->ngroups, total = TP * ng;
+  for (int i0 = threadIdx.x; i0 < total; i0 += TPB * 4) {
+    float f[4][8];
+    int dst[4], lim[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
-    if (ch < L.CH) {
-      float sc[4][8], sh[4][8];         // (k loops fully unrolled with a guard: a run-time index would put these in scratch)
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TPB;
+      lim[u] = 0;
+      if (i < total) {
+        const int r = i / ng, g = i - r * ng;
+        int k = 0;
+        while (k + 1 < cd->n && g >= cd->g0[k + 1]) ++k;
+        const int gg = g - cd->g0[k];
+        const int64_t pix = p0 + r;
+        if (pix < npix) {
+          load8((const T*)cd->x[k] + pix * cd->cs[k] + gg * 8, f[u]);
+        } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          sc[k][t] = (k < n && aff.sc[k] != nullptr) ? aff.sc[k][ch * 8 + t] : 1.f;
-          sh[k][t] = (k < n && aff.sh[k] != nullptr) ? aff.sh[k][ch * 8 + t] : 0.f;
+          for (int t = 0; t < 8; ++t) f[u][t] = 0.f;
         }
-      for (int64_t pix = (int64_t)part * L.RP + rowi; pix < npix; pix += (int64_t)L.RP * nparts) {   // interleaved rows
-        float o[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k < n) {
-            float f[8];
-            load8(xs.p[k] + pix * cs + ch * 8, f);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] += f[t] * sc[k][t] + sh[k][t];
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = seg_act(o[t], act, alpha);
-        store8(y + pix * cs + ch * 8, o);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float v = stored<T>(o[t]);              // the statistics of what the BatchNormalization will read
-          acc[0][t] += v;
-          acc[1][t] += v * v;
-        }
+        dst[u] = r * cs + cd->coff[k] + gg * 8;
+        lim[u] = min(8, cd->C[k] - gg * 8);
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < lim[u]) sm[dst[u] + t] = f[u][t];
+  }
+}
+
+template <typename T, bool GATHER, int NIN>
+__global__ __launch_bounds__(TPB) void tail_fwd_kernel(Ptr4<T> xs, Aff4 aff, int n, CatDev cdv, const float* cat_sc, const float* cat_sh, T* y,
+                                                       int64_t npix, int cs, int c_valid, int act, float alpha, float* stats, ColLayout L) {
+  __shared__ float sm[GATHER ? TPB * 8 * UNR : TPB * 8];
+  __shared__ CatDev scd;
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int TP = L.RP * UNR;
+  const int ch = col;                       // (the host launches this kernel for cs <= 8 * TPB only: one column group)
+  if (GATHER) {
+    if (threadIdx.x == 0) scd = cdv;
+    for (int i = threadIdx.x; i < TP * cs; i += TPB) sm[i] = 0.f;
+  }
+  float acc[2][8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
+  float sc[NIN][8], sh[NIN][8], csc[8], csh[8];       // (k loops fully unrolled with a guard: a run-time index would put these in scratch)
+#pragma unroll
+  for (int k = 0; k < NIN; ++k)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      sc[k][t] = (ch < L.CH && k < n && aff.sc[k] != nullptr) ? aff.sc[k][ch * 8 + t] : 1.f;
+      sh[k][t] = (ch < L.CH && k < n && aff.sh[k] != nullptr) ? aff.sh[k][ch * 8 + t] : 0.f;
+    }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    csc[t] = (GATHER && ch < L.CH && cat_sc != nullptr) ? cat_sc[ch * 8 + t] : 1.f;
+    csh[t] = (GATHER && ch < L.CH && cat_sh != nullptr) ? cat_sh[ch * 8 + t] : 0.f;
+  }
+  for (int64_t p0 = (int64_t)blockIdx.x * TP; p0 < npix; p0 += (int64_t)TP * gridDim.x) {     // interleaved tiles of RP * UNR pixels
+    if (GATHER) {
+      __syncthreads();
+      cat_gather<T>(&scd, p0, TP, npix, sm, cs);
+      __syncthreads();
+    }
+    if (ch >= L.CH) continue;
+    float f[NIN][UNR][8];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k)
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
+        if (k < n && pix < npix) load8(xs.p[k] + pix * cs + ch * 8, f[k][u]);
+      }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
+      if (pix >= npix) continue;
+      float o[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] = GATHER ? sm[(rowi + u * L.RP) * cs + ch * 8 + t] * csc[t] + csh[t] : 0.f;
+#pragma unroll
+      for (int k = 0; k < NIN; ++k) {
+        if (k >= n) continue;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          float v = f[k][u][t] * sc[k][t] + sh[k][t];
+          if (aff.relu[k]) v = fmaxf(v, 0.f);
+          o[t] += v;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        o[t] = seg_act(o[t], act, alpha);
+        if (ch * 8 + t >= c_valid) o[t] = 0.f;
+      }
+      if (y != nullptr) store8(y + pix * cs + ch * 8, o);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float v = stored<T>(o[t]);              // the statistics of what the BatchNormalization will read
+        acc[0][t] += v;
+        acc[1][t] += v * v;
+      }
+    }
+  }
+  __syncthreads();
+  block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
+  if (rowi == 0 && ch < L.CH) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      stats[((size_t)blockIdx.x * 2 + 0) * cs + ch * 8 + t] = acc[0][t];
+      stats[((size_t)blockIdx.x * 2 + 1) * cs + ch * 8 + t] = acc[1][t];
+    }
+  }
+}
+
+template <typename T, bool GATHER>
+__global__ __launch_bounds__(TPB) void tail_bwd_fanout_kernel(const T* dy, const T* x, MPtr4<T> dxs, int n, int accmask, int64_t npix, int cs,
+                                                              const float* scale, const float* mean, const float* invstd, const float* c1,
+                                                              const float* c2, int relu_mask, CatDev cdv, const float* cat_mean,
+                                                              const float* cat_invstd, float* cat_partial, ColLayout L) {
+  __shared__ float sm[GATHER ? TPB * 8 * UNR : 1];
+  __shared__ CatDev scd;
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int TP = L.RP * UNR;
+  const int ch = col;
+  if (GATHER) {
+    if (threadIdx.x == 0) scd = cdv;
+    for (int i = threadIdx.x; i < TP * cs; i += TPB) sm[i] = 0.f;
+  }
+  float sc[8], ka[8], kb[8], cmu[8], cis[8], acc[2][8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int c = ch * 8 + t;
+    const bool ok = ch < L.CH;
+    sc[t] = ok ? scale[c] : 0.f;
+    const float k = ok ? invstd[c] * c2[c] : 0.f;
+    ka[t] = -sc[t] * k;
+    kb[t] = ok ? sc[t] * (mean[c] * k - c1[c]) : 0.f;
+    cmu[t] = (GATHER && ok) ? cat_mean[c] : 0.f;
+    cis[t] = (GATHER && ok) ? cat_invstd[c] : 0.f;
+    acc[0][t] = 0.f;
+    acc[1][t] = 0.f;
+  }
+  for (int64_t p0 = (int64_t)blockIdx.x * TP; p0 < npix; p0 += (int64_t)TP * gridDim.x) {
+    if (GATHER) {
+      __syncthreads();
+      cat_gather<T>(&scd, p0, TP, npix, sm, cs);
+      __syncthreads();
+    }
+    if (ch >= L.CH) continue;
+    float g[UNR][8], xv[UNR][8];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
+      if (pix < npix) {
+        load8(dy + pix * cs + ch * 8, g[u]);
+        load8(x + pix * cs + ch * 8, xv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
+      if (pix >= npix) continue;
+      float o[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float v = g[u][t] * sc[t] + xv[u][t] * ka[t] + kb[t];
+        o[t] = (relu_mask && !(xv[u][t] > 0.f)) ? 0.f : v;
+      }
+      if (GATHER) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float gg = stored<T>(o[t]);           // the sums of what seg_cat_bn_bwd_scatter will read back
+          acc[0][t] += gg;
+          acc[1][t] += gg * (sm[(rowi + u * L.RP) * cs + ch * 8 + t] - cmu[t]) * cis[t];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k >= n || dxs.p[k] == nullptr) continue;
+        float w[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w[t] = o[t];
+        if (accmask & (1 << k)) {
+          float old[8];
+          load8(dxs.p[k] + pix * cs + ch * 8, old);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) w[t] += old[t];
+        }
+        store8(dxs.p[k] + pix * cs + ch * 8, w);
+      }
+    }
+  }
+  if (GATHER) {
+    __syncthreads();
     block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
     if (rowi == 0 && ch < L.CH) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        stats[((size_t)part * 2 + 0) * cs + ch * 8 + t] = acc[0][t];
-        stats[((size_t)part * 2 + 1) * cs + ch * 8 + t] = acc[1][t];
+        cat_partial[((size_t)blockIdx.x * 2 + 0) * cs + ch * 8 + t] = acc[0][t];
+        cat_partial[((size_t)blockIdx.x * 2 + 1) * cs + ch * 8 + t] = acc[1][t];
       }
     }
   }
 }
 
-// backward of BN(ReLU(a + b + ..)): dx = [x > 0] * sc * (g - c1 - xhat c2) written to EVERY input of the add (the add fans the same
-// gradient out), x = the BatchNormalization's input = the ReLU's output.  Replaces bn_act_bwd_apply + add_act_bwd.
+// d cat = sc (g - c1 - xhat c2) of the BatchNormalization over the virtual concatenation, written to the pieces' gradients
 template <typename T>
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_fanout_kernel(const T* dy, const T* x, MPtr4<T> dxs, int n, int accmask, int64_t npix, int cs,
-                                                                  const float* scale, const float* mean, const float* invstd, const float* c1,
-                                                                  const float* c2, int relu_mask, ColLayout L) {
+__global__ __launch_bounds__(TPB) void cat_bn_bwd_scatter_kernel(const T* g, CatDev cdv, int64_t npix, int cs, const float* scale, const float* mean,
+                                                                 const float* invstd, const float* c1, const float* c2, ColLayout L) {
+  __shared__ float sm[TPB * 8 * UNR];
+  __shared__ CatDev scd;
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
-  const int64_t chunk = (int64_t)L.RP * UNR;
-  for (int grp = 0; grp < L.ngrp; ++grp) {
-    const int ch = grp * L.CHP + col;
-    if (ch >= L.CH) continue;
-    float sc[8], ka[8], kb[8];
+  const int TP = L.RP * UNR;
+  const int ch = col;
+  if (threadIdx.x == 0) scd = cdv;
+  for (int i = threadIdx.x; i < TP * cs; i += TPB) sm[i] = 0.f;
+  float sc[8], ka[8], kb[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int c = ch * 8 + t;
-      sc[t] = scale[c];
-      const float k = invstd[c] * c2[c];
-      ka[t] = -sc[t] * k;
-      kb[t] = sc[t] * (mean[c] * k - c1[c]);
+  for (int t = 0; t < 8; ++t) {
+    const int c = ch * 8 + t;
+    const bool ok = ch < L.CH && c < cdv.ctotal;
+    sc[t] = ok ? scale[c] : 0.f;
+    const float k = ok ? invstd[c] * c2[c] : 0.f;
+    ka[t] = -sc[t] * k;
+    kb[t] = ok ? sc[t] * (mean[c] * k - c1[c]) : 0.f;
+  }
+  for (int64_t p0 = (int64_t)blockIdx.x * TP; p0 < npix; p0 += (int64_t)TP * gridDim.x) {
+    __syncthreads();
+    cat_gather<T>(&scd, p0, TP, npix, sm, cs);
+    __syncthreads();
+    if (ch < L.CH) {
+      float gv[UNR][8];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
+        if (pix < npix) load8(g + pix * cs + ch * 8, gv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
+        float* cell = sm + (rowi + u * L.RP) * cs + ch * 8;        // (this thread's own cells: read the cat value, leave d cat)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cell[t] = pix < npix ? gv[u][t] * sc[t] + cell[t] * ka[t] + kb[t] : 0.f;
+      }
     }
-    for (int64_t pb = blockIdx.x * chunk + rowi; pb < npix; pb += chunk * gridDim.x) {
-      float g[UNR][8], xv[UNR][8];
+    __syncthreads();
+    const int ng = scd.ngroups, total = TP * ng;
+    for (int i = threadIdx.x; i < total; i += TPB) {
+      const int r = i / ng, gi = i - r * ng;
+      int k = 0;
+      while (k + 1 < scd.n && gi >= scd.g0[k + 1]) ++k;
+      const int gg = gi - scd.g0[k];
+      const int64_t pix = p0 + r;
+      if (pix >= npix || scd.dx[k] == nullptr) continue;
+      const int lim = scd.C[k] - gg * 8;
+      const float* src = sm + r * cs + scd.coff[k] + gg * 8;
+      float o[8];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int64_t pix = pb + (int64_t)u * L.RP;
-        if (pix < npix) {
-          load8(dy + pix * cs + ch * 8, g[u]);
-          load8(x + pix * cs + ch * 8, xv[u]);
-        }
+      for (int t = 0; t < 8; ++t) o[t] = t < lim ? src[t] : 0.f;
+      T* dst = (T*)scd.dx[k] + pix * scd.cs[k] + gg * 8;
+      if (scd.acc[k]) {
+        float old[8];
+        load8(dst, old);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] += old[t];
       }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int64_t pix = pb + (int64_t)u * L.RP;
-        if (pix >= npix) continue;
-        float o[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float v = g[u][t] * sc[t] + xv[u][t] * ka[t] + kb[t];
-          o[t] = (relu_mask && !(xv[u][t] > 0.f)) ? 0.f : v;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k >= n || dxs.p[k] == nullptr) continue;
-          float w[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) w[t] = o[t];
-          if (accmask & (1 << k)) {
-            float old[8];
-            load8(dxs.p[k] + pix * cs + ch * 8, old);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) w[t] += old[t];
-          }
-          store8(dxs.p[k] + pix * cs + ch * 8, w);
-        }
-      }
+      store8(dst, o);
     }
   }
 }
@@ -1832,43 +2012,98 @@ static int seg_add_act_bwd_impl(const void* dy, const void* y, void* const* dxs,
 extern "C" int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<half_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
 extern "C" int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha, int32_t accumulate_mask, seg_stream_t stream) { return seg_add_act_bwd_impl<split_t>(dy, y, dxs, n, nelem, act, alpha, accumulate_mask, stream); }
 
+static int cat_to_dev(const seg_cat_desc* cat, int32_t cs, bool backward, CatDev* cd) {
+  cd->n = 0; cd->ngroups = 0; cd->ctotal = 0;
+  for (int k = 0; k < 4; ++k) { cd->x[k] = nullptr; cd->dx[k] = nullptr; cd->cs[k] = cd->C[k] = cd->coff[k] = cd->g0[k] = cd->acc[k] = 0; }
+  if (cat == nullptr) return SEG_OK;
+  SEG_CHECK_ARG(cat->n >= 1 && cat->n <= 4, "virtual concatenation: 1 .. 4 pieces (got %d)", cat->n);
+  cd->n = cat->n;
+  for (int k = 0; k < cat->n; ++k) {
+    const seg_cat_piece& q = cat->p[k];
+    SEG_CHECK_ARG(q.x != nullptr && q.C > 0 && q.cs >= q.C && (q.cs & 7) == 0 && q.coff == cd->ctotal,
+                  "virtual concatenation: piece %d (C=%d cs=%d coff=%d, expected offset %d)", k, q.C, q.cs, q.coff, cd->ctotal);
+    cd->x[k] = q.x; cd->dx[k] = backward ? q.dx : nullptr; cd->cs[k] = q.cs; cd->C[k] = q.C; cd->coff[k] = q.coff; cd->acc[k] = q.acc;
+    cd->g0[k] = cd->ngroups;
+    cd->ngroups += (q.C + 7) / 8;
+    cd->ctotal += q.C;
+  }
+  SEG_CHECK_ARG(cd->ctotal <= cs && cs <= 8 * TPB, "virtual concatenation: %d channels into a row of %d (row limit %d)", cd->ctotal, cs, 8 * TPB);
+  return SEG_OK;
+}
+
 template <typename T>
-static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y,
-                                      int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) {
-  SEG_CHECK_ARG(xs && y && stats && n >= 1 && n <= 4 && npix > 0 && cs > 0 && (cs & 7) == 0 && nparts > 0, "seg_add_act_stats_fwd: bad arguments (n=%d cs=%d)", n, cs);
+static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n,
+                                      const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,
+                                      int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) {
+  SEG_CHECK_ARG(stats && n >= 0 && n <= 4 && (n > 0 || cat != nullptr) && (n == 0 || xs != nullptr) && npix > 0 && cs > 0 && (cs & 7) == 0 &&
+                cs <= 8 * TPB && nparts > 0 && c_valid > 0 && c_valid <= cs && (cat_scale == nullptr) == (cat_shift == nullptr),
+                "seg_add_act_stats_fwd: bad arguments (n=%d cs=%d)", n, cs);
   Ptr4<T> p;
   Aff4 a;
   for (int k = 0; k < 4; ++k) {
     p.p[k] = k < n ? (const T*)xs[k] : nullptr;
     a.sc[k] = (k < n && scales != nullptr) ? scales[k] : nullptr;
     a.sh[k] = (k < n && shifts != nullptr) ? shifts[k] : nullptr;
+    a.relu[k] = (k < n && relus != nullptr) ? relus[k] : 0;
     SEG_CHECK_ARG(k >= n || (p.p[k] != nullptr && (a.sc[k] == nullptr) == (a.sh[k] == nullptr)), "seg_add_act_stats_fwd: input %d", k);
   }
-  hipLaunchKernelGGL((add_act_stats_kernel<T>), dim3(nparts), dim3(TPB), 0, ST(stream), p, a, n, (T*)y, npix, cs, act, alpha, stats, nparts, col_layout(cs));
+  CatDev cd;
+  if (int rc = cat_to_dev(cat, cs, false, &cd)) return rc;
+  const ColLayout L = col_layout(cs);
+#define LAUNCH_TAIL_FWD(G, NIN)                                                                                                          \
+  hipLaunchKernelGGL((tail_fwd_kernel<T, G, NIN>), dim3(nparts), dim3(TPB), 0, ST(stream), p, a, n, cd, cat_scale, cat_shift, (T*)y, npix, cs, \
+                     c_valid, act, alpha, stats, L)
+  if (cat != nullptr) { if (n <= 2) LAUNCH_TAIL_FWD(true, 2); else LAUNCH_TAIL_FWD(true, 4); }
+  else { if (n <= 2) LAUNCH_TAIL_FWD(false, 2); else LAUNCH_TAIL_FWD(false, 4); }
+#undef LAUNCH_TAIL_FWD
   SEG_CHECK_LAUNCH("seg_add_act_stats_fwd");
   return SEG_OK;
 }
-extern "C" int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y, int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<half_t>(xs, scales, shifts, n, y, npix, cs, act, alpha, stats, nparts, stream); }
-extern "C" int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, int32_t n, void* y, int64_t npix, int32_t cs, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<split_t>(xs, scales, shifts, n, y, npix, cs, act, alpha, stats, nparts, stream); }
+extern "C" int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<half_t>(xs, scales, shifts, relus, n, cat, cat_scale, cat_shift, y, npix, cs, c_valid, act, alpha, stats, nparts, stream); }
+extern "C" int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<split_t>(xs, scales, shifts, relus, n, cat, cat_scale, cat_shift, y, npix, cs, c_valid, act, alpha, stats, nparts, stream); }
 
 template <typename T>
 static int seg_bn_bwd_apply_fanout_impl(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs,
                                         const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
-                                        int32_t relu_mask, seg_stream_t stream) {
-  SEG_CHECK_ARG(dy && x && dxs && n >= 1 && n <= 4 && npix > 0 && cs > 0 && (cs & 7) == 0 && scale && mean && invstd && c1 && c2,
-                "seg_bn_bwd_apply_fanout: bad arguments");
+                                        int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
+                                        float* cat_partial, int32_t nparts, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && x && dxs && n >= 1 && n <= 4 && npix > 0 && cs > 0 && (cs & 7) == 0 && cs <= 8 * TPB && scale && mean && invstd && c1 && c2 &&
+                (cat == nullptr || (cat_mean && cat_invstd && cat_partial && nparts > 0)), "seg_bn_bwd_apply_fanout: bad arguments");
   MPtr4<T> p;
   for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (T*)dxs[k] : nullptr;
+  CatDev cd;
+  if (int rc = cat_to_dev(cat, cs, false, &cd)) return rc;
   const ColLayout L = col_layout(cs);
   int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL((bn_bwd_apply_fanout_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n, accumulate_mask,
-                     npix, cs, scale, mean, invstd, c1, c2, relu_mask, L);
+  if (cat != nullptr) {      // one partial row per block: the grid IS the row count the finalize launch is told
+    hipLaunchKernelGGL((tail_bwd_fanout_kernel<T, true>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n, accumulate_mask,
+                       npix, cs, scale, mean, invstd, c1, c2, relu_mask, cd, cat_mean, cat_invstd, cat_partial, L);
+  } else {
+    hipLaunchKernelGGL((tail_bwd_fanout_kernel<T, false>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n, accumulate_mask,
+                       npix, cs, scale, mean, invstd, c1, c2, relu_mask, cd, nullptr, nullptr, nullptr, L);
+  }
   SEG_CHECK_LAUNCH("seg_bn_bwd_apply_fanout");
   return SEG_OK;
 }
-extern "C" int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<half_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, stream); }
-extern "C" int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<split_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, stream); }
+extern "C" int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd, float* cat_partial, int32_t nparts, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<half_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cat, cat_mean, cat_invstd, cat_partial, nparts, stream); }
+extern "C" int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd, float* cat_partial, int32_t nparts, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<split_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cat, cat_mean, cat_invstd, cat_partial, nparts, stream); }
+
+template <typename T>
+static int seg_cat_bn_bwd_scatter_impl(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,
+                                       const float* invstd, const float* c1, const float* c2, seg_stream_t stream) {
+  SEG_CHECK_ARG(g && cat && npix > 0 && cs > 0 && (cs & 7) == 0 && scale && mean && invstd && c1 && c2, "seg_cat_bn_bwd_scatter: bad arguments");
+  CatDev cd;
+  if (int rc = cat_to_dev(cat, cs, true, &cd)) return rc;
+  const ColLayout L = col_layout(cs);
+  int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL((cat_bn_bwd_scatter_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)g, cd, npix, cs, scale, mean, invstd, c1, c2, L);
+  SEG_CHECK_LAUNCH("seg_cat_bn_bwd_scatter");
+  return SEG_OK;
+}
+extern "C" int seg_cat_bn_bwd_scatter(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, seg_stream_t stream) { return seg_cat_bn_bwd_scatter_impl<half_t>(g, cat, npix, cs, scale, mean, invstd, c1, c2, stream); }
+extern "C" int seg_cat_bn_bwd_scatter_f32(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, seg_stream_t stream) { return seg_cat_bn_bwd_scatter_impl<split_t>(g, cat, npix, cs, scale, mean, invstd, c1, c2, stream); }
 
 template <typename T>
 static int seg_mul_bcast_fwd_impl(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs, seg_stream_t stream) {

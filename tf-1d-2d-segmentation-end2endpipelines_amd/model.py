@@ -326,6 +326,10 @@ def fwd_halo_patch(g: Geom) -> int:
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 FUSE_BN_TAILS = os.environ.get("SEG_FUSE_BN_TAILS", "1") != "0"             # BN(ReLU(a + b)) tails of MultiResBlock / ResPath as fused passes
 FUSE_INFERENCE_BN = os.environ.get("SEG_FUSE_INFERENCE_BN", "1") != "0"     # predict: conv -> BN(moving statistics) -> activation as ONE launch
+# the fused tails, round 4 (each with its own switch for bisecting / same-box A/Bs):
+TAIL_LAZY_INPUTS = os.environ.get("SEG_TAIL_LAZY_INPUTS", "1") != "0"       # a Conv_Block feeding only the add is normalised on load there (no bn_act_apply pass)
+TAIL_SHARED_GRAD = os.environ.get("SEG_TAIL_SHARED_GRAD", "1") != "0"       # the add's gradient is written once; the Conv_Blocks behind it read the one buffer
+TAIL_VIRTUAL_CAT = os.environ.get("SEG_TAIL_VIRTUAL_CAT", "1") != "0"       # MultiResBlock's cat[c3, c5, c7] exists only in the tail kernels' LDS tiles
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
@@ -692,6 +696,8 @@ class ConvOp(Op):
         self.wt = torch.zeros(Kpad * self.T * self.rows_pad, dtype=DevTensor.dtype, device=dev) if any(self.need_dgrad) else None
         self.fwd_args = None
         self.gathered: Dict[int, "GatherDgrad"] = {}      # segment index -> gathered data gradient that covers it
+        self.lazy = False            # training: `out` is never written - its only consumer (a fused add) normalises z on load
+        self.grad_src: Optional[DevTensor] = None      # backward: dOut is read from this tensor's gradient (shared with a sibling)
         self.gather_launch: List["GatherDgrad"] = []      # gathered data gradients launched at the end of this op's backward
         self.dz_ptr = None
 
@@ -802,6 +808,8 @@ class ConvOp(Op):
                  st.ptr(bn + "/beta"), self.eps, self.momentum, st.ptr(bn + "/moving_mean"), st.ptr(bn + "/moving_variance"),
                  1 if self.m.graph.ndim == 2 else 0, 1 if training else 0, _p(self.mean), _p(self.invstd), _p(self.scale),
                  _p(self.shift), s)
+            if self.lazy and training:
+                return                   # (the fused add that consumes this block applies scale / shift / ReLU on load)
             ph, pw = self.pool_size if self.pooled is not None else (1, 1)
             call("seg_bn_act_apply", _p(self.z.buf), self.z.cs, 0, _p(self.out.buf), self.out.cs, 0, self.z.N, self.z.H,
                  self.z.W, self.n_rows, self.cout, _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha),
@@ -891,7 +899,7 @@ class ConvOp(Op):
         if self.has_bn:
             bn = self.bn_name
             dA = self.out.ensure_grad()
-            src = _p(dA)
+            src = _p(self.grad_src.grad if self.grad_src is not None else dA)      # (a sibling's buffer: written once for both, read-only here)
             call("seg_bn_act_bwd_reduce", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
                  _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
                  _p(self.bpart), BN_PARTS_BWD, s)
@@ -1130,6 +1138,16 @@ class ReshapeOp(Op):
         self._copy(not self.to_flat, self.out.grad, self.x.grad, self.acc)
 
 
+def _tail_parts(npix: int, cs: int) -> int:
+    """Partial rows (= blocks) of the tail kernels that walk tiles of RP * 4 pixels (csrc/elementwise.hip col_layout): at most
+    BN_PARTS_BWD, never more than there are tiles."""
+    chp = 1
+    while chp < cs // 8:
+        chp <<= 1
+    tile = (256 // min(chp, 256)) * 4
+    return max(1, min(BN_PARTS_BWD, _cdiv(npix, tile)))
+
+
 class BNOp(Op):
     """Stand-alone BatchNormalization (+ activation) on an existing tensor (MultiResBlock / ResPath tails)."""
 
@@ -1147,14 +1165,34 @@ class BNOp(Op):
             torch.zeros(self.C, dtype=torch.float32, device=dev) for _ in range(6))
         # fused tails (FUSE_BN_TAILS, see SegModel._fuse_bn_tail): `fused_add` - this BN follows ReLU(a + b): the add kernel delivers
         # the statistics and this op's backward writes the masked gradient to the add's inputs; `folded_into` - this BN feeds such an
-        # add and has no other consumer: its normalisation is applied inside the add kernel, `out` is never written
+        # add and has no other consumer: its normalisation is applied inside the add kernel, `out` is never written;
+        # `pieces` - (folded only) the input is a concatenation that is never materialised: the tail kernels gather it (seg_cat_desc)
         self.fused_add: Optional["AddOp"] = None
         self.folded_into: Optional["AddOp"] = None
+        self.pieces: Optional[List[Tuple[DevTensor, int]]] = None
+        self.cat: Optional[_ffi.CatDesc] = None
+        self.cat_parts = _tail_parts(x.npix, self.C)
+
+    def make_virtual(self, pieces: List[Tuple[DevTensor, int]]):
+        """The input becomes a virtual concatenation of `pieces` (never written: the tensor's buffer is released)."""
+        self.pieces = pieces
+        d = _ffi.CatDesc()
+        d.n, off = len(pieces), 0
+        for k, (t, c) in enumerate(pieces):
+            d.p[k].x, d.p[k].dx, d.p[k].cs, d.p[k].C, d.p[k].coff, d.p[k].acc = t.buf.data_ptr(), None, t.cs, c, off, 0
+            off += c
+        self.cat = d
+        self.x.materialised = False
+        self.x.buf = torch.empty((0,), dtype=self.x.buf.dtype, device=self.x.buf.device)      # (nothing reads or writes the concatenated tensor any more)
 
     def forward(self, training):
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
         if training and self.fused_add is None:
-            call("seg_bn_stats", _p(x.buf), x.npix, x.cs, 0, self.C, _p(self.stats), self.nparts, self.C, 0, s)
+            if self.pieces is not None:       # statistics of the virtual concatenation: one gathering pass over the pieces
+                call("seg_add_act_stats_fwd", None, None, None, None, 0, C.byref(self.cat), None, None, None, x.npix, self.C, self.cl,
+                     0, 0.0, _p(self.stats), self.nparts, s)
+            else:
+                call("seg_bn_stats", _p(x.buf), x.npix, x.cs, 0, self.C, _p(self.stats), self.nparts, self.C, 0, s)
         call("seg_bn_finalize", _p(self.stats), self.nparts, self.C, x.npix, st.ptr(bn + "/gamma"), st.ptr(bn + "/beta"),
              self.eps, self.momentum, st.ptr(bn + "/moving_mean"), st.ptr(bn + "/moving_variance"),
              1 if self.m.graph.ndim == 2 else 0, 1 if training else 0, _p(self.mean), _p(self.invstd), _p(self.scale),
@@ -1171,21 +1209,43 @@ class BNOp(Op):
             if self.live:
                 self.x.gw = True              # the add's output does receive a gradient - handed straight on to the add's inputs
             return
+        if self.pieces is not None:
+            self.acc = None
+            if self.live:
+                for k, (t, _c) in enumerate(self.pieces):
+                    if t.needs_grad:
+                        self.cat.p[k].acc = t.claim()
+                        self.cat.p[k].dx = t.grad.data_ptr()
+            return
         self.acc = self.x.claim() if (self.live and self.x.needs_grad) else None
 
     def backward(self):
         if not self.live:
             return
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
+        gs_inv = C.c_void_p(self.m.gs.data_ptr() + 4)
+        if self.pieces is not None:
+            # virtual concatenation (folded into a fused add): the fan-out launch of the BatchNormalization behind the add left this
+            # BN's two sums in `bpart` and the add's gradient g in `tail_grad`; d cat = sc (g - c1 - xhat c2) goes to the pieces
+            add = self.folded_into
+            call("seg_bn_bwd_finalize", _p(self.bpart), self.cat_parts, self.C, x.npix, st.ptr(bn + "/gamma", "G"),
+                 st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
+            call("seg_cat_bn_bwd_scatter", _p(add.tail_grad.grad), C.byref(self.cat), x.npix, self.C, _p(self.scale), _p(self.mean),
+                 _p(self.invstd), _p(self.c1), _p(self.c2), s)
+            return
         dA = self.out.grad
         call("seg_bn_act_bwd_reduce", _p(dA), self.out.cs, 0, _p(x.buf), x.cs, 0, x.npix, self.C, _p(self.scale), _p(self.shift),
              _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha), _p(self.bpart), BN_PARTS_BWD, s)
         call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.C, x.npix, st.ptr(bn + "/gamma", "G"),
-             st.ptr(bn + "/beta", "G"), 1.0, C.c_void_p(self.m.gs.data_ptr() + 4), _p(self.c1), _p(self.c2), s)
+             st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
         if self.fused_add is not None:
             a = self.fused_add                # dx = [x > 0] sc (g - c1 - xhat c2) to every input of the add: no add backward pass
+            vb = a.virtual_bn                 # ... and, with a virtual concatenation among the inputs, the sums of ITS BatchNormalization
             call("seg_bn_bwd_apply_fanout", _p(dA), _p(x.buf), a.gptrs, len(a.xs), a.mask, x.npix, self.C, _p(self.scale), _p(self.mean),
-                 _p(self.invstd), _p(self.c1), _p(self.c2), 1 if ACT[a.act] == ACT["relu"] else 0, s)
+                 _p(self.invstd), _p(self.c1), _p(self.c2), 1 if ACT[a.act] == ACT["relu"] else 0,
+                 C.byref(vb.cat) if vb is not None else None, _p(vb.mean) if vb is not None else None,
+                 _p(vb.invstd) if vb is not None else None, _p(vb.bpart) if vb is not None else None,
+                 vb.cat_parts if vb is not None else 0, s)
             return
         if self.acc is None:          # the input needs no gradient (a BN placed on the network input): gamma / beta are done
             return
@@ -1196,19 +1256,23 @@ class BNOp(Op):
 
 class ConcatOp(Op):
     """Materialised concatenate(axis=-1) for consumers that cannot walk the pieces (BatchNormalization over a
-    concatenation: MultiResBlock, unet_variants.py:95-96).  Convolutions never need it (virtual concat)."""
+    concatenation: MultiResBlock, unet_variants.py:95-96).  Convolutions never need it (virtual concat); neither does a
+    BatchNormalization that is folded into a fused tail (`virtual`: this op then does nothing - see BNOp.make_virtual)."""
 
     def __init__(self, m, segs: List[Tuple[DevTensor, int]], out: DevTensor):
         self.m, self.segs, self.out = m, segs, out
+        self.virtual = False
 
     def forward(self, training):
+        if self.virtual:
+            return
         off = 0
         for t, c in self.segs:
             call("seg_copy_channels", _p(t.buf), t.cs, 0, _p(self.out.buf), self.out.cs, off, c, t.npix, 0, _stream())
             off += c
 
     def plan_backward(self):
-        self.live = self.out.gw
+        self.live = self.out.gw and not self.virtual
         self.accs = [t.claim() if (self.live and t.needs_grad) else None for t, _c in self.segs]
 
     def backward(self):
@@ -1233,19 +1297,39 @@ class AddOp(Op):
         self.ptrs = (C.c_void_p * 4)(*[x.buf.data_ptr() for x in xs])
         self.fused_bn: Optional[BNOp] = None          # the BatchNormalization that follows (fused tail): gets its statistics from here
         self.folded: List[Optional[BNOp]] = [None] * len(xs)      # inputs that are BatchNormalizations applied on the fly
+        self.lazy: List[Optional[ConvOp]] = [None] * len(xs)      # inputs that are Conv_Blocks normalised on load (training passes)
+        self.virtual_bn: Optional[BNOp] = None        # the folded BatchNormalization whose input is a virtual concatenation
+        self.tail_grad: Optional[DevTensor] = None    # backward: the input whose gradient buffer holds THE gradient of the add
 
     def fuse(self, bn: "BNOp"):
+        """Argument sets of the fused forward launch: [training] reads lazy Conv_Blocks from their raw conv output, [inference]
+        from their (then materialised) output; a virtual concatenation is not a dense input - it travels as the cat descriptor."""
         self.fused_bn = bn
-        srcs = [(b.x if b is not None else x) for x, b in zip(self.xs, self.folded)]
-        self.fptrs = (C.c_void_p * 4)(*[t.buf.data_ptr() for t in srcs])
-        self.fscales = (C.c_void_p * 4)(*[(b.scale.data_ptr() if b is not None else None) for b in self.folded])
-        self.fshifts = (C.c_void_p * 4)(*[(b.shift.data_ptr() if b is not None else None) for b in self.folded])
+        self.virtual_bn = next((b for b in self.folded if b is not None and b.pieces is not None), None)
+        self.fsets = {}
+        for training in (True, False):
+            ptr, sc, sh, relu = [], [], [], []
+            for x, b, cv in zip(self.xs, self.folded, self.lazy):
+                if b is not None and b.pieces is not None:
+                    continue
+                if b is not None:
+                    ptr.append(b.x.buf.data_ptr()); sc.append(b.scale.data_ptr()); sh.append(b.shift.data_ptr()); relu.append(0)
+                elif cv is not None and training:
+                    ptr.append(cv.z.buf.data_ptr()); sc.append(cv.scale.data_ptr()); sh.append(cv.shift.data_ptr())
+                    relu.append(1 if ACT[cv.act] == ACT["relu"] else 0)
+                else:
+                    ptr.append(x.buf.data_ptr()); sc.append(None); sh.append(None); relu.append(0)
+            pad = lambda v, fill=None: list(v) + [fill] * (4 - len(v))
+            self.fsets[training] = ((C.c_void_p * 4)(*pad(ptr)), (C.c_void_p * 4)(*pad(sc)), (C.c_void_p * 4)(*pad(sh)),
+                                    (C.c_int32 * 4)(*pad(relu, 0)), len(ptr))
 
     def forward(self, training):
         if self.fused_bn is not None:
-            b = self.fused_bn
-            call("seg_add_act_stats_fwd", self.fptrs, self.fscales, self.fshifts, len(self.xs), _p(self.out.buf), self.out.npix, self.out.cs,
-                 ACT[self.act], float(self.alpha), _p(b.stats), b.nparts, _stream())
+            b, vb = self.fused_bn, self.virtual_bn
+            ptr, sc, sh, relu, n = self.fsets[bool(training)]
+            call("seg_add_act_stats_fwd", ptr, sc, sh, relu, n, C.byref(vb.cat) if vb is not None else None,
+                 _p(vb.scale) if vb is not None else None, _p(vb.shift) if vb is not None else None, _p(self.out.buf), self.out.npix,
+                 self.out.cs, self.out.C, ACT[self.act], float(self.alpha), _p(b.stats), b.nparts, _stream())
             return
         call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
              float(self.alpha), _stream())
@@ -1255,11 +1339,35 @@ class AddOp(Op):
         if not self.live:
             return
         self.mask, gp = 0, []
+        fused = self.fused_bn is not None
+        # fused tail: the add hands ONE gradient to all its inputs.  It is written once, into the buffer of the input whose producer
+        # runs its backward LAST (the first in forward order); a Conv_Block behind another input reads that buffer (ConvOp.grad_src)
+        # and writes its own dz, a virtual concatenation's BatchNormalization reads it in seg_cat_bn_bwd_scatter.
+        prod = [self.m.producer_of.get(id(x)) for x in self.xs]
+        share = (fused and TAIL_SHARED_GRAD and len(self.xs) >= 2 and all(x.needs_grad and not x.gw for x in self.xs)
+                 and prod[0] is not None and prod[0].has_bn
+                 and all((p is not None and p.has_bn and self.m.ops.index(p) > self.m.ops.index(prod[0])) or (b is not None and b.pieces is not None)
+                         for p, b in list(zip(prod, self.folded))[1:]))
         for k, x in enumerate(self.xs):
+            b = self.folded[k] if fused else None
+            if b is not None and b.pieces is not None:
+                x.gw = True                   # (no buffer: the gradient of BN(cat)'s OUTPUT is the add's gradient itself)
+                gp.append(None)
+                if self.tail_grad is None and not share:
+                    raise NotImplementedError("a virtual concatenation needs a dense sibling input that carries the add's gradient")
+                continue
+            if share and k > 0:
+                x.gw = True
+                x.ensure_grad()               # the Conv_Block's own dz lands here; dOut is read from the shared buffer
+                prod[k].grad_src = self.xs[0]
+                gp.append(None)
+                continue
             if x.needs_grad:
                 if x.claim():
                     self.mask |= 1 << k
                 gp.append(x.grad.data_ptr())
+                if k == 0:
+                    self.tail_grad = x
             else:
                 gp.append(None)
         self.gptrs = (C.c_void_p * 4)(*gp)
@@ -1744,6 +1852,25 @@ class SegModel:
                 add.folded[k] = b1
                 b1.folded_into = add
                 b1.out.materialised = False                   # (never written: tests / tools must not read it)
+                # BN over a concatenation (MultiResBlock's BN(cat[c3, c5, c7]), unet_variants.py:95-96) that only this add reads: the
+                # concatenation is never materialised either - the tail kernels gather the pieces (a dense sibling input must carry
+                # the add's gradient for the backward scatter: input 0, checked in AddOp.plan_backward)
+                co = next((o for o in self.ops if isinstance(o, ConcatOp) and o.out is b1.x), None)
+                bn1 = g.nodes[addn.inputs[k]]
+                if (TAIL_VIRTUAL_CAT and TAIL_SHARED_GRAD and co is not None and k > 0 and len(co.segs) <= 4 and b1.C <= 2048
+                        and list(cons[bn1.inputs[0]]) == [bn1.idx]
+                        and any(isinstance(o, ConvOp) and o.out is add.xs[0] and o.has_bn for o in self.ops)):
+                    co.virtual = True
+                    b1.make_virtual(co.segs)
+                    b1.out.buf = torch.empty((0,), dtype=b1.out.buf.dtype, device=b1.out.buf.device)
+                continue
+            # a Conv_Block (conv -> BN -> ReLU) whose only consumer is this add: normalised on load inside the add (training passes)
+            cv = next((o for o in self.ops if isinstance(o, ConvOp) and o.out is x), None)
+            if (TAIL_LAZY_INPUTS and cv is not None and cv.has_bn and cv.kind == "conv" and cv.pooled is None
+                    and ACT[cv.act] in (ACT[None], ACT["relu"])):
+                add.lazy[k] = cv
+                cv.lazy = True
+                cv.out.materialised = False                   # (written by inference passes only)
         bop.fused_add = add
         add.fuse(bop)
 
