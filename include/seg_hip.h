@@ -261,13 +261,24 @@ typedef struct {
   int32_t acc;        /* seg_cat_bn_bwd_scatter: add to dx instead of storing                                               */
 } seg_cat_piece;
 typedef struct { int32_t n; seg_cat_piece p[4]; } seg_cat_desc;
+/* An input of the add that is a Conv_Block normalised on load (see `forward`): the gradient the backward launch writes is that
+ * block's dOut, so the launch also delivers the two sums of the block's own BatchNormalization backward - per-block partial rows
+ * partial[nparts][2][cs] of sum dOut act'(.) and sum dOut act'(.) xhat_z, the operand of seg_bn_bwd_finalize - from the block's
+ * raw conv output z (replaces a seg_bn_act_bwd_reduce pass over dOut and z).                                                       */
+typedef struct {
+  const void* z;                 /* raw conv output [npix][cs]                                                              */
+  const float *scale, *shift;    /* the block's BatchNormalization as y = z * scale + shift (activation mask)               */
+  const float *mean, *invstd;    /* its batch statistics (xhat_z)                                                           */
+  int32_t relu;                  /* the block ends in a ReLU                                                                */
+  float* partial;
+} seg_lazy_bn;
 int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n,
                           const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,
                           int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
 int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
                             int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
                             int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
-                            float* cat_partial, int32_t nparts, seg_stream_t stream);
+                            float* cat_partial, const seg_lazy_bn* lazy, int32_t nlazy, int32_t nparts, seg_stream_t stream);
 int seg_cat_bn_bwd_scatter(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,
                            const float* invstd, const float* c1, const float* c2, seg_stream_t stream);
 
@@ -470,7 +481,7 @@ int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales,
 int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
                                 int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
                                 int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
-                                float* cat_partial, int32_t nparts, seg_stream_t stream);
+                                float* cat_partial, const seg_lazy_bn* lazy, int32_t nlazy, int32_t nparts, seg_stream_t stream);
 int seg_cat_bn_bwd_scatter_f32(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,
                                const float* invstd, const float* c1, const float* c2, seg_stream_t stream);
 int seg_mul_bcast_fwd_f32(const void* a, const void* r, void* y, int64_t npix, int32_t cs, int32_t r_cs,

@@ -81,6 +81,8 @@ BASELINE_BATCH = {"C1": 8, "C2": 16, "C3": 16, "C4": 8, "C5": 8}
 
 def pads_are_zero(model):
     for name, t in model.tensors.items():
+        if t.buf.numel() == 0:          # (a virtual concatenation / a BatchNormalization applied on the fly: never stored)
+            continue
         if t.cs > t.C and float(U.M.DevTensor.decode(t.buf)[..., t.C:].abs().max()) != 0.0:
             return name
     return None

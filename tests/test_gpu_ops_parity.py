@@ -126,7 +126,7 @@ def test_fused_tail_add_relu_statistics_and_fanout_backward():
     d2 = dev(prev)
     gp = (C.c_void_p * 4)(d1.data_ptr(), d2.data_ptr(), None, None)
     dyd, keep = dev(dy), [pad(v) for v in (gamma * invstd, mean, invstd, c1, c2)]      # (held: P() only takes the address)
-    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dyd), P(y), gp, 2, 0b10, npix, cs, *[P(t) for t in keep], 1, None, None, None, None, 0, stream())
+    ffi.call("seg_bn_bwd_apply_fanout_f32", P(dyd), P(y), gp, 2, 0b10, npix, cs, *[P(t) for t in keep], 1, None, None, None, None, None, 0, 0, stream())
     torch.cuda.synchronize()
     assert rel(val(d1, Cc), want) < 2e-5 and rel(val(d2, Cc), want + prev) < 2e-5
 
@@ -214,10 +214,34 @@ def test_multires_tail_over_a_virtual_concatenation(chans, W, f32):
     gp = (C.c_void_p * 4)(gbuf.data_ptr(), None, None, None)
     nb = 5
     part = torch.full((nb * 2 * cs,), 9.0, device="cuda")
-    ffi.call("seg_bn_bwd_apply_fanout" + sfx, P(dyd), P(sd), gp, 2, 0, npix, cs, *[P(t) for t in k2], 1, C.byref(cat), P(k1[0]), P(k1[1]), P(part), nb, stream())
+    # (the dense input is a Conv_Block normalised on load: the sums of ITS BatchNormalization backward ride along - seg_lazy_bn)
+    mu_a, is_a = za.mean((0, 1, 2)), torch.rsqrt(za.var((0, 1, 2), unbiased=False) + 1e-3)
+    kl = [pad(mu_a), pad(is_a)]
+    lpart = torch.full((nb * 2 * cs,), 9.0, device="cuda")
+    lz = (ffi.LazyBN * 2)()
+    lz[0].z, lz[0].scale, lz[0].shift, lz[0].mean, lz[0].invstd, lz[0].relu, lz[0].partial = (
+        zad.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), kl[0].data_ptr(), kl[1].data_ptr(), 1, lpart.data_ptr())
+    ffi.call("seg_bn_bwd_apply_fanout" + sfx, P(dyd), P(sd), gp, 2, 0, npix, cs, *[P(t) for t in k2], 1, C.byref(cat), P(k1[0]), P(k1[1]), P(part),
+             lz, 1, nb, stream())
     torch.cuda.synchronize()
     gv = U.dev_values(gbuf)[..., :Cc]
     assert rel(gv, want_g) < tol
+    gm = gv * ((za * sa + ha) > 0)
+    lp = lpart.reshape(nb, 2, cs).sum(0).cpu()
+    assert rel(lp[0, :Cc], gm.sum((0, 1, 2))) < 1e-4 and rel(lp[1, :Cc], (gm * (za - mu_a) * is_a).sum((0, 1, 2))) < 1e-4
+    # the same launch without the concatenation (ResPath: two Conv_Blocks normalised on load) gives the same dense result and sums
+    g2 = torch.full_like(zad, 4.0)
+    gp2 = (C.c_void_p * 4)(g2.data_ptr(), None, None, None)
+    lz[1].z, lz[1].scale, lz[1].shift, lz[1].mean, lz[1].invstd, lz[1].relu, lz[1].partial = (
+        zad.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), kl[0].data_ptr(), kl[1].data_ptr(), 0, st1.data_ptr())      # (no ReLU: plain sums)
+    lpart.fill_(9.0)
+    ffi.call("seg_bn_bwd_apply_fanout" + sfx, P(dyd), P(sd), gp2, 2, 0, npix, cs, *[P(t) for t in k2], 1, None, None, None, None, lz, 2, nb, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(U.dev_values(g2), U.dev_values(gbuf))
+    lp2 = lpart.reshape(nb, 2, cs).sum(0).cpu()
+    assert rel(lp2[:, :Cc], lp[:, :Cc]) < 1e-5
+    lp3 = st1[:nb * 2 * cs].reshape(nb, 2, cs).sum(0).cpu()
+    assert rel(lp3[0, :Cc], gv.sum((0, 1, 2))) < 1e-4 and rel(lp3[1, :Cc], (gv * (za - mu_a) * is_a).sum((0, 1, 2))) < 1e-4
     xh1 = ((catv - mean1) * invstd1).detach()
     ps = part.reshape(nb, 2, cs).sum(0).cpu()
     assert rel(ps[0, :Cc], gv.sum((0, 1, 2))) < 1e-4 and rel(ps[1, :Cc], (gv * xh1).sum((0, 1, 2))) < 1e-4

@@ -79,7 +79,8 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     of the BN that follows; that BN's backward writes the masked gradient to the add's inputs.  Against the unfused lowering: no
     seg_add_act_fwd / seg_add_act_bwd, one seg_bn_stats and one seg_bn_act_apply fewer per fused BN / folded BN.
     Round 4 on top (each behind its own switch): the Conv_Blocks that feed only the add are normalised ON LOAD there (no
-    seg_bn_act_apply for them), cat[c3, c5, c7] is never materialised (no seg_copy_channels, its statistics from one gathering
+    seg_bn_act_apply for them; their BN-backward sums come out of the tail's fan-out launch, no reduce pass), cat[c3, c5, c7] is
+    never materialised (no seg_copy_channels, its statistics from one gathering
     launch, its backward = finalize + seg_cat_bn_bwd_scatter), and the add's gradient is written once."""
     def counts():
         m = B("MultiResUNet", 32, 32, 16, 2, alpha=1.0).build(2, dtype="f16")
@@ -89,7 +90,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
         lazy = sum(1 for o in m.ops if isinstance(o, M.ConvOp) and o.lazy)
         virt = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.pieces is not None)
         return c, tails, folded, lazy, virt, m
-    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT"):
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS"):
         monkeypatch.setattr(M, sw, False)
     c1, tails, folded, lazy, virt, _m = counts()                                # the round-3 form
     assert tails > 0 and folded > 0 and lazy == 0 and virt == 0
@@ -103,7 +104,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     assert c0["seg_bn_act_bwd_apply"] - c1["seg_bn_act_bwd_apply"] == tails    # replaced by the fan-out form
     # ---- round 4
     monkeypatch.setattr(M, "FUSE_BN_TAILS", True)
-    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT"):
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS"):
         monkeypatch.setattr(M, sw, True)
     c2, tails2, folded2, lazy, virt, m = counts()
     assert (tails2, folded2) == (tails, folded) and virt == folded            # every BN(cat) of this model is a virtual concatenation
@@ -112,7 +113,9 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     assert c2["seg_copy_channels"] == 0 and c1["seg_copy_channels"] == 2 * 3 * folded      # three pieces, forward and backward
     assert c2["seg_bn_stats"] == c1["seg_bn_stats"] - folded and c2["seg_add_act_stats_fwd"] == tails + folded
     assert c2["seg_cat_bn_bwd_scatter"] == folded
-    assert c1["seg_bn_act_bwd_reduce"] - c2["seg_bn_act_bwd_reduce"] == folded  # BN(cat)'s sums ride on the fan-out launch
+    # BN(cat)'s sums ride on the fan-out launch, and so do those of the Conv_Blocks normalised on load (their dOut is written there)
+    assert c1["seg_bn_act_bwd_reduce"] - c2["seg_bn_act_bwd_reduce"] == folded + lazy
+    assert c1["seg_bn_bwd_finalize"] == c2["seg_bn_bwd_finalize"]
     assert c1["seg_bn_act_bwd_apply"] - c2["seg_bn_act_bwd_apply"] == folded    # ... and its input gradient is the scatter
     assert not any(isinstance(o, M.ConcatOp) and not o.virtual for o in m.ops)
     # the add's gradient is written once: every second input reads the first one's buffer

@@ -74,6 +74,12 @@ class CatDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("p", CatPiece * 4)]
 
 
+class LazyBN(C.Structure):
+    """seg_lazy_bn: a Conv_Block normalised on load by a fused add (its BN-backward sums ride on the fan-out launch)."""
+    _fields_ = [("z", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("relu", C.c_int32), ("partial", C.c_void_p)]
+
+
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 _PROTOS = {
@@ -101,7 +107,7 @@ _PROTOS = {
     "seg_upsample_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_add_act_fwd": ([C.POINTER(vp), i32, vp, i64, i32, f32, vp], C.c_int),
     "seg_add_act_stats_fwd": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(CatDesc), vp, vp, vp, i64, i32, i32, i32, f32, vp, i32, vp], C.c_int),
-    "seg_bn_bwd_apply_fanout": ([vp, vp, C.POINTER(vp), i32, i32, i64, i32, vp, vp, vp, vp, vp, i32, C.POINTER(CatDesc), vp, vp, vp, i32, vp], C.c_int),
+    "seg_bn_bwd_apply_fanout": ([vp, vp, C.POINTER(vp), i32, i32, i64, i32, vp, vp, vp, vp, vp, i32, C.POINTER(CatDesc), vp, vp, vp, C.POINTER(LazyBN), i32, i32, vp], C.c_int),
     "seg_cat_bn_bwd_scatter": ([vp, C.POINTER(CatDesc), i64, i32, vp, vp, vp, vp, vp, vp], C.c_int),
     "seg_add_act_bwd": ([vp, vp, C.POINTER(vp), i32, i64, i32, f32, i32, vp], C.c_int),
     "seg_copy_channels": ([vp, i32, i32, vp, i32, i32, i32, i64, i32, vp], C.c_int),

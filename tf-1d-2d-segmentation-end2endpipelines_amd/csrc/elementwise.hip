@@ -826,25 +826,34 @@ __global__ __launch_bounds__(TPB) void tail_fwd_kernel(Ptr4<T> xs, Aff4 aff, int
   }
 }
 
-template <typename T, bool GATHER>
+// LZ > 0: up to two inputs of the add are Conv_Blocks normalised on load (conv -> BN -> ReLU whose only consumer is this add):
+// the gradient written here IS their dOut, so the two sums their own BatchNormalization backward needs - sum dOut act'(.),
+// sum dOut act'(.) xhat_z - are accumulated in this launch from their raw conv outputs z (one more read each) instead of by a
+// seg_bn_act_bwd_reduce pass per block (two reads each).
+struct LazyBN { const void* z; const float *sc, *sh, *mu, *is; int relu; float* partial; };
+struct LazyBN2 { LazyBN l[2]; };
+
+template <typename T, bool GATHER, int LZ>
 __global__ __launch_bounds__(TPB) void tail_bwd_fanout_kernel(const T* dy, const T* x, MPtr4<T> dxs, int n, int accmask, int64_t npix, int cs,
                                                               const float* scale, const float* mean, const float* invstd, const float* c1,
                                                               const float* c2, int relu_mask, CatDev cdv, const float* cat_mean,
-                                                              const float* cat_invstd, float* cat_partial, ColLayout L) {
-  __shared__ float sm[GATHER ? TPB * 8 * UNR : 1];
+                                                              const float* cat_invstd, float* cat_partial, LazyBN2 lz, ColLayout L) {
+  constexpr int UN = LZ > 0 ? 2 : UNR;            // (the lazy sums keep 40 more registers per input: two pixels per thread in flight)
+  __shared__ float sm[GATHER ? TPB * 8 * UN : (LZ > 0 ? TPB * 8 : 1)];
   __shared__ CatDev scd;
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
-  const int TP = L.RP * UNR;
+  const int TP = L.RP * UN;
   const int ch = col;
+  const bool ok = ch < L.CH;
   if (GATHER) {
     if (threadIdx.x == 0) scd = cdv;
     for (int i = threadIdx.x; i < TP * cs; i += TPB) sm[i] = 0.f;
   }
   float sc[8], ka[8], kb[8], cmu[8], cis[8], acc[2][8];
+  float lsc[LZ > 0 ? LZ : 1][8], lsh[LZ > 0 ? LZ : 1][8], lmu[LZ > 0 ? LZ : 1][8], lacc[LZ > 0 ? LZ : 1][2][8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int c = ch * 8 + t;
-    const bool ok = ch < L.CH;
     sc[t] = ok ? scale[c] : 0.f;
     const float k = ok ? invstd[c] * c2[c] : 0.f;
     ka[t] = -sc[t] * k;
@@ -853,6 +862,14 @@ __global__ __launch_bounds__(TPB) void tail_bwd_fanout_kernel(const T* dy, const
     cis[t] = (GATHER && ok) ? cat_invstd[c] : 0.f;
     acc[0][t] = 0.f;
     acc[1][t] = 0.f;
+#pragma unroll
+    for (int j = 0; j < LZ; ++j) {
+      lsc[j][t] = ok ? lz.l[j].sc[c] : 0.f;
+      lsh[j][t] = ok ? lz.l[j].sh[c] : 0.f;
+      lmu[j][t] = ok ? lz.l[j].mu[c] : 0.f;
+      lacc[j][0][t] = 0.f;
+      lacc[j][1][t] = 0.f;
+    }
   }
   for (int64_t p0 = (int64_t)blockIdx.x * TP; p0 < npix; p0 += (int64_t)TP * gridDim.x) {
     if (GATHER) {
@@ -860,18 +877,20 @@ __global__ __launch_bounds__(TPB) void tail_bwd_fanout_kernel(const T* dy, const
       cat_gather<T>(&scd, p0, TP, npix, sm, cs);
       __syncthreads();
     }
-    if (ch >= L.CH) continue;
-    float g[UNR][8], xv[UNR][8];
+    if (!ok) continue;
+    float g[UN][8], xv[UN][8], zv[LZ > 0 ? LZ : 1][UN][8];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
       if (pix < npix) {
         load8(dy + pix * cs + ch * 8, g[u]);
         load8(x + pix * cs + ch * 8, xv[u]);
+#pragma unroll
+        for (int j = 0; j < LZ; ++j) load8((const T*)lz.l[j].z + pix * cs + ch * 8, zv[j][u]);
       }
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
       if (pix >= npix) continue;
       float o[8];
@@ -880,12 +899,21 @@ __global__ __launch_bounds__(TPB) void tail_bwd_fanout_kernel(const T* dy, const
         const float v = g[u][t] * sc[t] + xv[u][t] * ka[t] + kb[t];
         o[t] = (relu_mask && !(xv[u][t] > 0.f)) ? 0.f : v;
       }
-      if (GATHER) {
+      if (GATHER || LZ > 0) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const float gg = stored<T>(o[t]);           // the sums of what seg_cat_bn_bwd_scatter will read back
-          acc[0][t] += gg;
-          acc[1][t] += gg * (sm[(rowi + u * L.RP) * cs + ch * 8 + t] - cmu[t]) * cis[t];
+          const float gg = stored<T>(o[t]);           // the sums of what the consumers of this gradient will read back
+          if (GATHER) {
+            acc[0][t] += gg;
+            acc[1][t] += gg * (sm[(rowi + u * L.RP) * cs + ch * 8 + t] - cmu[t]) * cis[t];
+          }
+#pragma unroll
+          for (int j = 0; j < LZ; ++j) {
+            const float pre = zv[j][u][t] * lsc[j][t] + lsh[j][t];
+            const float gm = (lz.l[j].relu && !(pre > 0.f)) ? 0.f : gg;
+            lacc[j][0][t] += gm;
+            lacc[j][1][t] += gm * (zv[j][u][t] - lmu[j][t]);        // (x invstd once, at the end)
+          }
         }
       }
 #pragma unroll
@@ -907,11 +935,23 @@ __global__ __launch_bounds__(TPB) void tail_bwd_fanout_kernel(const T* dy, const
   if (GATHER) {
     __syncthreads();
     block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
-    if (rowi == 0 && ch < L.CH) {
+    if (rowi == 0 && ok) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         cat_partial[((size_t)blockIdx.x * 2 + 0) * cs + ch * 8 + t] = acc[0][t];
         cat_partial[((size_t)blockIdx.x * 2 + 1) * cs + ch * 8 + t] = acc[1][t];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LZ; ++j) {
+    __syncthreads();
+    block_col_reduce<2>(lacc[j], sm, rowi, col, L.CHP, L.RP);
+    if (rowi == 0 && ok) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        lz.l[j].partial[((size_t)blockIdx.x * 2 + 0) * cs + ch * 8 + t] = lacc[j][0][t];
+        lz.l[j].partial[((size_t)blockIdx.x * 2 + 1) * cs + ch * 8 + t] = lacc[j][1][t] * lz.l[j].is[ch * 8 + t];
       }
     }
   }
@@ -2066,28 +2106,38 @@ template <typename T>
 static int seg_bn_bwd_apply_fanout_impl(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs,
                                         const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
                                         int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
-                                        float* cat_partial, int32_t nparts, seg_stream_t stream) {
+                                        float* cat_partial, const seg_lazy_bn* lazy, int32_t nlazy, int32_t nparts, seg_stream_t stream) {
   SEG_CHECK_ARG(dy && x && dxs && n >= 1 && n <= 4 && npix > 0 && cs > 0 && (cs & 7) == 0 && cs <= 8 * TPB && scale && mean && invstd && c1 && c2 &&
-                (cat == nullptr || (cat_mean && cat_invstd && cat_partial && nparts > 0)), "seg_bn_bwd_apply_fanout: bad arguments");
+                (cat == nullptr || (cat_mean && cat_invstd && cat_partial)) && nlazy >= 0 && nlazy <= 2 && (nlazy == 0 || lazy != nullptr) &&
+                ((cat == nullptr && nlazy == 0) || nparts > 0), "seg_bn_bwd_apply_fanout: bad arguments");
   MPtr4<T> p;
   for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (T*)dxs[k] : nullptr;
   CatDev cd;
   if (int rc = cat_to_dev(cat, cs, false, &cd)) return rc;
+  LazyBN2 lz;
+  for (int j = 0; j < 2; ++j) {
+    lz.l[j] = LazyBN{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    if (j < nlazy) {
+      const seg_lazy_bn& q = lazy[j];
+      SEG_CHECK_ARG(q.z && q.scale && q.shift && q.mean && q.invstd && q.partial, "seg_bn_bwd_apply_fanout: lazy input %d", j);
+      lz.l[j] = LazyBN{q.z, q.scale, q.shift, q.mean, q.invstd, q.relu, q.partial};
+    }
+  }
   const ColLayout L = col_layout(cs);
   int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
   if (blocks > 512) blocks = 512;
-  if (cat != nullptr) {      // one partial row per block: the grid IS the row count the finalize launch is told
-    hipLaunchKernelGGL((tail_bwd_fanout_kernel<T, true>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n, accumulate_mask,
-                       npix, cs, scale, mean, invstd, c1, c2, relu_mask, cd, cat_mean, cat_invstd, cat_partial, L);
-  } else {
-    hipLaunchKernelGGL((tail_bwd_fanout_kernel<T, false>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n, accumulate_mask,
-                       npix, cs, scale, mean, invstd, c1, c2, relu_mask, cd, nullptr, nullptr, nullptr, L);
-  }
+  if (cat != nullptr || nlazy > 0) blocks = nparts;      // one partial row per block: the grid IS the row count the finalize launches are told
+#define LAUNCH_FANOUT(G, LZN)                                                                                                                \
+  hipLaunchKernelGGL((tail_bwd_fanout_kernel<T, G, LZN>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, (const T*)x, p, n,       \
+                     accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cd, cat_mean, cat_invstd, cat_partial, lz, L)
+  if (cat != nullptr) { if (nlazy == 0) LAUNCH_FANOUT(true, 0); else if (nlazy == 1) LAUNCH_FANOUT(true, 1); else LAUNCH_FANOUT(true, 2); }
+  else { if (nlazy == 0) LAUNCH_FANOUT(false, 0); else if (nlazy == 1) LAUNCH_FANOUT(false, 1); else LAUNCH_FANOUT(false, 2); }
+#undef LAUNCH_FANOUT
   SEG_CHECK_LAUNCH("seg_bn_bwd_apply_fanout");
   return SEG_OK;
 }
-extern "C" int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd, float* cat_partial, int32_t nparts, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<half_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cat, cat_mean, cat_invstd, cat_partial, nparts, stream); }
-extern "C" int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd, float* cat_partial, int32_t nparts, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<split_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cat, cat_mean, cat_invstd, cat_partial, nparts, stream); }
+extern "C" int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd, float* cat_partial, const seg_lazy_bn* lazy, int32_t nlazy, int32_t nparts, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<half_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cat, cat_mean, cat_invstd, cat_partial, lazy, nlazy, nparts, stream); }
+extern "C" int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd, float* cat_partial, const seg_lazy_bn* lazy, int32_t nlazy, int32_t nparts, seg_stream_t stream) { return seg_bn_bwd_apply_fanout_impl<split_t>(dy, x, dxs, n, accumulate_mask, npix, cs, scale, mean, invstd, c1, c2, relu_mask, cat, cat_mean, cat_invstd, cat_partial, lazy, nlazy, nparts, stream); }
 
 template <typename T>
 static int seg_cat_bn_bwd_scatter_impl(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,

@@ -330,6 +330,7 @@ FUSE_INFERENCE_BN = os.environ.get("SEG_FUSE_INFERENCE_BN", "1") != "0"     # pr
 TAIL_LAZY_INPUTS = os.environ.get("SEG_TAIL_LAZY_INPUTS", "1") != "0"       # a Conv_Block feeding only the add is normalised on load there (no bn_act_apply pass)
 TAIL_SHARED_GRAD = os.environ.get("SEG_TAIL_SHARED_GRAD", "1") != "0"       # the add's gradient is written once; the Conv_Blocks behind it read the one buffer
 TAIL_VIRTUAL_CAT = os.environ.get("SEG_TAIL_VIRTUAL_CAT", "1") != "0"       # MultiResBlock's cat[c3, c5, c7] exists only in the tail kernels' LDS tiles
+TAIL_LAZY_SUMS = os.environ.get("SEG_TAIL_LAZY_SUMS", "1") != "0"           # the BN-backward sums of those Conv_Blocks ride on the tail's fan-out launch (no reduce pass)
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
@@ -698,6 +699,7 @@ class ConvOp(Op):
         self.gathered: Dict[int, "GatherDgrad"] = {}      # segment index -> gathered data gradient that covers it
         self.lazy = False            # training: `out` is never written - its only consumer (a fused add) normalises z on load
         self.grad_src: Optional[DevTensor] = None      # backward: dOut is read from this tensor's gradient (shared with a sibling)
+        self.tail_sums = 0           # backward: > 0 = a fused tail's fan-out launch already left this BN's two sums in `bpart` (that many rows)
         self.gather_launch: List["GatherDgrad"] = []      # gathered data gradients launched at the end of this op's backward
         self.dz_ptr = None
 
@@ -900,10 +902,11 @@ class ConvOp(Op):
             bn = self.bn_name
             dA = self.out.ensure_grad()
             src = _p(self.grad_src.grad if self.grad_src is not None else dA)      # (a sibling's buffer: written once for both, read-only here)
-            call("seg_bn_act_bwd_reduce", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
-                 _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
-                 _p(self.bpart), BN_PARTS_BWD, s)
-            call("seg_bn_bwd_finalize", _p(self.bpart), BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
+            if not self.tail_sums:
+                call("seg_bn_act_bwd_reduce", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
+                     _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
+                     _p(self.bpart), BN_PARTS_BWD, s)
+            call("seg_bn_bwd_finalize", _p(self.bpart), self.tail_sums or BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
                  st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
             call("seg_bn_act_bwd_apply", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
                  self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
@@ -1245,7 +1248,7 @@ class BNOp(Op):
                  _p(self.invstd), _p(self.c1), _p(self.c2), 1 if ACT[a.act] == ACT["relu"] else 0,
                  C.byref(vb.cat) if vb is not None else None, _p(vb.mean) if vb is not None else None,
                  _p(vb.invstd) if vb is not None else None, _p(vb.bpart) if vb is not None else None,
-                 vb.cat_parts if vb is not None else 0, s)
+                 a.lazy_descs, a.n_lazy_descs, self.cat_parts, s)
             return
         if self.acc is None:          # the input needs no gradient (a BN placed on the network input): gamma / beta are done
             return
@@ -1300,6 +1303,7 @@ class AddOp(Op):
         self.lazy: List[Optional[ConvOp]] = [None] * len(xs)      # inputs that are Conv_Blocks normalised on load (training passes)
         self.virtual_bn: Optional[BNOp] = None        # the folded BatchNormalization whose input is a virtual concatenation
         self.tail_grad: Optional[DevTensor] = None    # backward: the input whose gradient buffer holds THE gradient of the add
+        self.lazy_descs, self.n_lazy_descs = None, 0  # backward: seg_lazy_bn of the Conv_Blocks whose BN-backward sums ride on the fan-out
 
     def fuse(self, bn: "BNOp"):
         """Argument sets of the fused forward launch: [training] reads lazy Conv_Blocks from their raw conv output, [inference]
@@ -1371,6 +1375,19 @@ class AddOp(Op):
             else:
                 gp.append(None)
         self.gptrs = (C.c_void_p * 4)(*gp)
+        # Conv_Blocks normalised on load whose dOut is exactly the gradient written here (no other contribution): their
+        # BatchNormalization-backward sums come out of the fan-out launch (at most two: seg_bn_bwd_apply_fanout)
+        if fused and TAIL_LAZY_SUMS and self.mask == 0:
+            cvs = [cv for cv in self.lazy if cv is not None][:2]
+            if cvs:
+                parts = self.fused_bn.cat_parts
+                arr = (_ffi.LazyBN * 2)()
+                for d, cv in zip(arr, cvs):
+                    d.z, d.scale, d.shift, d.mean, d.invstd = (cv.z.buf.data_ptr(), cv.scale.data_ptr(), cv.shift.data_ptr(),
+                                                               cv.mean.data_ptr(), cv.invstd.data_ptr())
+                    d.relu, d.partial = (1 if ACT[cv.act] == ACT["relu"] else 0), cv.bpart.data_ptr()
+                    cv.tail_sums = parts
+                self.lazy_descs, self.n_lazy_descs = arr, len(cvs)
 
     def backward(self):
         if self.live and self.fused_bn is None:       # (fused tail: the BatchNormalization's backward wrote the inputs' gradients)
