@@ -417,6 +417,9 @@ typedef struct seg_transpose_desc {
   int32_t rows_pad, dst_ld, dst_coff;
   int32_t tile0;
   int32_t src16;                 /* != 0: w points at an fp16 copy of the weight (same layout) instead of the fp32 master */
+  int32_t dst_T, dst_t0;         /* dst_T > 0: the destination has dst_T taps and source tap t lands at tap t + dst_t0 (a 1x1
+                                    kernel as the centre tap of a 3x3 operand: the shortcut conv of a ResPath / MultiResBlock
+                                    joining the gathered data gradient of its 3x3 sibling); the other taps are never written   */
 } seg_transpose_desc;
 int seg_transpose_w_multi(const seg_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, seg_stream_t stream);
 /* fp32 -> fp16 cast of n elements                                                                              */

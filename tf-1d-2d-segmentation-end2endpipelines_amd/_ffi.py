@@ -62,7 +62,7 @@ class IgemmWgradArgs(C.Structure):
 class TransposeDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("rows", C.c_int32), ("T", C.c_int32), ("K", C.c_int32),
                 ("k0", C.c_int32), ("kcount", C.c_int32), ("rows_pad", C.c_int32), ("dst_ld", C.c_int32),
-                ("dst_coff", C.c_int32), ("tile0", C.c_int32), ("src16", C.c_int32)]
+                ("dst_coff", C.c_int32), ("tile0", C.c_int32), ("src16", C.c_int32), ("dst_T", C.c_int32), ("dst_t0", C.c_int32)]
 
 
 class CatPiece(C.Structure):

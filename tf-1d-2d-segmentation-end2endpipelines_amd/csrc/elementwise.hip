@@ -1784,7 +1784,9 @@ __global__ __launch_bounds__(TPB) void transpose_w_multi_kernel(const seg_transp
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = kt * 32 + ty + 8 * j, r = rt * 32 + tx;
-    if (k < d.kcount && r < d.rows_pad) store_elem(wt, ((int64_t)k * d.T + t) * d.dst_ld + d.dst_coff + r, tile[tx][ty + 8 * j]);
+    // (dst_T: the destination has more taps than the source - a 1x1 kernel laid into the centre tap dst_t0 of a 3x3 operand)
+    if (k < d.kcount && r < d.rows_pad)
+      store_elem(wt, ((int64_t)k * (d.dst_T > 0 ? d.dst_T : d.T) + t + d.dst_t0) * d.dst_ld + d.dst_coff + r, tile[tx][ty + 8 * j]);
   }
 }
 

@@ -332,6 +332,8 @@ TAIL_SHARED_GRAD = os.environ.get("SEG_TAIL_SHARED_GRAD", "1") != "0"       # th
 TAIL_VIRTUAL_CAT = os.environ.get("SEG_TAIL_VIRTUAL_CAT", "1") != "0"       # MultiResBlock's cat[c3, c5, c7] exists only in the tail kernels' LDS tiles
 TAIL_LAZY_SUMS = os.environ.get("SEG_TAIL_LAZY_SUMS", "1") != "0"           # the BN-backward sums of those Conv_Blocks ride on the tail's fan-out launch (no reduce pass)
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
+GATHER_DGRAD_1X1 = os.environ.get("SEG_GATHER_DGRAD_1X1", "1") != "0"       # the 1x1 shortcut conv joins the gathered data gradient of its 3x3 sibling
+GATHER_1X1_MAX_C = int(os.environ.get("SEG_GATHER_1X1_MAX_C", "64"))         # ... for layers of at most this many channels (HBM-bound ones)
 BIAS_FROM_WGRAD = os.environ.get("SEG_BIAS_FROM_WGRAD", "1") != "0"
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
 DP_ASYNC = os.environ.get("SEG_DP_ASYNC", "1") != "0"           # data parallel: exchanged slices are awaited + updated on the side stream under the next forward
@@ -968,7 +970,10 @@ class GatherDgrad:
             self.coloff.append(k)
             k += op.rows_pad
         self.Kg = k
-        self.T = members[0][0].T
+        # a 1x1 / stride-1 conv on the same tensor (the shortcut of a ResPath iteration / MultiResBlock, unet_variants.py:88,110)
+        # rides along as the CENTRE TAP of the 3x3 operand: its data gradient is no read-modify-write launch of its own
+        self.op3 = next(op for op, _si in members if op.T == 9)
+        self.T = 9
         self.w = torch.zeros(t.cs * self.T * self.Kg, dtype=DevTensor.dtype, device=_dev())
         self.args = None
         for op, si in members:
@@ -977,10 +982,10 @@ class GatherDgrad:
 
     def transpose_jobs(self):
         return [(self.m.store.ptr(op.wname, self.m.src_buf).value, self.w.data_ptr(), op.n_rows, op.T, op.Kpad, op.woff[si], self.t.cs,
-                 op.rows_pad, self.Kg, self.coloff[j]) for j, (op, si) in enumerate(self.members)]
+                 op.rows_pad, self.Kg, self.coloff[j]) + ((9, 4) if op.T == 1 else ()) for j, (op, si) in enumerate(self.members)]
 
     def plan(self):
-        op0 = self.members[0][0]
+        op0 = self.op3
         a = IgemmFwdArgs()
         a.g = op0.g_dgrad
         a.nseg = len(self.members)
@@ -1013,13 +1018,24 @@ def plan_gathers(m, ops) -> List[GatherDgrad]:
     for op in ops:
         if not isinstance(op, ConvOp) or op.kind != "conv" or op.wt is None:
             continue
-        if tuple(op.node.attrs["kernel"]) != (3, 3) or tuple(op.node.attrs.get("strides", (1, 1))) != (1, 1) or not fwd_halo_patch(op.g_dgrad):
+        kern, unit = tuple(op.node.attrs["kernel"]), tuple(op.node.attrs.get("strides", (1, 1))) == (1, 1)
+        if kern == (1, 1) and unit and GATHER_DGRAD_1X1:
+            # the 1x1 shortcut next to a 3x3 conv on the same tensor: a member only where the layer is HBM-bound (few channels on a
+            # large image - there the read-modify-write of its own launch is what it costs: level 0 of C4 154 us against ~60 as one
+            # more K segment of the sibling's launch); deeper levels are MFMA-bound and eight zero taps per product would lose
+            if not (len(op.segs) == 1 and op.segs[0][0].cs <= GATHER_1X1_MAX_C and op.n_rows <= GATHER_1X1_MAX_C):
+                continue
+        elif kern != (3, 3) or not unit or not fwd_halo_patch(op.g_dgrad):
             continue
         for si, (t, _c) in enumerate(op.segs):
             if t.needs_grad:
                 users.setdefault(id(t), []).append((op, si))
                 tens[id(t)] = t
-    return [GatherDgrad(m, tens[k], mem) for k, mem in users.items() if 2 <= len(mem) <= _ffi.MAX_SEG]
+    out = []
+    for k, mem in users.items():
+        if any(op.T == 9 for op, _si in mem) and 2 <= len(mem) <= _ffi.MAX_SEG:       # (a 1x1 conv alone is no gathered launch)
+            out.append(GatherDgrad(m, tens[k], mem))
+    return out
 
 
 def _pad_to(n):
@@ -1904,8 +1920,10 @@ class SegModel:
         if not jobs or _DryRun.on:
             return
         arr = (TransposeDesc * len(jobs))()
-        for d, (w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff) in zip(arr, jobs):
+        for d, job in zip(arr, jobs):
+            w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff = job[:10]
             d.w, d.wt, d.rows, d.T, d.K, d.k0, d.kcount, d.rows_pad, d.dst_ld, d.dst_coff = w, wt, rows, T, K, k0, kcount, rows_pad, dst_ld, dst_coff
+            d.dst_T, d.dst_t0 = job[10:12] if len(job) > 10 else (0, 0)
             d.tile0, d.src16 = self.tr_tiles, src16
             self.tr_tiles += T * _cdiv(kcount, 32) * _cdiv(rows_pad, 32)
         self.tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(_dev())

@@ -36,6 +36,17 @@ def main(d):
         gaps = sorted(((mainq[i + 1]["s"] - mainq[i]["e"], mainq[i]["Kernel_Name"][:30], mainq[i + 1]["Kernel_Name"][:30]) for i in range(len(mainq) - 1)),
                       reverse=True)[:6]
         print("   largest main-queue gaps (us):", [(round(g / 1e3, 1), x, y) for g, x, y in gaps])
+        # launch-count view of the step: kernels per queue, the idle time behind each kernel name (what the dependent chains of
+        # ten-microsecond launches cost), and the at::native launches inside the step (fills / copies that are NOT build-time)
+        allg = [(mainq[i + 1]["s"] - mainq[i]["e"], mainq[i]["Kernel_Name"]) for i in range(len(mainq) - 1)]
+        idle_by = Counter()
+        for gns, nm in allg:
+            idle_by[nm.split("<")[0].split("(")[0][-40:]] += max(gns, 0)
+        print(f"   kernels: main {len(mainq)}, side {len(side)}; main-queue gaps: {sum(1 for g_, _ in allg if g_ > 2000)} above 2 us, "
+              f"sum {sum(max(g_, 0) for g_, _ in allg) / 1e6:.3f} ms")
+        print("   idle behind (ms):", [(k, round(v / 1e6, 3)) for k, v in idle_by.most_common(8)])
+        native = Counter(r["Kernel_Name"].split("<")[0][-48:] for r in step if "at::native" in r["Kernel_Name"] or "rocclr" in r["Kernel_Name"])
+        print("   at::native / runtime launches inside the step:", dict(native))
 
 
 if __name__ == "__main__":
