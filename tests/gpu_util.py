@@ -185,12 +185,13 @@ def ref_conv(xs, kern, bias, kind, strides):
 
 
 # ------------------------------------------------------------------------------------------------ whole-model compare
-def oracle_run(g, w_np, x, targets, loss, emulate_fp16=False):
+def oracle_run(g, w_np, x, targets, loss, emulate_fp16=False, impose=None):
     """Forward (training-mode BN) + loss + backward of the oracle primitives wired by graph g.  Returns what
-    compare_model needs; computed once and shared when several engine modes are compared at an expensive size."""
+    compare_model needs; computed once and shared when several engine modes are compared at an expensive size.
+    impose: branch decisions of another run (ir_interp.run_graph)."""
     W = {k: torch.from_numpy(np.array(v, np.float32)).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
          for k, v in w_np.items()}
-    outs_ref, vals = run_graph(g, x, W, training=True, return_all=True, emulate_fp16=emulate_fp16)
+    outs_ref, vals = run_graph(g, x, W, training=True, return_all=True, emulate_fp16=emulate_fp16, impose=impose)
     for v in vals.values():
         if v.requires_grad:
             v.retain_grad()
@@ -199,7 +200,57 @@ def oracle_run(g, w_np, x, targets, loss, emulate_fp16=False):
     return dict(W=W, outs=outs_ref, vals=vals, loss=ref_loss)
 
 
-def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, oracle=None):
+def gpu_decisions(model):
+    """The branch decisions the GPU run just took (after forward(training=True)), per graph node, in the form ir_interp.run_graph
+    imposes: ReLU / LeakyReLU nodes -> bool "positive branch" (from the stored output, or - a Conv_Block normalised on load, never
+    stored - from its raw conv output and the device's own scale / shift), max-pool nodes -> arg-max positions of the STORED input
+    (first maximum in scan order: the rule of seg_maxpool_bwd and of torch alike), ConvLSTM nodes -> the hard-sigmoid knees of the
+    input and output gates from the stored gate pre-activations."""
+    g = model.graph
+    dec = {}
+    lazy = {op.out.name: op for op in model.ops if isinstance(op, M.ConvOp) and getattr(op, "lazy", False)}
+    for i in g.live_nodes():
+        n = g.nodes[i]
+        if n.kind == "act" and n.attrs["fn"] in ("relu", "leaky_relu"):
+            t = model.tensors.get(n.name)
+            if t is None:
+                continue
+            if n.name in lazy:
+                op = lazy[n.name]
+                pre = op.z.values().cpu() * op.scale[:op.cout].cpu() + op.shift[:op.cout].cpu()
+                dec[n.name] = pre > 0
+            elif t.buf.numel() and getattr(t, "materialised", True):
+                dec[n.name] = t.values().cpu() > 0
+        elif n.kind == "maxpool":
+            src = model.tensors.get(g.nodes[n.inputs[0]].name)
+            if src is not None and src.buf.numel() and getattr(src, "materialised", True):
+                xv = src.values().cpu().permute(0, 3, 1, 2)
+                _y, idx = F.max_pool2d(xv, n.attrs["size"], n.attrs["size"], return_indices=True)
+                dec[n.name] = idx
+        elif n.kind == "convlstm":
+            z = model.tensors.get(n.name + ":z")
+            if z is not None:
+                zi, _zf, _zc, zo = torch.chunk(z.values().cpu(), 4, dim=-1)
+                dec[n.name] = {k: (0.2 * v + 0.5 <= 0.0, 0.2 * v + 0.5 >= 1.0) for k, v in (("i", zi), ("o", zo))}
+    return dec
+
+
+def decision_flips(dec, vals, g):
+    """How many of the imposed decisions differ from the ones the oracle takes on its own: {node name: (differing, elements)}."""
+    out = {}
+    for name, d in dec.items():
+        n = next(nd for nd in g.nodes if nd.name == name)
+        if n.kind == "act":
+            own = vals[name].detach() > 0
+            out[name] = (int((own != d).sum()), d.numel())
+        elif n.kind == "maxpool":
+            xin = vals[g.nodes[n.inputs[0]].name].detach().permute(0, 3, 1, 2)
+            _y, idx = F.max_pool2d(xin, n.attrs["size"], n.attrs["size"], return_indices=True)
+            out[name] = (int((idx != d).sum()), idx.numel())
+    return out
+
+
+def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, oracle=None, impose_decisions=False):
     """Runs forward(training) + loss + backward on the GPU model and on the oracle primitives wired by the same
     graph (the wiring itself is checked against the independent oracle wiring in test_graph_builders.py).
     Returns per-node forward errors, loss pair, per-node activation-gradient errors and per-parameter gradient
@@ -260,6 +311,22 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, or
         na, nb = np.linalg.norm(a), np.linalg.norm(b)
         res["gcos"][k] = (float(a @ b / (na * nb + 1e-300)), float(na / (nb + 1e-300)), float(np.abs(gr).max()))
         res.setdefault("gl2", {})[k] = (float(np.linalg.norm(a - b)), float(nb))
+    # a conv bias in front of BatchNormalization has a mathematically ZERO gradient (the normalisation removes it): both sides hold
+    # only the summation noise of N cancelling terms there - judged against the model's largest gradient norm, not relatively
+    res["zero_grad_params"] = {op.bname for op in model.ops if isinstance(op, M.ConvOp) and op.has_bn and op.bname}
+    if impose_decisions:
+        # the same comparison against an oracle that takes the GPU's branch decisions (ReLU signs, pool arg-maxes, gate knees):
+        # what is left is arithmetic - the flip-induced part of the gradient error is res["gl2"] minus this
+        dec = gpu_decisions(model)
+        res["flips"] = decision_flips(dec, vals, g)
+        orb = oracle_run(g, model.get_weights(), x, targets, loss, emulate_fp16, impose=dec)
+        res["gl2_imposed"] = {}
+        for k, t in orb["W"].items():
+            if t.grad is None or k not in grads:
+                continue
+            a, b = grads[k].reshape(-1).astype(np.float64), t.grad.numpy().reshape(-1).astype(np.float64)
+            res["gl2_imposed"][k] = (float(np.linalg.norm(a - b)), float(np.linalg.norm(b)))
+        res["out_err_imposed"] = [float((o.cpu() - r.detach()).abs().max()) for o, r in zip(outs, orb["outs"])]
     if verbose:
         for n, e, mag in res["nodes"]:
             print(f"   node {n:34s} max|err| {e:.3e}  (ref max {mag:.3e})")

@@ -15,7 +15,10 @@ Asserted per config, with the oracle computed ONCE and shared by both modes:
             tolerance, independent of what this run measured: a probability that close to the threshold has no defined mask
             under any two fp32 summation orders.  Reported per config: pixels inside the band and pixels whose mask actually
             differs (gpurun_out/fullsize_report.json; a differing pixel is by the assertion inside the band).
-            Every node within 1e-3 relative, gradients to 2e-2 relative L2 per parameter tensor
+            Every node within 1e-3 relative.  Gradients per parameter tensor, two readings: with the GPU's branch decisions
+            (ReLU signs, pool arg-maxes, gate knees) imposed on the oracle - the arithmetic alone - to ARITH_L2 (5e-5; C4 2e-4)
+            relative L2; against the oracle's own decisions (a pre-activation within the forward error of zero takes either
+            branch) to GRAD_L2 (1e-2; C4 5e-2), with the differing decisions counted and held below 1e-3 of all of them
   f16 mode  fp16 operands carry a 2^-12 relative rounding per stored activation and weight; through a random-initialised
             network the relative error grows ~1.2x per ReLU layer (measured and reproduced by the rounding-emulating oracle,
             DESIGN.md section 3), so this mode is NOT the north-star mode.  Asserted: the RMS output error (F16_RMS), the
@@ -49,7 +52,10 @@ TIE_BAND = 1e-4            # decision margin below which a mask pixel is a near-
 # the RMS bound is the tight one)
 F16_TOL = {"C1": 4e-2, "C2": 3e-3, "C3": 3e-3, "C5": 3e-3, "C4": 1.5e-1}
 F16_RMS = {"C1": 5e-3, "C2": 6e-4, "C3": 6e-4, "C5": 6e-4, "C4": 2e-2}
-GRAD_L2 = {"C4": 5e-2}            # relative L2 error per parameter tensor in f32 mode (default 2e-2)
+GRAD_L2 = {"C4": 5e-2}            # relative L2 error per parameter tensor in f32 mode against the oracle's OWN branch decisions (default 2e-2)
+NOISE_FLOOR = 1e-6                # absolute summation noise allowed on any gradient tensor, relative to the model's largest gradient norm
+ZERO_FLOOR = 2e-4                 # summation noise of a mathematically zero gradient (conv bias in front of BN), relative to the model's largest gradient norm
+ARITH_L2 = 2e-4                   # ... and with the GPU's branch decisions imposed on the oracle: the arithmetic alone (measured: see fullsize_report.json)
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_report.json")
 
 
@@ -110,7 +116,7 @@ def test_baseline_config_at_its_own_size(cfg):
     deep = lambda name: any(name.startswith(p) for p in ("latent", "enc6", "enc5", "X41", "X4", "dec0", "bottleneck"))
 
     # ---- parity mode: the north star as written
-    r = U.compare_model(model32, x, targets, loss, oracle=oracle)
+    r = U.compare_model(model32, x, targets, loss, oracle=oracle, impose_decisions=True)
     worst_node = max(((e / max(1.0, m)), nm) for nm, e, m in r["nodes"])
     _record(cfg, "f32", {"out_err": r["outs"], "out_mag": r["out_mag"], "worst_node_rel": worst_node[0], "worst_node": worst_node[1],
                          "loss": r["loss"]})
@@ -128,9 +134,43 @@ def test_baseline_config_at_its_own_size(cfg):
     assert worst_node[0] < 1e-3, worst_node
     assert abs(r["loss"][0] - r["loss"][1]) < 1e-5 * max(1.0, abs(r["loss"][1]))
     gn = max(nrm for _e, nrm in r["gl2"].values())
+    # gradients, two readings (gpu_util.compare_model(impose_decisions=True)):
+    #  (1) ARITHMETIC - against the oracle run with the GPU's branch decisions imposed (every ReLU / LeakyReLU sign, max-pool
+    #      arg-max and hard-sigmoid knee taken from the device tensors): no element is "flipped" any more, what is left is the
+    #      arithmetic of the kernels - every parameter tensor within ARITH_L2 relative L2;
+    #  (2) as the oracle decides on its own: a pre-activation within the forward error (1e-6 .. 1e-5) of a branch point takes the
+    #      other branch, its gradient element is off by its whole value and spreads upstream - the looser GRAD_L2, with the
+    #      number of differing decisions counted and held below 1e-3 of all decisions.
+    # (a conv bias in front of BatchNormalization has an exactly-zero gradient - both sides hold the summation noise of N cancelling
+    # terms there: those tensors are held to ZERO_FLOOR x the model's largest gradient norm instead of relatively)
+    zero = r["zero_grad_params"]
+    # per tensor: error / (ARITH_L2 x its norm + NOISE_FLOOR x the model's largest gradient norm) must stay below 1 (the floor: a
+    # gradient that is a small difference of large sums - the gamma of a BatchNormalization feeding another one - carries
+    # summation noise that does not scale with its own size); reported beside it: the plain relative error of every
+    # well-conditioned tensor (norm above 1 % of the largest)
+    ARITH_L2 = ARITH_L2_CFG.get(cfg, ARITH_L2_DEFAULT)
+    imposed = {k: e / (ARITH_L2 * nrm + NOISE_FLOOR * gn) * ARITH_L2 for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero}
+    plain = {k: e / nrm for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero and nrm > 1e-2 * gn}
+    zero_noise = max((e / gn for k, (e, _n) in r["gl2_imposed"].items() if k in zero), default=0.0)
+    own = {k: e / (nrm + 5e-3 * gn) for k, (e, nrm) in r["gl2"].items()}
+    flips = sorted(((a / max(b, 1), nm, a, b) for nm, (a, b) in r["flips"].items()), reverse=True)
+    nflip, ndec = sum(a for a, _b in r["flips"].values()), sum(b for _a, b in r["flips"].values())
+    wk = max(imposed, key=imposed.get)
+    _record(cfg, "f32_gradients", {"rel_l2_decisions_imposed_worst_well_conditioned": max(plain.values()),
+                                   "rel_l2_decisions_imposed_worst": imposed[wk], "rel_l2_decisions_imposed_worst_tensor": wk,
+                                   "rel_l2_decisions_imposed_median": float(np.median(list(imposed.values()))),
+                                   "rel_l2_own_decisions_worst": max(own.values()), "rel_l2_own_decisions_median": float(np.median(list(own.values()))),
+                                   "flipped_decisions": nflip, "decisions": ndec, "layers_with_flips": sum(1 for f in flips if f[2]),
+                                   "most_flipped_layers": [(nm, a, b) for _f, nm, a, b in flips[:5]],
+                                   "zero_gradient_bias_noise_over_largest_norm": zero_noise,
+                                   "out_err_vs_imposed_oracle": r["out_err_imposed"]})
+    for k, v in imposed.items():
+        assert v < ARITH_L2, (cfg, k, v)
+    assert zero_noise < ZERO_FLOOR, (cfg, zero_noise)
+    assert nflip <= 1e-3 * ndec, (cfg, nflip, ndec)
     for k, (e, nrm) in r["gl2"].items():
         # (a conv bias in front of BatchNormalization has an exactly-zero gradient: both sides hold summation noise ~1e-4 x gn there)
-        assert e < GRAD_L2.get(cfg, 2e-2) * (nrm + 5e-3 * gn), (cfg, k, e, nrm)
+        assert e < GRAD_L2.get(cfg, 1e-2) * (nrm + 5e-3 * gn), (cfg, k, e, nrm)
     _record(cfg, "f32_ties", {"near_tie_pixels": ties, "mask_pixels_differing": flipped, "mask_pixels": npx, "band": TIE_BAND})
     assert flipped <= ties
     assert pads_are_zero(model32) is None
