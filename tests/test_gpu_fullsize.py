@@ -25,7 +25,9 @@ Asserted per config, with the oracle computed ONCE and shared by both modes:
             maximum (F16_TOL x max(1, |ref|)), masks identical on every pixel whose margin exceeds that maximum and on >= 99 %
             of all pixels, the 8x8 / 16x16 level (K up to 18 432) in line with the other nodes, gradient direction per tensor
   both      channel padding of every stored tensor exactly zero
-and a 3-step loss decrease at the BASELINE batch in f16 mode (test_three_steps_reduce_the_loss_at_the_baseline_batch)."""
+and a 3-step loss decrease at the BASELINE batch of every configuration in both modes
+(test_three_steps_reduce_the_loss_at_the_baseline_batch); the headline configuration's forward AND backward pass at the benched
+batch of 16 against the oracle (test_c3_forward_and_backward_at_the_benched_batch_match_the_oracle)."""
 import json
 import os
 
@@ -52,10 +54,17 @@ TIE_BAND = 1e-4            # decision margin below which a mask pixel is a near-
 # the RMS bound is the tight one)
 F16_TOL = {"C1": 4e-2, "C2": 3e-3, "C3": 3e-3, "C5": 3e-3, "C4": 1.5e-1}
 F16_RMS = {"C1": 5e-3, "C2": 6e-4, "C3": 6e-4, "C5": 6e-4, "C4": 2e-2}
-GRAD_L2 = {"C4": 5e-2}            # relative L2 error per parameter tensor in f32 mode against the oracle's OWN branch decisions (default 2e-2)
+# relative L2 error per parameter tensor in f32 mode, two readings (test_baseline_config_at_its_own_size):
+# ARITH_L2 - with the GPU's branch decisions imposed on the oracle: the arithmetic alone.  Measured on MI355X (fullsize_report.json,
+#            `f32_gradients`): worst well-conditioned tensor C1 8.3e-6, C2 7.2e-6, C3 3.3e-6, C5 6.8e-6; C4 (about 100 conv layers of
+#            5 .. 512 channels, BatchNormalization on BatchNormalization) 1.1e-4 - the bounds are ~6x / ~2x those figures;
+# GRAD_L2  - against the oracle's OWN decisions: 1 / 31 / 112 / 665 / 37 of 2.4 M .. 325 M decisions differ (C1 .. C5), each flipped
+#            element carries its whole value upstream: measured 6.5e-4 / 3.0e-3 / 1.1e-3 / 1.8e-2 / 3.0e-3.
+ARITH_L2_CFG = {"C4": 2e-4}
+ARITH_L2_DEFAULT = 5e-5
+GRAD_L2 = {"C4": 5e-2}            # (default 1e-2)
 NOISE_FLOOR = 1e-6                # absolute summation noise allowed on any gradient tensor, relative to the model's largest gradient norm
 ZERO_FLOOR = 2e-4                 # summation noise of a mathematically zero gradient (conv bias in front of BN), relative to the model's largest gradient norm
-ARITH_L2 = 2e-4                   # ... and with the GPU's branch decisions imposed on the oracle: the arithmetic alone (measured: see fullsize_report.json)
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_report.json")
 
 
@@ -215,29 +224,38 @@ def test_baseline_config_at_its_own_size(cfg):
     assert pads_are_zero(model16) is None
 
 
-def test_c3_forward_at_the_benched_batch_matches_the_oracle():
+def test_c3_forward_and_backward_at_the_benched_batch_match_the_oracle():
     """The headline configuration at the batch bench.py times (16): training-mode forward (BatchNormalization statistics over
-    all 16 images - not the 2 of the per-config test above) in the parity mode against the oracle's forward pass."""
+    all 16 images - not the 2 of the per-config test above), the summed MSE loss over the six outputs and the backward pass in the
+    parity mode against the oracle at the same batch (about 20 s of host time per oracle pass; two passes: its own branch
+    decisions and the GPU's imposed).  Outputs inside the tie band (a tenth of the 1e-3 tolerance), masks equal outside it, every
+    parameter gradient to ARITH_L2 with the decisions imposed and to GRAD_L2 against the oracle's own."""
     torch.manual_seed(21)
-    model, x, _targets, _loss = CONFIGS["C3"](16)
+    model, x, targets, loss = CONFIGS["C3"](16)
     model.build(16, dtype="f32")
-    w = {k: torch.from_numpy(np.array(v, np.float32)) for k, v in model.get_weights().items()}
-    from ir_interp import run_graph
-    with torch.no_grad():
-        ref = run_graph(model.graph, x, w, training=True)
-    outs = model.forward(x, training=True)
-    torch.cuda.synchronize()
-    errs, flips, ties = [], 0, 0
-    for o, r in zip(outs, ref):
-        oc = o.cpu()
-        errs.append(float((oc - r).abs().max()))
-        flips += int((masks(oc) != masks(r)).sum())
-        ties += int((margin(r) <= TIE_BAND).sum())
-    _record("C3", "f32_batch16_forward", {"out_err": errs, "mask_pixels_differing": flips, "near_tie_pixels": ties})
-    assert max(errs) < TIE_BAND < NORTH_STAR_TOL
-    o0, r0 = outs[0].cpu(), ref[0]
-    near = margin(r0) <= TIE_BAND
-    assert not bool((masks(o0) != masks(r0))[~near].any())
+    r = U.compare_model(model, x, targets, loss, impose_decisions=True)
+    flips = ties = 0
+    for got, ref in r["out_tensors"]:
+        flips += int((masks(got) != masks(ref)).sum())
+        ties += int((margin(ref) <= TIE_BAND).sum())
+    gn = max(nrm for _e, nrm in r["gl2"].values())
+    zero = r["zero_grad_params"]
+    imposed = {k: e / (ARITH_L2_DEFAULT * nrm + NOISE_FLOOR * gn) * ARITH_L2_DEFAULT for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero}
+    plain = {k: e / nrm for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero and nrm > 1e-2 * gn}
+    own = {k: e / (nrm + 5e-3 * gn) for k, (e, nrm) in r["gl2"].items()}
+    nflip, ndec = sum(a for a, _b in r["flips"].values()), sum(b for _a, b in r["flips"].values())
+    _record("C3", "f32_batch16_forward_backward", {"out_err": r["outs"], "mask_pixels_differing": flips, "near_tie_pixels": ties, "loss": r["loss"],
+                                                   "grad_rel_l2_decisions_imposed_worst_well_conditioned": max(plain.values()),
+                                                   "grad_rel_l2_decisions_imposed_worst": max(imposed.values()),
+                                                   "grad_rel_l2_own_decisions_worst": max(own.values()),
+                                                   "flipped_decisions": nflip, "decisions": ndec})
+    assert max(r["outs"]) < TIE_BAND < NORTH_STAR_TOL
+    got0, ref0 = r["out_tensors"][0]
+    assert not bool((masks(got0) != masks(ref0))[margin(ref0) > TIE_BAND].any())
+    assert abs(r["loss"][0] - r["loss"][1]) < 1e-5 * max(1.0, abs(r["loss"][1]))
+    assert max(imposed.values()) < ARITH_L2_DEFAULT, max(imposed, key=imposed.get)
+    assert nflip <= 1e-3 * ndec
+    assert max(own.values()) < GRAD_L2.get("C3", 1e-2), max(own, key=own.get)
 
 
 def test_load_keras_model_walks_the_layer_graph_into_the_engine():
@@ -279,7 +297,8 @@ def test_load_keras_model_walks_the_layer_graph_into_the_engine():
     assert all(np.array_equal(back[k], now[k]) for k in now) and any(not np.array_equal(now[k], fake.planted[k]) for k in now)
 
 
-@pytest.mark.parametrize("cfg,dtype", [("C1", "f16"), ("C2", "f16"), ("C3", "f16"), ("C5", "f16"), ("C4", "f16"), ("C3", "f32"), ("C4", "f32")])
+@pytest.mark.parametrize("cfg,dtype", [("C1", "f16"), ("C2", "f16"), ("C3", "f16"), ("C5", "f16"), ("C4", "f16"),
+                                       ("C1", "f32"), ("C2", "f32"), ("C3", "f32"), ("C4", "f32"), ("C5", "f32")])
 def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg, dtype):
     torch.manual_seed(5)
     n = BASELINE_BATCH[cfg]
