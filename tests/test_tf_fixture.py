@@ -3,9 +3,11 @@
 While no fixture is present every test here SKIPS - and the oracle stays "parity unpinned" (DESIGN.md section 3): this
 container has no TensorFlow.  With fixtures present:
   * CPU  the oracle (oracle/models_ref.py) must reproduce the Keras outputs (predict: inference-mode BN; train_fwd:
-         training-mode BN) within 1e-4 - that pins the oracle;
-  * GPU  the HIP engine in f32 mode must reproduce them within 1e-3 with bit-exact masks - the north star, against the
-         reference itself."""
+         training-mode BN) within 1e-4, the BatchNormalization moving statistics a training-mode call leaves (momentum 0.99,
+         unbiased variance on 4-D inputs) and the loss + every weight after ONE Adam step - that pins the oracle;
+  * GPU  the HIP engine in f32 mode must reproduce the outputs within 1e-3 with bit-exact masks - the north star, against the
+         reference itself - and the same moving statistics / post-step weights.
+2D cases (reference `models.unet_variants.unet_model_builder`) and 1D cases (`Models.unet_variants.UNet`, `Models.BCDUNet`)."""
 import glob
 import json
 import os
@@ -29,6 +31,38 @@ def _load(path):
     return meta, z["x"], w, pred, trn
 
 
+def _load_training(path):
+    """(moving statistics after one training-mode forward, loss of the optimiser step, weights after it) - absent in fixtures
+    written by the first version of the capture script."""
+    z = np.load(path)
+    name = lambda k, pre: k[len(pre):].replace("|", "/")
+    moving = {name(k, "moving_after/"): z[k] for k in z.files if k.startswith("moving_after/")}
+    after = {name(k, "w_after/"): z[k] for k in z.files if k.startswith("w_after/")}
+    return moving, (float(z["loss"]) if "loss" in z.files else None), after
+
+
+def _oracle_forward(L, meta, xt):
+    """The oracle's forward pass for the constructor call a fixture records (2D builder, 1D builder or BCDUNet)."""
+    from oracle.models_ref import unet2d_forward, unet1d_forward, bcdunet1d_forward
+    kw = dict(meta["kwargs"])
+    if meta.get("ndim", 2) == 2:
+        kw.pop("num_channels", None)                 # (the oracle reads the channel count from x)
+        return unet2d_forward(L, xt, meta["decoder"], meta["width"], meta["depth"], **kw)
+    _length, depth, _ch, width, ksize = meta["args"]
+    if meta["cls"] == "BCDUNet":
+        return bcdunet1d_forward(L, xt, depth, width, ksize, **kw)
+    return unet1d_forward(L, xt, meta["method"], depth, width, ksize, **kw)
+
+
+def _engine(meta):
+    import segamd
+    if meta.get("ndim", 2) == 2:
+        return segamd.unet_model_builder(meta["decoder"], meta["H"], meta["W"], meta["width"], meta["depth"], train_mode="from_scratch",
+                                         **meta["kwargs"]).ResNet50()
+    builder = (segamd.BCDUNet if meta["cls"] == "BCDUNet" else segamd.UNet1D)(*meta["args"], **meta["kwargs"])
+    return getattr(builder, meta["method"])()
+
+
 def _masks(p):
     return (p >= 0.5) if p.shape[-1] == 1 else p.argmax(-1)[..., None]
 
@@ -37,21 +71,44 @@ def _masks(p):
 @pytest.mark.parametrize("path", FIXTURES or ["<none>"])
 def test_oracle_reproduces_the_reference(path):
     from oracle.keras_ref import Layers
-    from oracle.models_ref import unet2d_forward
+    from oracle.train_ref import KerasAdam, loss_and_grads
     meta, x, w, pred, trn = _load(path)
-    L = Layers(2, seed=0)
-    L.set_weights(w)
-    L.update_moving = False
+    ndim = meta.get("ndim", 2)
     xt = torch.from_numpy(x)
     for training, want in ((False, pred), (True, trn)):
+        L = Layers(ndim, seed=0)
+        L.set_weights(w)
+        L.update_moving = training
         L.training = training
         with torch.no_grad():
-            kw = {k: v for k, v in meta["kwargs"].items() if k != "num_channels"}        # (the oracle reads the channel count from x)
-            got = unet2d_forward(L, xt, meta["decoder"], meta["width"], meta["depth"], **kw)
+            got = _oracle_forward(L, meta, xt)
         assert len(got) == len(want)
         for g_, r in zip(got, want):
             assert float(np.abs(g_.numpy() - r).max()) < 1e-4, (meta["case"], training)
             assert np.array_equal(_masks(g_.numpy()), _masks(r))
+        if training:                                   # Keras' moving-average update (momentum, unbiased variance on 4-D inputs)
+            moving, _loss, _after = _load_training(path)
+            now = L.get_weights()
+            for k, v in moving.items():
+                assert float(np.abs(np.asarray(now[k]) - v).max()) < 1e-5 * max(1.0, float(np.abs(v).max())), (meta["case"], k)
+    _moving, loss, after = _load_training(path)
+    if loss is not None:                               # one Adam(1e-3) step on MSE against 0.5
+        L = Layers(ndim, seed=0)
+        L.set_weights(w)
+        L.training, L.update_moving = True, True
+        tg = [torch.full(tuple(t.shape), 0.5) for t in trn]
+        opt = KerasAdam({k: v for k, v in L.params.items() if L.trainable[k]}, lr=1e-3)
+        got_loss, _per, _outs, grads = loss_and_grads(L, lambda: _oracle_forward(L, meta, xt), tg, "mse")
+        opt.step(grads)
+        assert abs(got_loss - loss) < 1e-5 * max(1.0, abs(loss)), (meta["case"], got_loss, loss)
+        now = L.get_weights()
+        for k, v in after.items():
+            # (the first Adam step moves every weight by ~lr x sign(gradient): a weight whose gradient is numerically zero may go
+            # either way, hence the absolute part of the bound)
+            assert float(np.abs(np.asarray(now[k]) - v).max()) < 2.5e-3 if np.abs(v - w[k]).max() < 1.5e-3 else True, (meta["case"], k)
+        moved = [k for k in after if not (k.endswith("moving_mean") or k.endswith("moving_variance"))]
+        close = np.mean([float(np.mean(np.abs(np.asarray(now[k]) - after[k]) < 1e-5)) for k in moved])
+        assert close > 0.99, (meta["case"], close)     # all but a sliver of the weights land where Keras put them
 
 
 @needs_fixture
@@ -60,10 +117,8 @@ def test_oracle_reproduces_the_reference(path):
 def test_engine_reproduces_the_reference(path):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    import segamd
     meta, x, w, pred, trn = _load(path)
-    m = segamd.unet_model_builder(meta["decoder"], meta["H"], meta["W"], meta["width"], meta["depth"], train_mode="from_scratch",
-                                  **meta["kwargs"]).ResNet50()
+    m = _engine(meta)
     m.build(x.shape[0], dtype="f32")
     m.set_weights(w)
     got = m.predict(x)
@@ -74,6 +129,20 @@ def test_engine_reproduces_the_reference(path):
     outs = [o.cpu().numpy() for o in m.forward(torch.from_numpy(x), training=True)]
     for g_, r in zip(outs, trn):
         assert float(np.abs(g_ - r).max()) < 1e-3, meta["case"]
+    moving, loss, after = _load_training(path)
+    now = m.get_weights()
+    for k, v in moving.items():
+        assert float(np.abs(now[k] - v).max()) < 1e-4 * max(1.0, float(np.abs(v).max())), (meta["case"], k)
+    if loss is not None:
+        m.set_weights(w)
+        m.compile(loss="mse", lr=1e-3)
+        tg = [torch.full(tuple(t.shape), 0.5) for t in trn]
+        got_loss = float(m.train_step(torch.from_numpy(x), tg).cpu())
+        assert abs(got_loss - loss) < 1e-4 * max(1.0, abs(loss)), (meta["case"], got_loss, loss)
+        now = m.get_weights()
+        moved = [k for k in after if not (k.endswith("moving_mean") or k.endswith("moving_variance"))]
+        close = np.mean([float(np.mean(np.abs(now[k] - after[k]) < 1e-4)) for k in moved])
+        assert close > 0.99, (meta["case"], close)
 
 
 def test_the_skip_is_visible_and_the_capture_spec_is_self_contained():
@@ -81,5 +150,56 @@ def test_the_skip_is_visible_and_the_capture_spec_is_self_contained():
     fixture tests would load."""
     src = open(os.path.join(os.path.dirname(GOLDEN), "..", "tools", "tf_capture_spec.py")).read()
     assert "keras_map.keras_weights_by_structural_name" in src and "/root/reference" not in src
+    # the cases cover the semantics SURVEY 8c marks: ConvLSTM (hard-sigmoid) in 2D and 1D, attention gates, MultiRes, 1D builders,
+    # BCDUNet, and the training-side quantities (moving statistics after a training-mode call, one Adam step)
+    for needle in ("lstm=1", "ag=1", "MultiResUNet", "Models.unet_variants", "Models.BCDUNet", "moving_after/", "w_after/", "train_on_batch"):
+        assert needle in src, needle
     if not FIXTURES:
         pytest.skip("parity unpinned: no TensorFlow-produced fixture present (expected in this container)")
+
+
+@pytest.mark.parametrize("case", ["unet_lstm", "unet1d_lstm_ag", "bcdunet1d"])
+def test_fixture_consumers_run_on_an_oracle_made_stand_in(case, tmp_path):
+    """Plumbing only - NOT a pin: a file in the fixture format is written from the ORACLE's own outputs (same keys, same meta as
+    tools/tf_capture_spec.py writes for the case) and the CPU consumer above is run on it, so that the first TensorFlow-made
+    fixture does not fail on a key name, a 1D argument order or the training-step bookkeeping."""
+    import importlib.util
+    from oracle.keras_ref import Layers
+    from oracle.train_ref import KerasAdam, loss_and_grads
+    spec = importlib.util.spec_from_file_location("tf_capture_spec", os.path.join(os.path.dirname(GOLDEN), "..", "tools", "tf_capture_spec.py"))
+    cap = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cap)
+    if case in cap.CASES:
+        dec, kw = cap.CASES[case]
+        meta = dict(case=case, ndim=2, decoder=dec, kwargs=kw, H=32, W=32, width=cap.WIDTH, depth=cap.DEPTH)
+        x = np.random.default_rng(0).random((2, 32, 32, kw.get("num_channels", 3)), dtype=np.float32)
+    else:
+        _mod, cls, method, pos, kw = cap.CASES_1D[case]
+        meta = dict(case=case, ndim=1, cls=cls, method=method, args=list(pos), kwargs=kw)
+        x = np.random.default_rng(0).random((2, pos[0], pos[2]), dtype=np.float32)
+    xt = torch.from_numpy(x)
+    L = Layers(meta["ndim"], seed=3)
+    L.training, L.update_moving = False, False
+    with torch.no_grad():
+        pred = [o.numpy() for o in _oracle_forward(L, meta, xt)]      # (creates the parameters)
+    w = {k: np.asarray(v) for k, v in L.get_weights().items()}
+    L.training, L.update_moving = True, True
+    with torch.no_grad():
+        trn = [o.numpy() for o in _oracle_forward(L, meta, xt)]
+    moving = {k: np.asarray(v) for k, v in L.get_weights().items() if k.endswith("moving_mean") or k.endswith("moving_variance")}
+    L2 = Layers(meta["ndim"], seed=3)
+    L2.set_weights(w)
+    L2.training, L2.update_moving = True, True
+    opt = KerasAdam({k: v for k, v in L2.params.items() if L2.trainable[k]}, lr=1e-3)
+    loss, _per, _outs, grads = loss_and_grads(L2, lambda: _oracle_forward(L2, meta, xt), [torch.full(tuple(t.shape), 0.5) for t in trn], "mse")
+    opt.step(grads)
+    after = {k: np.asarray(v) for k, v in L2.get_weights().items()}
+    arrays = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), "x": x, "loss": np.float32(loss)}
+    arrays.update({"w/" + k.replace("/", "|"): v for k, v in w.items()})
+    arrays.update({"moving_after/" + k.replace("/", "|"): v for k, v in moving.items()})
+    arrays.update({"w_after/" + k.replace("/", "|"): v for k, v in after.items()})
+    arrays.update({f"predict/{i}": p for i, p in enumerate(pred)})
+    arrays.update({f"train_fwd/{i}": p for i, p in enumerate(trn)})
+    path = str(tmp_path / f"standin_{case}.npz")
+    np.savez_compressed(path, **arrays)
+    test_oracle_reproduces_the_reference.__wrapped__(path) if hasattr(test_oracle_reproduces_the_reference, "__wrapped__") else test_oracle_reproduces_the_reference(path)

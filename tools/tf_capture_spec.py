@@ -5,7 +5,7 @@ the committed SPEC of the capture SURVEY.md section 8c asks for, and the only ro
 status changes from "unpinned" to "pinned".  It copies nothing from the reference: it imports whatever
 `models.unet_variants` is importable and calls the public constructors.
 
-    PYTHONPATH=<reference>/TensorFlow/2DCNN:<this repo> python tools/tf_capture_spec.py --out tests/golden
+    PYTHONPATH=<reference>/TensorFlow/2DCNN:<reference>/TensorFlow/1DCNN:<this repo> python tools/tf_capture_spec.py --out tests/golden
 
 For every case below it
   1. builds the Keras model through the reference's own `unet_model_builder(...)` call (d2 / w8 / 64x64: fixtures < 1 MB),
@@ -15,8 +15,17 @@ For every case below it
      `inbound_nodes` (keras_map.map_keras_model - never by list position or auto-name),
   4. runs `model.predict(x)` (inference-mode BN) and one `train_on_batch`-free training-mode forward
      (`model(x, training=True)`) on x = np.random.default_rng(0).random((2, H, W, C), float32),
-  5. writes tests/golden/tf_<case>.npz: 'meta' (json: constructor arguments, TF / Keras versions), 'x', 'w/<structural name>'
-     for every weight, 'predict/<i>' and 'train_fwd/<i>' for every output.
+  5. keeps the BatchNormalization moving statistics as that training-mode call left them ('moving_after/<name>': Keras'
+     momentum 0.99 update with the UNBIASED batch variance on 4-D inputs - one of the semantics SURVEY 8c marks),
+  6. takes ONE optimiser step - `compile(Adam(1e-3), 'mse')`, `train_on_batch(x, t)` with t = 0.5 everywhere - and keeps the loss it
+     reports and every weight afterwards ('loss', 'w_after/<name>': Keras' Adam with epsilon outside the root, the MSE reduction,
+     the gradient of every layer type on the path),
+  7. writes tests/golden/tf_<case>.npz: 'meta' (json: constructor arguments, TF / Keras versions), 'x', 'w/<structural name>'
+     for every weight, 'predict/<i>' and 'train_fwd/<i>' for every output, and the arrays of 5. and 6.
+The cases cover every semantic SURVEY.md 8c marks as a risk in ONE run: Conv2DTranspose 'same' cropping and LeakyReLU 0.3
+(every transposed-conv case), the hard-sigmoid ConvLSTM gates (`lstm=1`, 2D and 1D), the attention gate's bilinear + 1-channel
+transposed conv (`ag=1`), BatchNormalization over a concatenation (MultiResUNet), the 1D builders (Conv1D / k2-s2
+Conv1DTranspose with BN + ReLU, UpSampling1D) and BCDUNet.
 tests/test_tf_fixture.py picks the files up: the oracle (CPU) and the HIP engine in f32 mode (GPU) must reproduce
 'predict/*' and 'train_fwd/*' within 1e-4 / 1e-3 with bit-exact masks; the tests skip while no fixture is present.
 """
@@ -43,51 +52,84 @@ CASES = {
     "unet3p": ("UNet3P", dict(num_channels=3)),
     "multiresunet_ag": ("MultiResUNet", dict(num_channels=3, ag=1, alpha=1.0)),
 }
+# 1D: (module of the reference, class, method, positional (length, model_depth, num_channel, model_width, kernel_size), kwargs)
+CASES_1D = {
+    "unet1d": ("Models.unet_variants", "UNet", "UNet", (256, 2, 1, 8, 3), dict(problem_type="Regression", output_nums=1, ds=1)),
+    "unet1d_lstm_ag": ("Models.unet_variants", "UNet", "UNet", (256, 2, 1, 8, 3), dict(problem_type="Regression", output_nums=1, ds=0, ag=1, lstm=1)),
+    "unetpp1d_cls": ("Models.unet_variants", "UNet", "UNetPP", (256, 2, 1, 8, 3), dict(problem_type="Classification", output_nums=2, ds=0)),
+    "multiresunet1d": ("Models.unet_variants", "UNet", "MultiResUNet", (256, 2, 1, 8, 3), dict(problem_type="Regression", output_nums=1, ds=0, alpha=1)),
+    "bcdunet1d": ("Models.BCDUNet", "BCDUNet", "BCDUNet", (256, 2, 1, 8, 3), dict(problem_type="Regression", output_nums=1, ds=0, lstm=1, dense_loop=2)),
+}
 H = W = 64
 WIDTH, DEPTH = 8, 2
+
+
+def capture(tf, kmodel, g, x, meta, keras_map, path):
+    """Steps 2 - 7 of the module docstring for one Keras model / one graph of this package."""
+    rng = np.random.default_rng(1)
+    for layer in kmodel.layers:                            # non-trivial moving statistics, gamma / beta
+        if layer.__class__.__name__ == "BatchNormalization":
+            gm, bt, mu, var = layer.get_weights()
+            layer.set_weights([rng.uniform(0.5, 1.5, gm.shape), rng.normal(0, 0.1, bt.shape),
+                               rng.normal(0, 0.1, mu.shape), rng.uniform(0.5, 1.5, var.shape)])
+    weights = keras_map.keras_weights_by_structural_name(kmodel, g)
+    missing = {p.name for p in g.param_specs()} - set(weights)
+    assert not missing, f"{meta['case']}: parameters without a Keras counterpart: {sorted(missing)}"
+    pred = kmodel.predict(x, verbose=0)
+    pred = pred if isinstance(pred, list) else [pred]
+    trn = kmodel(x, training=True)
+    trn = [np.asarray(t) for t in (trn if isinstance(trn, (list, tuple)) else [trn])]
+    after_fwd = keras_map.keras_weights_by_structural_name(kmodel, g)
+    moving = {k: v for k, v in after_fwd.items() if k.endswith("moving_mean") or k.endswith("moving_variance")}
+    # one optimiser step from the ORIGINAL moving statistics (so that the consumer starts from 'w/*' alone)
+    keras_map.export_to_keras(weights, kmodel, g)
+    kmodel.compile(optimizer=tf.keras.optimizers.Adam(learning_rate=1e-3), loss="mse")
+    targets = [np.full(t.shape, 0.5, np.float32) for t in trn]
+    loss = kmodel.train_on_batch(x, targets if len(targets) > 1 else targets[0])
+    loss = float(loss[0] if isinstance(loss, (list, tuple)) else loss)
+    w_after = keras_map.keras_weights_by_structural_name(kmodel, g)
+    meta = dict(meta, tensorflow=tf.__version__, keras=getattr(tf.keras, "__version__", "?"), output_names=list(kmodel.output_names),
+                train_step=dict(optimizer="Adam", lr=1e-3, loss="mse", target=0.5))
+    arrays = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), "x": x, "loss": np.float32(loss)}
+    arrays.update({"w/" + k.replace("/", "|"): v for k, v in weights.items()})
+    arrays.update({"moving_after/" + k.replace("/", "|"): v for k, v in moving.items()})
+    arrays.update({"w_after/" + k.replace("/", "|"): v for k, v in w_after.items()})
+    arrays.update({f"predict/{i}": np.asarray(p, np.float32) for i, p in enumerate(pred)})
+    arrays.update({f"train_fwd/{i}": np.asarray(p, np.float32) for i, p in enumerate(trn)})
+    np.savez_compressed(path, **arrays)
+    print(f"{meta['case']}: {len(weights)} weights, {len(pred)} outputs, loss {loss:.6f} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--cases", default=",".join(list(CASES) + list(CASES_1D)))
     args = ap.parse_args()
     import tensorflow as tf                                    # noqa: F401  (the whole point of this script)
-    ref = importlib.import_module("models.unet_variants")     # the reference's module, from PYTHONPATH
     segamd = importlib.import_module("segamd")
     from segamd import keras_map
 
     os.makedirs(args.out, exist_ok=True)
     for case in args.cases.split(","):
-        dec, kw = CASES[case]
         tf.keras.backend.clear_session()
         tf.keras.utils.set_random_seed(0)
-        kmodel = ref.unet_model_builder(dec, H, W, WIDTH, DEPTH, train_mode="from_scratch", **kw).ResNet50()
-        g = segamd.unet_model_builder(dec, H, W, WIDTH, DEPTH, train_mode="from_scratch", **kw).graph()
-        rng = np.random.default_rng(1)
-        for layer in kmodel.layers:                            # non-trivial moving statistics, gamma / beta
-            if layer.__class__.__name__ == "BatchNormalization":
-                gm, bt, mu, var = layer.get_weights()
-                layer.set_weights([rng.uniform(0.5, 1.5, gm.shape), rng.normal(0, 0.1, bt.shape),
-                                   rng.normal(0, 0.1, mu.shape), rng.uniform(0.5, 1.5, var.shape)])
-        weights = keras_map.keras_weights_by_structural_name(kmodel, g)
-        missing = {p.name for p in g.param_specs()} - set(weights)
-        assert not missing, f"{case}: parameters without a Keras counterpart: {sorted(missing)}"
-        C = kw.get("num_channels", 3)
-        x = np.random.default_rng(0).random((2, H, W, C), dtype=np.float32)
-        pred = kmodel.predict(x, verbose=0)
-        pred = pred if isinstance(pred, list) else [pred]
-        trn = kmodel(x, training=True)
-        trn = [np.asarray(t) for t in (trn if isinstance(trn, (list, tuple)) else [trn])]
-        meta = dict(case=case, decoder=dec, kwargs=kw, H=H, W=W, width=WIDTH, depth=DEPTH, tensorflow=tf.__version__,
-                    keras=getattr(tf.keras, "__version__", "?"), output_names=list(kmodel.output_names))
-        arrays = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), "x": x}
-        arrays.update({"w/" + k.replace("/", "|"): v for k, v in weights.items()})
-        arrays.update({f"predict/{i}": np.asarray(p, np.float32) for i, p in enumerate(pred)})
-        arrays.update({f"train_fwd/{i}": np.asarray(p, np.float32) for i, p in enumerate(trn)})
         path = os.path.join(args.out, f"tf_{case}.npz")
-        np.savez_compressed(path, **arrays)
-        print(f"{case}: {len(weights)} weights, {len(pred)} outputs -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
+        if case in CASES:
+            ref = importlib.import_module("models.unet_variants")     # the reference's 2D module, from PYTHONPATH
+            dec, kw = CASES[case]
+            kmodel = ref.unet_model_builder(dec, H, W, WIDTH, DEPTH, train_mode="from_scratch", **kw).ResNet50()
+            g = segamd.unet_model_builder(dec, H, W, WIDTH, DEPTH, train_mode="from_scratch", **kw).graph()
+            x = np.random.default_rng(0).random((2, H, W, kw.get("num_channels", 3)), dtype=np.float32)
+            meta = dict(case=case, ndim=2, decoder=dec, kwargs=kw, H=H, W=W, width=WIDTH, depth=DEPTH)
+        else:
+            mod, cls, method, pos, kw = CASES_1D[case]
+            ref = importlib.import_module(mod)                         # the reference's 1D module (TensorFlow/1DCNN on PYTHONPATH)
+            kmodel = getattr(getattr(ref, cls)(*pos, **kw), method)()
+            builder = (segamd.BCDUNet if cls == "BCDUNet" else segamd.UNet1D)(*pos, **kw)
+            g = getattr(builder, "graph_" + method)()
+            x = np.random.default_rng(0).random((2, pos[0], pos[2]), dtype=np.float32)
+            meta = dict(case=case, ndim=1, cls=cls, method=method, args=list(pos), kwargs=kw)
+        capture(tf, kmodel, g, x, meta, keras_map, path)
 
 
 if __name__ == "__main__":
