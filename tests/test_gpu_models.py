@@ -93,6 +93,12 @@ CASES = {
 }
 
 
+# f16 mode, gradient of every well-conditioned parameter tensor against the ROUNDING-EMULATING oracle with the GPU's branch decisions
+# imposed: measured 1.0e-3 .. 4.0e-3 (fp16 storage of the activation gradients), 1.0e-2 .. 2.0e-2 on the MultiRes / BCD-1D stacks
+F16_KERNEL_GRAD_L2 = 1.5e-2
+F16_KERNEL_GRAD_L2_FRAGILE = 6e-2
+
+
 def masks(p):
     return (p >= 0.5) if p.shape[-1] == 1 else p.argmax(-1, keepdim=True)
 
@@ -110,7 +116,7 @@ def test_model_forward_backward_parity(name):
     model, x, targets, loss = CASES[name]()
     model.build(x.shape[0], dtype="f16")
     r32 = U.compare_model(model, x, targets, loss, emulate_fp16=False)
-    r16 = U.compare_model(model, x, targets, loss, emulate_fp16=True)
+    r16 = U.compare_model(model, x, targets, loss, emulate_fp16=True, impose_decisions=True)
     # ---- forward, vs the fp32 oracle
     tol = OUT_TOL_CASE.get(name, OUT_TOL)
     for e, m in zip(r32["outs"], r32["out_mag"]):
@@ -128,6 +134,12 @@ def test_model_forward_backward_parity(name):
         # (the fragile MultiRes cases: two equivalent lowerings of the same graph - BN tails fused or not, SEG_FUSE_BN_TAILS - differ
         # by this much between themselves in f16 mode: relative error 0.60 against 0.32 on enc1/mrb/c3/bn/beta, tools/dbg_f32_case.py)
         assert (0.90 if name not in OUT_TOL_CASE else 0.60) < ratio < (1.10 if name not in OUT_TOL_CASE else 1.60), (k, ratio)
+    # ---- gradients vs the ROUNDING-EMULATING oracle with the GPU's branch decisions imposed (kernel logic of the backward pass: what
+    # the wide band above cannot see in the fragile cases - a missing ReLU mask or c2 term in a fused tail moves these by O(1))
+    gn = max(n for _e, n in r16["gl2_imposed"].values())
+    worst = max(((e / n, k) for k, (e, n) in r16["gl2_imposed"].items() if n > 1e-2 * gn and k not in r16["zero_grad_params"]), default=(0.0, ""))
+    print(f"[{name}] f16 gradient rel-L2 vs the rounding-emulating oracle, decisions imposed: worst {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < (F16_KERNEL_GRAD_L2_FRAGILE if (name in OUT_TOL_CASE or name.startswith('bcdunet1d')) else F16_KERNEL_GRAD_L2), worst
 
 
 @pytest.mark.parametrize("name", ["unet_softmax_cce", "unet_w64_bce", "unet1d_softmax_cce"])
