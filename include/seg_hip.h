@@ -194,6 +194,15 @@ int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32
                      int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
                      const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
                      seg_stream_t stream);
+/* the same with a ONE-CHANNEL 1x1 OUTPUT HEAD on the tensor riding along (a deep-supervision level of UNet++, unet_variants.py:300-302,
+ * or the model output, :1106): head->y[pix] = act_h(sum_c y[pix][c] * head->w[c] + head->b[0]) comes out of this pass - the lanes of a
+ * pixel reduce their partial dot products - instead of a seg_head_fwd launch that reads the tensor again (w / b / act / y per head k < n).
+ * C / 8 a power of two <= 64.                                                                                                      */
+typedef struct { int32_t n; const float* w[2]; const float* b[2]; int32_t act[2]; float* y[2]; } seg_head_fwd_desc;   /* n = 1 | 2 heads (UNet++'s X0d feeds level d AND the output) */
+int seg_bn_act_apply_head(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff,
+                          int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
+                          const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
+                          const seg_head_fwd_desc* head, seg_stream_t stream);
 /* backward, pass 1: g = dy * act'(y), y = x*scale+shift; partial[part][0][c] = sum g, [1][c] = sum g*xhat       */
 int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
                           int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
@@ -204,6 +213,20 @@ int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const 
 int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma,
                         float* dbeta, float gscale, const float* gscale_ptr, float* c1, float* c2,
                         seg_stream_t stream);
+/* passes 1 and 2 with the data gradient of such heads INJECTED: the gradient read is dy[pix][c] + gs * sum_k dpre_k[pix] * inj->w[k][c]
+ * (dpre_k = inj->dy[k] * act_h'(inj->y[k]) of head k, gs = *inj->gs_ptr or 1) - the head's seg_head_bwd does not write its dx into the
+ * gradient tensor first (a write of the whole tensor and a read-modify-write by the data gradient that follows).  dy == NULL:
+ * the head is the tensor's only consumer.                                                                                       */
+typedef struct { int32_t n; const float* dy[2]; const float* y[2]; const float* w[2]; int32_t act[2]; const float* gs_ptr; } seg_head_inject;
+int seg_bn_act_bwd_reduce_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                              int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, int32_t act, float alpha, float* partial,
+                              int32_t nparts, const seg_head_inject* inj, seg_stream_t stream);
+int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                             int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate,
+                             const seg_head_inject* inj, seg_stream_t stream);
 /* pass 2: dx = scale * (g - c1 - xhat*c2)   (training)   or   dx = scale * g   (c1 == NULL: inference BN)     */
 int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
                          int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C,
@@ -455,6 +478,19 @@ int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, i
                          int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
                          const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
                          seg_stream_t stream);
+int seg_bn_act_apply_head_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff,
+                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale,
+                              const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw,
+                              const seg_head_fwd_desc* head, seg_stream_t stream);
+int seg_bn_act_bwd_reduce_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                                  int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, int32_t act, float alpha, float* partial,
+                                  int32_t nparts, const seg_head_inject* inj, seg_stream_t stream);
+int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
+                                 int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd,
+                                 const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate,
+                                 const seg_head_inject* inj, seg_stream_t stream);
 int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
                               int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
                               const float* mean, const float* invstd, int32_t act, float alpha, float* partial,

@@ -89,6 +89,91 @@ def test_bn_statistics_apply_and_backward(Cc, act, pool):
     assert rel(dg[:Cc].cpu(), gr.grad) < 1e-5 and rel(db[:Cc].cpu(), br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("f32", [True, False])
+@pytest.mark.parametrize("Cc,pool,nheads", [(64, None, 1), (64, (2, 2), 2), (16, None, 2), (24, None, 0)])
+def test_output_heads_ride_on_the_block_they_read(Cc, pool, nheads, f32):
+    """seg_bn_act_apply_head: the one-channel heads' forward (dot product over the channels, bias, activation) out of the
+    bn_act_apply pass (plain and pooling form); seg_bn_act_bwd_reduce_inj / _apply_inj: their data gradient gs * dpre * w added on
+    the fly to the gradient the BatchNormalization-backward passes read - against the separate kernels (seg_head_fwd,
+    seg_head_bwd writing dx first).  A channel count whose group count is not a power of two is refused."""
+    sfx = "_f32" if f32 else ""
+    dt = F32 if f32 else torch.float16
+    N, H, W = 2, 8, 16
+    cs, npix = U.r8(Cc), N * H * W
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(N, H, W, Cc, generator=g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
+    zd = U.to_dev_nhwc(z if f32 else U.h16(z), dt)
+    pad = lambda v: fdev(np.concatenate([v.numpy(), np.zeros(cs - Cc, np.float32)]))
+    scd, shd = pad(sc), pad(sh)
+    if nheads == 0:                                       # 3 groups of 8 channels: not a power of two
+        d = ffi.HeadFwdDesc()
+        d.n = 1
+        w0, y0 = fdev(np.zeros(cs, np.float32)), torch.zeros(npix, device="cuda")
+        d.w[0], d.y[0] = w0.data_ptr(), y0.data_ptr()
+        out = torch.zeros_like(zd)
+        with pytest.raises(ffi.SegHipError, match="power of two"):
+            ffi.call("seg_bn_act_apply_head" + sfx, P(zd), cs, 0, P(out), cs, 0, N, H, W, cs, Cc, P(scd), P(shd), ACT["relu"], 0.0, None, 1, 1, C.byref(d), stream())
+        return
+    acts = [ACT["sigmoid"], ACT[None]][:nheads]
+    ws = [fdev(np.concatenate([torch.randn(Cc, generator=g).numpy() * 0.3, np.zeros(cs - Cc, np.float32)])) for _ in range(nheads)]
+    bs = [fdev(np.array([0.1 * (k + 1)], np.float32)) for k in range(nheads)]
+    ys = [torch.full((npix,), 7.0, device="cuda") for _ in range(nheads)]
+    d = ffi.HeadFwdDesc()
+    d.n = nheads
+    for k in range(nheads):
+        d.w[k], d.b[k], d.act[k], d.y[k] = ws[k].data_ptr(), bs[k].data_ptr(), acts[k], ys[k].data_ptr()
+    out = torch.zeros_like(zd)
+    pooled = torch.zeros((N, H // 2, W // 2, cs), dtype=dt if not f32 else F32, device="cuda") if pool else None
+    ffi.call("seg_bn_act_apply_head" + sfx, P(zd), cs, 0, P(out), cs, 0, N, H, W, cs, Cc, P(scd), P(shd), ACT["relu"], 0.0,
+             P(pooled) if pool else None, *(pool or (1, 1)), C.byref(d), stream())
+    # the separate kernels on the same stored tensor
+    out2 = torch.zeros_like(zd)
+    pooled2 = torch.zeros_like(pooled) if pool else None
+    ffi.call("seg_bn_act_apply" + sfx, P(zd), cs, 0, P(out2), cs, 0, N, H, W, cs, Cc, P(scd), P(shd), ACT["relu"], 0.0,
+             P(pooled2) if pool else None, *(pool or (1, 1)), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and (pooled is None or torch.equal(pooled, pooled2))
+    for k in range(nheads):
+        y2 = torch.zeros(npix, device="cuda")
+        ffi.call("seg_head_fwd" + sfx, P(out2), cs, Cc, N, H, W, 1, 1, P(ws[k]), cs, P(bs[k]), 1, acts[k], P(y2), stream())
+        torch.cuda.synchronize()
+        assert float((ys[k] - y2).abs().max()) < 2e-6 * max(1.0, float(y2.abs().max())), k
+    # ---- backward: injected against written-first
+    dA = torch.randn(N, H, W, Cc, generator=g)
+    dAd = U.to_dev_nhwc(dA if f32 else U.h16(dA), dt)
+    dys = [torch.randn(npix, generator=g).cuda() for _ in range(nheads)]
+    gs = fdev(np.array([4.0, 0.25], np.float32))
+    mean, invstd = pad(z.mean((0, 1, 2))), pad(torch.rsqrt(z.var((0, 1, 2), unbiased=False) + 1e-3))
+    inj = ffi.HeadInject()
+    inj.n, inj.gs_ptr = nheads, gs.data_ptr()
+    for k in range(nheads):
+        inj.dy[k], inj.y[k], inj.w[k], inj.act[k] = dys[k].data_ptr(), ys[k].data_ptr(), ws[k].data_ptr(), acts[k]
+    for have_dout in (True, False):
+        # reference: seg_head_bwd writes / accumulates gs * dpre * w into the gradient tensor, then the plain passes
+        gref = dAd.clone() if have_dout else torch.zeros_like(dAd)
+        for k in range(nheads):
+            ffi.call("seg_head_bwd" + sfx, P(dys[k]), P(ys[k]), P(out2), cs, Cc, N, H, W, 1, 1, P(ws[k]), cs, 1, acts[k], P(gref), 1, P(gs),
+                     None, None, None, 0, stream())
+        part_a, part_b = torch.zeros(16 * 2 * cs, device="cuda"), torch.zeros(16 * 2 * cs, device="cuda")
+        common = (npix, cs, P(scd), P(shd), P(mean), P(invstd), ACT["relu"], 0.0)
+        ffi.call("seg_bn_act_bwd_reduce" + sfx, P(gref), cs, 0, P(zd), cs, 0, *common, P(part_a), 16, stream())
+        ffi.call("seg_bn_act_bwd_reduce_inj" + sfx, P(dAd) if have_dout else None, cs, 0, P(zd), cs, 0, *common, P(part_b), 16, C.byref(inj), stream())
+        c1, c2 = (torch.zeros(cs, device="cuda") for _ in range(2))
+        ffi.call("seg_bn_bwd_finalize", P(part_a), 16, cs, npix, None, None, 1.0, None, P(c1), P(c2), stream())
+        dz_a, dz_b = torch.zeros_like(zd), torch.zeros_like(zd)
+        tail = (npix, cs, P(scd), P(shd), P(mean), P(invstd), P(c1), P(c2), ACT["relu"], 0.0, 0)
+        ffi.call("seg_bn_act_bwd_apply" + sfx, P(gref), cs, 0, P(zd), cs, 0, P(dz_a), cs, 0, *tail, stream())
+        ffi.call("seg_bn_act_bwd_apply_inj" + sfx, P(dAd) if have_dout else None, cs, 0, P(zd), cs, 0, P(dz_b), cs, 0, *tail, C.byref(inj), stream())
+        torch.cuda.synchronize()
+        # (the written-first form rounds the sum to the storage format before the passes read it; the injected one adds in fp32)
+        tol = 1e-5 if f32 else 4e-3
+        pa, pb = part_a.reshape(16, 2, cs).sum(0), part_b.reshape(16, 2, cs).sum(0)
+        assert float((pa - pb).abs().max()) < tol * float(pa.abs().max())
+        va, vb = U.dev_values(dz_a), U.dev_values(dz_b)
+        assert float((va - vb).abs().max()) < tol * float(va.abs().max())
+
+
 def test_fused_tail_add_relu_statistics_and_fanout_backward():
     """seg_add_act_stats_fwd_f32 / seg_bn_bwd_apply_fanout_f32: BN2(ReLU(a + BN1(b))) with BN1 normalised on the fly."""
     N, H, W, Cc = 2, 8, 16, 24

@@ -36,8 +36,13 @@ def test_unetpp_fusion_counts():
     c = step(m, torch.rand(2, 32, 32, 3))
     nodes = d * (d + 1) // 2
     convs = (d + 1) + 2 + nodes                      # encoder + latent(2) + nested nodes, every one conv+BN+ReLU fused
-    assert c["seg_bn_act_apply"] == convs and c["seg_bn_finalize"] == convs
-    assert c["seg_head_fwd"] == d + 1 and c["seg_head_bwd"] == d + 1
+    # the d + 1 one-channel heads (deep-supervision levels + output) ride on the bn_act_apply pass of the block they read - no
+    # seg_head_fwd launch - and their data gradient is injected into that block's BN-backward passes (seg_head_bwd: dw / db only)
+    assert c["seg_bn_act_apply"] + c["seg_bn_act_apply_head"] == convs and c["seg_bn_finalize"] == convs
+    # (level d reads X00 = the first encoder block, whose apply pass also pools: the same launch)
+    assert c["seg_bn_act_apply_head"] == d + 1 and c["seg_head_fwd"] == 0 and c["seg_head_bwd"] == d + 1
+    assert c["seg_bn_act_bwd_reduce_inj"] == d + 1 and c["seg_bn_act_bwd_apply_inj"] == d + 1
+    assert sum(1 for h in m.heads if h.inject and h.acc is None) == d + 1
     assert c["seg_igemm_wgrad"] == convs + nodes     # + one transposed conv per node
     assert c["seg_maxpool_bwd"] == d                 # pooling fused into bn_act_apply forward; only the backward is a launch
     assert c["seg_maxpool_fwd"] == 0

@@ -206,19 +206,29 @@ constexpr int UNR = 4;
 __device__ __forceinline__ int ch_shift(int CH) { return (CH & (CH - 1)) == 0 ? __ffs(CH) - 1 : -1; }
 __device__ __forceinline__ int64_t div_ch(int64_t idx, int CH, int shift) { return shift >= 0 ? (idx >> shift) : idx / CH; }
 
-template <typename T>
+// HEAD: the tensor also feeds a one-channel 1x1 output head (a deep-supervision level of UNet++, unet_variants.py:300-302, or
+// the model output): the head's dot product over the channels rides on this pass - the CH lanes of a pixel reduce their partial
+// dots with shuffles and the first one writes act(sum + bias) - instead of a seg_head_fwd launch that reads the tensor again.
+struct HeadFwd { int n; const float* w[2]; const float* b[2]; int act[2]; float* y[2]; };      // (a tensor carries at most two: UNet++'s X0d feeds level d and the output)
+template <typename T, bool HEAD>
 __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs, int x_coff, T* y, int y_cs, int y_coff,
                                                            int64_t npix, int C, int c_valid, const float* scale, const float* shift,
-                                                           int act, float alpha) {
+                                                           int act, float alpha, HeadFwd hd) {
   const int CH = C / 8;
   const int64_t items = npix * CH, stride = (int64_t)gridDim.x * TPB;
   const int64_t it0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  const bool fixed = (stride % CH) == 0;
+  const bool fixed = HEAD || (stride % CH) == 0;       // (HEAD: CH is a power of two <= 64, checked by the host - always fixed)
   const int chs = ch_shift(CH);
   const int chf = (int)(it0 % CH);
-  float sc[8], sh[8];
+  float sc[8], sh[8], hw[2][8], hb[2];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) { sc[t] = scale[chf * 8 + t]; sh[t] = shift[chf * 8 + t]; }
+  for (int t = 0; t < 8; ++t) {
+    sc[t] = scale[chf * 8 + t]; sh[t] = shift[chf * 8 + t];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) hw[k][t] = (HEAD && k < hd.n && chf * 8 + t < c_valid) ? hd.w[k][chf * 8 + t] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) hb[k] = (HEAD && k < hd.n && hd.b[k] != nullptr) ? hd.b[k][0] : 0.f;
   for (int64_t it = it0; it < items; it += stride * UNR) {
     float f[UNR][8];
     int64_t pix[UNR];
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs,
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      if (it + u * stride >= items) continue;
+      if (it + u * stride >= items) continue;      // (items is a multiple of CH and a pixel's CH lanes are consecutive: whole groups skip)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int c = ch[u] * 8 + t;
@@ -241,28 +251,44 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_kernel(const T* x, int x_cs,
         f[u][t] = c < c_valid ? v : 0.f;
       }
       store8(y + pix[u] * y_cs + y_coff + ch[u] * 8, f[u]);
+      if (HEAD) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k >= hd.n) continue;
+          float dot = 0.f;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) dot += stored<T>(f[u][t]) * hw[k][t];      // the head reads the tensor as stored
+          for (int o = CH >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+          if (chf == 0) hd.y[k][pix[u]] = seg_act(dot + hb[k], hd.act[k], 0.f);
+        }
+      }
     }
   }
 }
 
-template <typename T>
+template <typename T, bool HEAD>
 __global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const T* x, int x_cs, int x_coff, T* y, int y_cs,
                                                                 int y_coff, int N, int H, int W, int C, int c_valid,
                                                                 const float* scale, const float* shift, int act, float alpha,
-                                                                T* pooled, int ph, int pw) {
+                                                                T* pooled, int ph, int pw, HeadFwd hd) {
   const int CH = C / 8;
   const int HP = H / ph, WP = W / pw;                  // pooled extent ('valid')
   const int HB = (H + ph - 1) / ph, WB = (W + pw - 1) / pw;   // windows incl. ragged border (no pooled output there)
   const int64_t items = (int64_t)N * HB * WB * CH;
+  // (HEAD: CH is a power of two <= 64, so the CH lanes of a window are consecutive lanes of one wave and walk the window together)
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < items; it += (int64_t)gridDim.x * TPB) {
     int64_t r = it;
     const int ch = (int)(r % CH); r /= CH;
     const int wb = (int)(r % WB); r /= WB;
     const int hb = (int)(r % HB);
     const int n = (int)(r / HB);
-    float sc[8], sh[8], mx[8];
+    float sc[8], sh[8], mx[8], hw[2][8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { sc[t] = scale[ch * 8 + t]; sh[t] = shift[ch * 8 + t]; mx[t] = -3.0e38f; }
+    for (int t = 0; t < 8; ++t) {
+      sc[t] = scale[ch * 8 + t]; sh[t] = shift[ch * 8 + t]; mx[t] = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) hw[k][t] = (HEAD && k < hd.n && ch * 8 + t < c_valid) ? hd.w[k][ch * 8 + t] : 0.f;
+    }
     for (int dy = 0; dy < ph; ++dy)
       for (int dx = 0; dx < pw; ++dx) {
         const int yy = hb * ph + dy, xx = wb * pw + dx;
@@ -279,6 +305,17 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const T* x, int 
         store8(y + pix * y_cs + y_coff + ch * 8, f);
 #pragma unroll
         for (int t = 0; t < 8; ++t) mx[t] = fmaxf(mx[t], stored<T>(f[t]));   // pool the values as stored (pooled == max of y)
+        if (HEAD) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k >= hd.n) continue;
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dot += stored<T>(f[t]) * hw[k][t];
+            for (int o = CH >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+            if (ch == 0) hd.y[k][pix] = seg_act(dot + (hd.b[k] != nullptr ? hd.b[k][0] : 0.f), hd.act[k], 0.f);
+          }
+        }
       }
     if (hb < HP && wb < WP) {
       const int64_t pp = ((int64_t)n * HP + hb) * WP + wb;
@@ -288,11 +325,21 @@ __global__ __launch_bounds__(TPB) void bn_act_apply_pool_kernel(const T* x, int 
 }
 
 // ------------------------------------------------------------------------------------------------ BN backward
-template <typename T>
+// INJ: the tensor also feeds a one-channel 1x1 output head: the head's data gradient gs * dpre[pix] * w[c] (dpre = dy act'(y) of
+// the head) is ADDED ON THE FLY to the gradient read here instead of being written to the gradient tensor by seg_head_bwd first
+// (a write of the whole tensor, and a read-modify-write by the data gradient that follows); dy == NULL: the head is the tensor's only
+// consumer.
+struct HeadInj { int n; const float* dy[2]; const float* y[2]; const float* w[2]; int act[2]; const float* gs; };
+__device__ __forceinline__ float head_inj_dpre(const HeadInj& hj, int k, int64_t pix) {
+  const float d = hj.dy[k][pix] * seg_act_grad_from_out(hj.y[k][pix], hj.act[k], 0.f);
+  return hj.gs != nullptr ? d * hj.gs[0] : d;
+}
+
+template <typename T, bool INJ>
 __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int dy_cs, int dy_coff, const T* x, int x_cs,
                                                                 int x_coff, int64_t npix, int C, const float* scale,
                                                                 const float* shift, const float* mean, const float* invstd, int act,
-                                                                float alpha, float* partial, int nparts, ColLayout L) {
+                                                                float alpha, float* partial, int nparts, ColLayout L, HeadInj hj) {
   __shared__ float sm[TPB * 8];
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
   const int part = blockIdx.x;
@@ -302,20 +349,28 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_reduce_kernel(const T* dy, int
 #pragma unroll
     for (int t = 0; t < 8; ++t) { acc[0][t] = 0.f; acc[1][t] = 0.f; }
     if (ch < L.CH) {
-      float sc[8], sh[8], mu[8], is[8];
+      float sc[8], sh[8], mu[8], is[8], hw[2][8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int c = ch * 8 + t;
         sc[t] = scale[c]; sh[t] = shift[c]; mu[t] = mean[c]; is[t] = invstd[c];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) hw[k][t] = (INJ && k < hj.n) ? hj.w[k][c] : 0.f;
       }
       for (int64_t pix = (int64_t)part * L.RP + rowi; pix < npix; pix += (int64_t)L.RP * nparts) {   // interleaved rows
         float g[8], xv[8];
-        load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
+        if (!INJ || dy != nullptr) {
+          load8(dy + pix * dy_cs + dy_coff + ch * 8, g);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) g[t] = 0.f;
+        }
         load8(x + pix * x_cs + x_coff + ch * 8, xv);
+        const float hp0 = INJ ? head_inj_dpre(hj, 0, pix) : 0.f, hp1 = (INJ && hj.n > 1) ? head_inj_dpre(hj, 1, pix) : 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const float yv = seg_act(xv[t] * sc[t] + sh[t], act, alpha);
-          const float gg = g[t] * seg_act_grad_from_out(yv, act, alpha);
+          const float gg = (g[t] + hp0 * hw[0][t] + hp1 * hw[1][t]) * seg_act_grad_from_out(yv, act, alpha);
           acc[0][t] += gg;
           acc[1][t] += gg * (xv[t] - mu[t]) * is[t];
         }
@@ -348,12 +403,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finalize_kernel(const float* parti
   c2[c] = q * inv_count;
 }
 
-template <typename T>
+template <typename T, bool INJ>
 __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int dy_cs, int dy_coff, const T* x, int x_cs,
                                                                int x_coff, T* dx, int dx_cs, int dx_coff, int64_t npix, int C,
                                                                const float* scale, const float* shift, const float* mean,
                                                                const float* invstd, const float* c1, const float* c2, int act,
-                                                               float alpha, int accumulate, ColLayout L) {
+                                                               float alpha, int accumulate, ColLayout L, HeadInj hj) {
   // thread = (pixel row rowi, channel chunk col); blocks walk the tensor in interleaved chunks of RP * UNR pixels (as
   // act_bwd_kernel: concurrently running blocks stream neighbouring addresses - 2.9 -> 4.5 TB/s against a plain
   // grid-stride loop whose four loads per thread are megabytes apart); the channel chunk of a thread is fixed, so
@@ -365,12 +420,14 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
     const int ch = grp * L.CHP + col;
     if (ch >= L.CH) continue;
     // dx = sc * (g - c1 - (x - mu) * is * c2) = g * sc + x * ka + kb   with ka = -sc*is*c2, kb = sc*(mu*is*c2 - c1)
-    float sc[8], sh[8], ka[8], kb[8];
+    float sc[8], sh[8], ka[8], kb[8], hw[2][8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int c = ch * 8 + t;
       sc[t] = scale[c];
       sh[t] = shift[c];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) hw[k][t] = (INJ && k < hj.n) ? hj.w[k][c] : 0.f;
       if (train) {
         const float k = invstd[c] * c2[c];
         ka[t] = -sc[t] * k;
@@ -381,14 +438,25 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
       }
     }
     for (int64_t pb = blockIdx.x * chunk + rowi; pb < npix; pb += chunk * gridDim.x) {
-      float g[UNR][8], xv[UNR][8], old[UNR][8];
+      float g[UNR][8], xv[UNR][8], old[UNR][8], hp[UNR][2];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int64_t pix = pb + (int64_t)u * L.RP;
+        hp[u][0] = 0.f;
+        hp[u][1] = 0.f;
         if (pix < npix) {
-          load8(dy + pix * dy_cs + dy_coff + ch * 8, g[u]);
+          if (!INJ || dy != nullptr) {
+            load8(dy + pix * dy_cs + dy_coff + ch * 8, g[u]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) g[u][t] = 0.f;
+          }
           load8(x + pix * x_cs + x_coff + ch * 8, xv[u]);
           if (accumulate) load8(dx + pix * dx_cs + dx_coff + ch * 8, old[u]);
+          if (INJ) {
+            hp[u][0] = head_inj_dpre(hj, 0, pix);
+            if (hj.n > 1) hp[u][1] = head_inj_dpre(hj, 1, pix);
+          }
         }
       }
 #pragma unroll
@@ -399,7 +467,7 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const float yv = seg_act(xv[u][t] * sc[t] + sh[t], act, alpha);
-          const float gg = g[u][t] * seg_act_grad_from_out(yv, act, alpha);
+          const float gg = (g[u][t] + hp[u][0] * hw[0][t] + hp[u][1] * hw[1][t]) * seg_act_grad_from_out(yv, act, alpha);
           o[t] = train ? gg * sc[t] + xv[u][t] * ka[t] + kb[t] : gg * sc[t];
           if (accumulate) o[t] += old[u][t];
         }
@@ -1897,41 +1965,86 @@ extern "C" int seg_bn_fold_inference(const float* gamma, const float* beta, cons
 template <typename T>
 static int seg_bn_act_apply_impl(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H,
                                 int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha,
-                                void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) {
+                                void* pooled, int32_t ph, int32_t pw, const seg_head_fwd_desc* head, seg_stream_t stream) {
   SEG_CHECK_ARG(x && y && scale && shift && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (x_cs & 7) == 0 && (y_cs & 7) == 0 &&
                     (x_coff & 7) == 0 && (y_coff & 7) == 0 && x_coff + C <= x_cs && y_coff + C <= y_cs,
                 "seg_bn_act_apply: bad arguments");
   const int64_t npix = (int64_t)N * H * W;
+  HeadFwd hd{0, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}, {nullptr, nullptr}};
+  if (head != nullptr) {
+    const int CH = C / 8;
+    SEG_CHECK_ARG(head->n >= 1 && head->n <= 2 && CH <= 64 && (CH & (CH - 1)) == 0,
+                  "seg_bn_act_apply_head: one or two one-channel heads on a tensor of 8 .. 512 channels (a power of two of 8-channel groups)");
+    hd.n = head->n;
+    for (int k = 0; k < head->n; ++k) {
+      SEG_CHECK_ARG(head->w[k] && head->y[k] && (head->act[k] == SEG_ACT_NONE || head->act[k] == SEG_ACT_SIGMOID || head->act[k] == SEG_ACT_RELU),
+                    "seg_bn_act_apply_head: head %d (weights, output, activation none / sigmoid / relu)", k);
+      hd.w[k] = head->w[k]; hd.b[k] = head->b[k]; hd.act[k] = head->act[k]; hd.y[k] = head->y[k];
+    }
+  }
   if (pooled == nullptr) {
-    hipLaunchKernelGGL((bn_act_apply_kernel<T>), dim3(grid_for((npix * (C / 8) + UNR - 1) / UNR)), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
-                       (T*)y, y_cs, y_coff, npix, C, c_valid, scale, shift, act, alpha);
+    const dim3 grid(grid_for((npix * (C / 8) + UNR - 1) / UNR));
+    if (head != nullptr)
+      hipLaunchKernelGGL((bn_act_apply_kernel<T, true>), grid, dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff, (T*)y, y_cs, y_coff, npix, C,
+                         c_valid, scale, shift, act, alpha, hd);
+    else
+      hipLaunchKernelGGL((bn_act_apply_kernel<T, false>), grid, dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff, (T*)y, y_cs, y_coff, npix, C,
+                         c_valid, scale, shift, act, alpha, hd);
   } else {
     SEG_CHECK_ARG(ph >= 1 && pw >= 1 && y_coff == 0 && C == y_cs, "seg_bn_act_apply: fused pooling needs a dense output (C == y_cs)");
     const int64_t items = (int64_t)N * ((H + ph - 1) / ph) * ((W + pw - 1) / pw) * (C / 8);
-    hipLaunchKernelGGL((bn_act_apply_pool_kernel<T>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
-                       (T*)y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, (T*)pooled, ph, pw);
+    if (head != nullptr)
+      hipLaunchKernelGGL((bn_act_apply_pool_kernel<T, true>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
+                         (T*)y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, (T*)pooled, ph, pw, hd);
+    else
+      hipLaunchKernelGGL((bn_act_apply_pool_kernel<T, false>), dim3(grid_for(items)), dim3(TPB), 0, ST(stream), (const T*)x, x_cs, x_coff,
+                         (T*)y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, (T*)pooled, ph, pw, hd);
   }
   SEG_CHECK_LAUNCH("seg_bn_act_apply");
   return SEG_OK;
 }
-extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<half_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
-extern "C" int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<split_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, stream); }
+extern "C" int seg_bn_act_apply(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<half_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, nullptr, stream); }
+extern "C" int seg_bn_act_apply_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, seg_stream_t stream) { return seg_bn_act_apply_impl<split_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, nullptr, stream); }
+extern "C" int seg_bn_act_apply_head(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, const seg_head_fwd_desc* head, seg_stream_t stream) { return seg_bn_act_apply_impl<half_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, head, stream); }
+extern "C" int seg_bn_act_apply_head_f32(const void* x, int32_t x_cs, int32_t x_coff, void* y, int32_t y_cs, int32_t y_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t c_valid, const float* scale, const float* shift, int32_t act, float alpha, void* pooled, int32_t ph, int32_t pw, const seg_head_fwd_desc* head, seg_stream_t stream) { return seg_bn_act_apply_impl<split_t>(x, x_cs, x_coff, y, y_cs, y_coff, N, H, W, C, c_valid, scale, shift, act, alpha, pooled, ph, pw, head, stream); }
+
+static int head_inj_check(const seg_head_inject* inj, HeadInj* hj) {
+  *hj = HeadInj{0, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}, nullptr};
+  if (inj == nullptr) return SEG_OK;
+  SEG_CHECK_ARG(inj->n >= 1 && inj->n <= 2, "head gradient injection: one or two heads");
+  hj->n = inj->n;
+  hj->gs = inj->gs_ptr;
+  for (int k = 0; k < inj->n; ++k) {
+    SEG_CHECK_ARG(inj->dy[k] && inj->y[k] && inj->w[k] && (inj->act[k] == SEG_ACT_NONE || inj->act[k] == SEG_ACT_SIGMOID || inj->act[k] == SEG_ACT_RELU),
+                  "head gradient injection: dy, y, w of one-channel head %d (activation none / sigmoid / relu)", k);
+    hj->dy[k] = inj->dy[k]; hj->y[k] = inj->y[k]; hj->w[k] = inj->w[k]; hj->act[k] = inj->act[k];
+  }
+  return SEG_OK;
+}
 
 template <typename T>
 static int seg_bn_act_bwd_reduce_impl(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff,
                                      int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts,
-                                     seg_stream_t stream) {
-  SEG_CHECK_ARG(dy && x && scale && shift && mean && invstd && partial && npix > 0 && C > 0 && (C & 7) == 0 && nparts > 0 &&
+                                     const seg_head_inject* inj, seg_stream_t stream) {
+  SEG_CHECK_ARG((dy || inj) && x && scale && shift && mean && invstd && partial && npix > 0 && C > 0 && (C & 7) == 0 && nparts > 0 &&
                     dy_coff + C <= dy_cs && x_coff + C <= x_cs,
                 "seg_bn_act_bwd_reduce: bad arguments");
-  hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff, (const T*)x,
-                     x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C));
+  HeadInj hj;
+  if (int rc = head_inj_check(inj, &hj)) return rc;
+  if (inj != nullptr)
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff, (const T*)x,
+                       x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C), hj);
+  else
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff, (const T*)x,
+                       x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, col_layout(C), hj);
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_reduce");
   return SEG_OK;
 }
-extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, stream); }
-extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, stream); }
+extern "C" int seg_bn_act_bwd_reduce(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
+extern "C" int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, nullptr, stream); }
+extern "C" int seg_bn_act_bwd_reduce_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
+extern "C" int seg_bn_act_bwd_reduce_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t act, float alpha, float* partial, int32_t nparts, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_reduce_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, npix, C, scale, shift, mean, invstd, act, alpha, partial, nparts, inj, stream); }
 
 extern "C" int seg_bn_bwd_finalize(const float* partial, int32_t nparts, int32_t C, int64_t count, float* dgamma, float* dbeta,
                                    float gscale, const float* gscale_ptr, float* c1, float* c2, seg_stream_t stream) {
@@ -1946,21 +2059,30 @@ template <typename T>
 static int seg_bn_act_bwd_apply_impl(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx,
                                     int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
                                     const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha,
-                                    int32_t accumulate, seg_stream_t stream) {
-  SEG_CHECK_ARG(dy && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
+                                    int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) {
+  SEG_CHECK_ARG((dy || inj) && x && dx && scale && shift && npix > 0 && C > 0 && (C & 7) == 0 && dy_coff + C <= dy_cs && x_coff + C <= x_cs &&
                     dx_coff + C <= dx_cs && (c1 == nullptr || (c2 && mean && invstd)),
                 "seg_bn_act_bwd_apply: bad arguments");
+  HeadInj hj;
+  if (int rc = head_inj_check(inj, &hj)) return rc;
   const ColLayout L = col_layout(C);
   int64_t blocks = (npix + (int64_t)L.RP * UNR - 1) / ((int64_t)L.RP * UNR);
   if (blocks > 512) blocks = 512;       // two blocks per CU: 96 us per 134 MB tensor against 114 us at 2048 blocks (measured sweep)
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
-                     (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
-                     accumulate, L);
+  if (inj != nullptr)
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, true>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
+                       (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
+                       accumulate, L, hj);
+  else
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, false>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, dy_cs, dy_coff,
+                       (const T*)x, x_cs, x_coff, (T*)dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha,
+                       accumulate, L, hj);
   SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply");
   return SEG_OK;
 }
-extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, stream); }
-extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, stream); }
+extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
+extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
+extern "C" int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
+extern "C" int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
 
 template <typename T>
 static int seg_act_bwd_impl(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,

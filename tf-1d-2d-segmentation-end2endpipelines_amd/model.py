@@ -452,6 +452,8 @@ def wgrad_halo_class_groups(g: Geom) -> int:
 FWD_HALO_NARROW = os.environ.get("SEG_FWD_HALO_NARROW", "1") != "0"    # parity mode: the 256 x 32 halo tile for layers of <= 32 output channels
 WGRAD_FORK_EARLY = os.environ.get("SEG_WGRAD_FORK_EARLY", "1") != "0"   # side stream forks when dz is final, before the op's data gradients are enqueued
 HEAD_DW_SIDE = os.environ.get("SEG_HEAD_DW_SIDE", "1") != "0"          # output heads: weight / bias gradient on the side stream
+HEAD_FUSE_FWD = os.environ.get("SEG_HEAD_FUSE_FWD", "1") != "0"        # a one-channel head's forward rides on the bn_act_apply pass of the Conv_Block it reads
+HEAD_INJECT = os.environ.get("SEG_HEAD_INJECT", "1") != "0"            # ... and its data gradient is added on the fly in that block's BN-backward passes
 WGRAD_BLOCKS = int(os.environ.get("SEG_WGRAD_BLOCKS", "1536"))       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = int(os.environ.get("SEG_HALO_BLOCKS_TC", os.environ.get("SEG_HALO_BLOCKS", "256")))   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
@@ -702,6 +704,10 @@ class ConvOp(Op):
         self.lazy = False            # training: `out` is never written - its only consumer (a fused add) normalises z on load
         self.grad_src: Optional[DevTensor] = None      # backward: dOut is read from this tensor's gradient (shared with a sibling)
         self.tail_sums = 0           # backward: > 0 = a fused tail's fan-out launch already left this BN's two sums in `bpart` (that many rows)
+        self.heads: List["HeadOp"] = []            # one-channel output heads on `out` (at most two) whose forward rides on this block's bn_act_apply
+        self._head_desc = None
+        self.head_done = False                     # ... did so in the forward pass just run (not in the one-launch inference form)
+        self.head_inj: Optional[_ffi.HeadInject] = None      # backward: that head's data gradient is injected into the BN-backward passes
         self.gather_launch: List["GatherDgrad"] = []      # gathered data gradients launched at the end of this op's backward
         self.dz_ptr = None
 
@@ -790,6 +796,7 @@ class ConvOp(Op):
 
     def forward(self, training):
         st, s = self.m.store, _stream()
+        self.head_done = False
         if not training and self.fwd_args_infer is not None:
             bn = self.bn_name
             if not self._infer_valid:
@@ -815,6 +822,18 @@ class ConvOp(Op):
             if self.lazy and training:
                 return                   # (the fused add that consumes this block applies scale / shift / ReLU on load)
             ph, pw = self.pool_size if self.pooled is not None else (1, 1)
+            if self.heads:                   # the heads' dot products over the channels come out of this pass
+                if self._head_desc is None:
+                    d = _ffi.HeadFwdDesc()
+                    d.n = len(self.heads)
+                    for k, h in enumerate(self.heads):
+                        d.w[k], d.b[k], d.act[k], d.y[k] = st.ptr(h.wname).value, st.ptr(h.bname).value, h.act, h.y.data_ptr()
+                    self._head_desc = d
+                call("seg_bn_act_apply_head", _p(self.z.buf), self.z.cs, 0, _p(self.out.buf), self.out.cs, 0, self.z.N, self.z.H,
+                     self.z.W, self.n_rows, self.cout, _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha),
+                     _p(self.pooled.buf) if self.pooled is not None else None, ph, pw, C.byref(self._head_desc), s)
+                self.head_done = True
+                return
             call("seg_bn_act_apply", _p(self.z.buf), self.z.cs, 0, _p(self.out.buf), self.out.cs, 0, self.z.N, self.z.H,
                  self.z.W, self.n_rows, self.cout, _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha),
                  _p(self.pooled.buf) if self.pooled is not None else None, ph, pw, s)
@@ -838,7 +857,8 @@ class ConvOp(Op):
         self.pool_acc = None
         if self.pooled is not None and self.pooled.gw:
             self.pool_acc = self.out.claim()
-        self.live = self.out.gw
+        self.has_dout = self.out.gw           # somebody writes dOut (with an injected head alone the buffer is only this block's dz)
+        self.live = self.out.gw or self.head_inj is not None
         self.fused_act_bwd = False
         if not self.live:
             return
@@ -904,15 +924,18 @@ class ConvOp(Op):
             bn = self.bn_name
             dA = self.out.ensure_grad()
             src = _p(self.grad_src.grad if self.grad_src is not None else dA)      # (a sibling's buffer: written once for both, read-only here)
+            inj = self.head_inj
+            if inj is not None and not self.has_dout:
+                src = None                    # the injected head is the only consumer: no gradient tensor to read
             if not self.tail_sums:
-                call("seg_bn_act_bwd_reduce", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, self.z.npix, self.n_rows,
-                     _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act], float(self.alpha),
-                     _p(self.bpart), BN_PARTS_BWD, s)
+                call("seg_bn_act_bwd_reduce" + ("_inj" if inj is not None else ""), src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0,
+                     self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act],
+                     float(self.alpha), _p(self.bpart), BN_PARTS_BWD, *((C.byref(inj),) if inj is not None else ()), s)
             call("seg_bn_bwd_finalize", _p(self.bpart), self.tail_sums or BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
                  st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
-            call("seg_bn_act_bwd_apply", src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA), self.out.cs, 0,
-                 self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
-                 _p(self.c2), ACT[self.act], float(self.alpha), 0, s)
+            call("seg_bn_act_bwd_apply" + ("_inj" if inj is not None else ""), src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA),
+                 self.out.cs, 0, self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
+                 _p(self.c2), ACT[self.act], float(self.alpha), 0, *((C.byref(inj),) if inj is not None else ()), s)
             dz = dA
         elif self.kind == "convlstm":
             dz = self.z.ensure_grad()
@@ -1068,13 +1091,43 @@ class HeadOp(Op):
         m.store.add(kspec, cout * w_ld, to_engine, lambda f: f.reshape(cout, w_ld)[:, :cin].T.reshape(kspec.shape).copy())
         m.store.add(bspec, cout, lambda b: np.asarray(b, np.float32), lambda f: f[:cout].copy())
         self.wname, self.bname = kspec.name, bspec.name
+        # one output channel on a Conv_Block's output (a deep-supervision level of UNet++ / the model output on X05): the forward
+        # dot product rides on that block's bn_act_apply pass, the data gradient is injected into its BN-backward passes
+        self.prod: Optional[ConvOp] = None
+        self.inject = False
+        CH = x.cs // 8
+        prod = next((o for o in m.ops if isinstance(o, ConvOp) and o.out is x), None)
+        if (prod is not None and prod.has_bn and prod.kind != "convlstm" and self.cout == 1 and (sh, sw) == (1, 1)
+                and CH <= 64 and CH & (CH - 1) == 0 and self.act in (ACT[None], ACT["sigmoid"], ACT["relu"]) and len(prod.heads) < 2):
+            if HEAD_FUSE_FWD:
+                self.prod = prod
+                prod.heads.append(self)
+            self.inject = HEAD_INJECT
+            if self.inject:
+                self.prod_inj = prod
 
     def forward(self, training):
         st = self.m.store
+        if self.prod is not None and self.prod.head_done:
+            return                         # (computed inside the producing block's bn_act_apply pass)
         call("seg_head_fwd", _p(self.x.buf), self.x.cs, self.cin, self.x.N, self.x.H, self.x.W, self.sy, self.sx,
              st.ptr(self.wname), self.w_ld, st.ptr(self.bname), self.cout, self.act, _p(self.y), _stream())
 
     def plan_backward(self):
+        if self.inject and self.x.needs_grad and (self.prod_inj.head_inj is None or self.prod_inj.head_inj.n < 2):
+            # no dx launch: the producing block adds gs * dpre * w to the gradient it reads in its own BN-backward passes
+            st = self.m.store
+            d = self.prod_inj.head_inj
+            if d is None:
+                d = _ffi.HeadInject()
+                d.n, d.gs_ptr = 0, self.m.gs.data_ptr()
+                self.prod_inj.head_inj = d
+            k = d.n
+            d.dy[k], d.y[k], d.w[k], d.act[k] = self.dy.data_ptr(), self.y.data_ptr(), st.ptr(self.wname).value, self.act
+            d.n = k + 1
+            self.acc = None
+            return
+        self.inject = False
         self.acc = self.x.claim() if self.x.needs_grad else None
 
     def backward(self):

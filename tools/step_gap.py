@@ -41,10 +41,20 @@ def main(d):
         allg = [(mainq[i + 1]["s"] - mainq[i]["e"], mainq[i]["Kernel_Name"]) for i in range(len(mainq) - 1)]
         idle_by = Counter()
         for gns, nm in allg:
-            idle_by[nm.split("<")[0].split("(")[0][-40:]] += max(gns, 0)
+            idle_by[nm.replace("void ", "").replace("(anonymous namespace)::", "").split("<")[0].split("(")[0][-40:]] += max(gns, 0)
         print(f"   kernels: main {len(mainq)}, side {len(side)}; main-queue gaps: {sum(1 for g_, _ in allg if g_ > 2000)} above 2 us, "
               f"sum {sum(max(g_, 0) for g_, _ in allg) / 1e6:.3f} ms")
         print("   idle behind (ms):", [(k, round(v / 1e6, 3)) for k, v in idle_by.most_common(8)])
+        def short(nm):
+            return nm.replace("void ", "").replace("(anonymous namespace)::", "").split("<")[0].split("(")[0][-44:]
+        busy_by = Counter()
+        for r in mainq:
+            busy_by[short(r["Kernel_Name"])] += r["e"] - r["s"]
+        side_by = Counter()
+        for r in side:
+            side_by[short(r["Kernel_Name"])] += r["e"] - r["s"]
+        print("   main-queue kernel time by kernel (ms):", [(k, round(v / 1e6, 2)) for k, v in busy_by.most_common(12)])
+        print("   side-queue kernel time by kernel (ms):", [(k, round(v / 1e6, 2)) for k, v in side_by.most_common(6)], "total", round(sum(side_by.values()) / 1e6, 2))
         native = Counter(r["Kernel_Name"].split("<")[0][-48:] for r in step if "at::native" in r["Kernel_Name"] or "rocclr" in r["Kernel_Name"])
         print("   at::native / runtime launches inside the step:", dict(native))
 
