@@ -145,18 +145,18 @@ def test_bucket_holds_follow_the_queue_model():
         m.world_size = 8
         bk = m.grad_buckets()
         assert len(bk) > 3 and bk[0][0] == 0 and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
-        old = M.DP_BUSBW_GBS
+        old = M.F.DP_BUSBW_GBS
         try:
-            M.DP_BUSBW_GBS = 1e-6                                               # a link that never finishes in time: all held
+            M.F.DP_BUSBW_GBS = 1e-6                                               # a link that never finishes in time: all held
             assert all(m.bucket_holds())
-            M.DP_BUSBW_GBS = 1e12                                               # an infinitely fast link: only slices that complete
+            M.F.DP_BUSBW_GBS = 1e12                                               # an infinitely fast link: only slices that complete
             h = m.bucket_holds()                                               # with the sweep's very last GEMM are held
             cost_before = [sum(1 for op in m.ops[:oi] if isinstance(op, M.ConvOp)) for _lo, _hi, oi in bk]
             assert h == [c == 0 for c in cost_before] and h[0]
-            M.DP_BUSBW_GBS = old
+            M.F.DP_BUSBW_GBS = old
             h = m.bucket_holds()
             assert h[0] and len(h) == len(bk)                                  # the sweep's last slice can never finish before it ends
         finally:
-            M.DP_BUSBW_GBS = old
+            M.F.DP_BUSBW_GBS = old
     finally:
         M._DryRun.on = False

@@ -129,7 +129,7 @@ def test_fused_inference_equals_the_three_pass_form(name, dtype, tol, monkeypatc
     assert any(getattr(op, "fwd_args_infer", None) is not None for op in model.ops)
     fused = model.predict(x)
     w = model.get_weights()
-    monkeypatch.setattr(M, "FUSE_INFERENCE_BN", False)
+    monkeypatch.setattr(M.F, "FUSE_INFERENCE_BN", False)
     m2, _x, _t, _l = CASES[name]()
     m2.build(x.shape[0], dtype=dtype)
     m2.set_weights(w)
@@ -284,7 +284,7 @@ def test_fused_bn_tails_equal_the_separate_passes(name, monkeypatch):
     m1.build(x.shape[0], dtype="f32")
     assert any(isinstance(o, M.BNOp) and o.fused_add is not None for o in m1.ops)
     w = m1.get_weights()
-    monkeypatch.setattr(M, "FUSE_BN_TAILS", False)
+    monkeypatch.setattr(M.F, "FUSE_BN_TAILS", False)
     m0, _x, _t, _l = CASES[name]()
     m0.build(x.shape[0], dtype="f32")
     m0.set_weights(w)
@@ -322,7 +322,7 @@ def test_split_reductions_in_a_training_step(dtype, tol, monkeypatch):
     split = [a for a in m1.fwd_ws_users if a.splitk > 1]
     assert any(a.nout > 1 for a in split) and any(a.g.ncls == 4 for a in split) and any(a.stats for a in split)
     w = m1.get_weights()
-    monkeypatch.setattr(M, "FWD_SPLITK", False)
+    monkeypatch.setattr(M.F, "FWD_SPLITK", False)
     m0 = B("UNet", 32, 32, 256, 3, num_channels=3, ds=1)
     m0.build(2, dtype=dtype)
     assert not any(a.splitk > 1 for a in m0.fwd_ws_users)

@@ -96,11 +96,11 @@ def test_multires_tails_are_fused_passes(monkeypatch):
         virt = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.pieces is not None)
         return c, tails, folded, lazy, virt, m
     for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS"):
-        monkeypatch.setattr(M, sw, False)
+        monkeypatch.setattr(M.F, sw, False)
     c1, tails, folded, lazy, virt, _m = counts()                                # the round-3 form
     assert tails > 0 and folded > 0 and lazy == 0 and virt == 0
     assert c1["seg_add_act_stats_fwd"] == tails and c1["seg_bn_bwd_apply_fanout"] == tails
-    monkeypatch.setattr(M, "FUSE_BN_TAILS", False)
+    monkeypatch.setattr(M.F, "FUSE_BN_TAILS", False)
     c0, t0, f0, _l, _v, _m = counts()
     assert t0 == 0 and f0 == 0 and c0["seg_add_act_stats_fwd"] == 0
     assert c0["seg_add_act_fwd"] - c1["seg_add_act_fwd"] == tails and c0["seg_add_act_bwd"] - c1["seg_add_act_bwd"] == tails
@@ -108,9 +108,9 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     assert c0["seg_bn_act_apply"] - c1["seg_bn_act_apply"] == folded           # BN(cat) applied inside the add
     assert c0["seg_bn_act_bwd_apply"] - c1["seg_bn_act_bwd_apply"] == tails    # replaced by the fan-out form
     # ---- round 4
-    monkeypatch.setattr(M, "FUSE_BN_TAILS", True)
+    monkeypatch.setattr(M.F, "FUSE_BN_TAILS", True)
     for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS"):
-        monkeypatch.setattr(M, sw, True)
+        monkeypatch.setattr(M.F, sw, True)
     c2, tails2, folded2, lazy, virt, m = counts()
     assert (tails2, folded2) == (tails, folded) and virt == folded            # every BN(cat) of this model is a virtual concatenation
     assert lazy == 2 * (tails - folded) + folded                                # ResPath: shortcut + conv; MultiResBlock: the shortcut

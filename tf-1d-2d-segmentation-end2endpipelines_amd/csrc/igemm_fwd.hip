@@ -104,9 +104,8 @@ static int launch_fwd2(const seg_igemm_fwd_args& a, int mblocks, int nblocks, hi
   };
   // deep-and-small layers: with ~1 block per CU nothing else hides a block's barriers and load latency, so take both
   // the 64-deep K step (8 instead of 4 MFMAs per wave and barrier) and two steps of loads in flight (72 KB of LDS)
-  static const bool no_deep = std::getenv("SEG_NO_DEEP_RING") != nullptr;
-  static const long deep_max = std::getenv("SEG_DEEP_RING_MAX") ? std::atol(std::getenv("SEG_DEEP_RING_MAX")) : 1024;    // measured: 384 -> 1024 blocks -0.14 ms per C3 step, 4096 the same
-  if (!no_deep && std::getenv("SEG_V2_BK") == nullptr && a.tile_m == 128 && a.tile_n == 64 && (long)mblocks * nblocks * a.g.ncls <= deep_max &&
+  constexpr long deep_max = 1024;          // measured: 384 -> 1024 blocks -0.14 ms per C3 step, 4096 the same
+  if (std::getenv("SEG_V2_BK") == nullptr && a.tile_m == 128 && a.tile_n == 64 && (long)mblocks * nblocks * a.g.ncls <= deep_max &&
       (a.g.ntaps == 9 || a.g.ntaps == 16) && (a.Kpad & 63) == 0) {
     bool ok = true;
     for (int s = 0; s < a.nseg; ++s) ok = ok && a.seg_c[s] >= 64 && (a.seg_c[s] & 63) == 0;

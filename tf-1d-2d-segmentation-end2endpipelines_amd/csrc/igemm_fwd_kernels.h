@@ -462,8 +462,6 @@ inline int check_fwd_args(const seg_igemm_fwd_args* a) {
 // the per-tap LDS-DMA kernel takes 128- and 256-row tiles, tap counts it is instantiated for, operands below 1 GiB
 // (esz = bytes per element of the operands: 2, parity mode 4)
 inline bool fwd2_eligible(const seg_igemm_fwd_args& a, int esz) {
-  static const bool force_v1 = std::getenv("SEG_IGEMM_V1") != nullptr;
-  if (force_v1) return false;
   if (!((a.tile_m == 128 && (a.tile_n == 128 || a.tile_n == 64)) || (a.tile_m == 256 && a.tile_n == 64))) return false;
   const int nt = a.g.ntaps;
   if (!(nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 9 || nt == 16)) return false;

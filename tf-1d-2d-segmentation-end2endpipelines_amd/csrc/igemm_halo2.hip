@@ -1,5 +1,5 @@
 // Halo-tile forward / data-gradient kernel, software-pipelined generation (variant 3 of seg_igemm_fwd, the default since
-// round 2; igemm_halo.hip keeps the round-1 kernel for A/B runs: SEG_FWD_PIPE=0).
+// round 2 for the transposed convs; igemm_halo.hip keeps the round-1 kernel, which the 3x3 layers run on).
 //
 // Same decomposition as igemm_fwd3_kernel - a block owns a 256-pixel patch x BN output channels, ONE input halo tile per
 // 32-channel chunk serves every tap, the weights stream through an LDS ring by LDS-DMA - but the MFMA operands are read
@@ -340,37 +340,19 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd4_kernel(const seg_igemm_fwd_
 SEG_FWD4_INST(9, 1, 1, 4)      // 3x3 conv and its data gradient
 SEG_FWD4_INST(4, 1, 1, 4)      // one sub-pixel class of the 4x4 / stride-2 transposed conv
 SEG_FWD4_INST(4, 1, 4, 4)      // ... and its data gradient (four parity planes)
-// the round-1 tap grouping of the 64-channel tile (3 taps per barrier, 3-stage ring) with read-ahead inside the step
-template __global__ void igemm_fwd4_kernel<32, 64, 9, 3, 1, 3>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd4_kernel<16, 64, 9, 3, 1, 3>(const seg_igemm_fwd_args);
-// the 64-channel tile of the transposed conv and of its data gradient: two taps per barrier (16 instead of 8 MFMAs per wave between barriers)
-template __global__ void igemm_fwd4_kernel<32, 64, 4, 2, 1, 4>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd4_kernel<16, 64, 4, 2, 1, 4>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd4_kernel<32, 64, 4, 2, 4, 4>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd4_kernel<16, 64, 4, 2, 4, 4>(const seg_igemm_fwd_args);
+// (round 4: the 3-taps-per-barrier and 2-taps-per-barrier groupings of the 64-channel tile - SEG_FWD4_TG3 / SEG_FWD4_TG2 - lost
+// their A/Bs in round 2 and are gone with their instances)
 #undef SEG_FWD4_INST
 
 template <int NT, int NPL>
 void launch_fwd4_nt(const seg_igemm_fwd_args& a, int pw, dim3 grid, hipStream_t st) {
   const int ni_a = pw == 32 ? 22 : 21;
-  static const bool tg3 = std::getenv("SEG_FWD4_TG3") != nullptr;       // A/B switch: 64-channel tile with 3 taps per barrier
-  static const bool tg2 = std::getenv("SEG_FWD4_TG2") != nullptr;       // A/B switch: transposed conv, 64-channel tile, 2 taps per barrier
   const bool dbgk = (a.variant >> 8) != 0 && pw == 32;     // timing experiments: the instantiation that keeps the switches
   if (a.tile_n == 128) {
     const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 8192;
     if (dbgk) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 128, NT, 1, NPL, 4, true>), grid, dim3(256), lds, st, a);
     else if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 128, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 128, NT, 1, NPL, 4>), grid, dim3(256), lds, st, a);
-  } else if (NT == 9 && NPL == 1 && tg3) {
-    const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (3 * 4096);
-    if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, 9, 3, 1, 3>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 64, 9, 3, 1, 3>), grid, dim3(256), lds, st, a);
-  } else if (NT == 4 && tg2) {
-    if constexpr (NT == 4) {
-      const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 8192;
-      if (pw == 32) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, 4, 2, NPL, 4>), grid, dim3(256), lds, st, a);
-      else hipLaunchKernelGGL((igemm_fwd4_kernel<16, 64, 4, 2, NPL, 4>), grid, dim3(256), lds, st, a);
-    }
   } else {
     const size_t lds = (size_t)2 * ni_a * 1024 + 4 * 4096;
     if (dbgk) hipLaunchKernelGGL((igemm_fwd4_kernel<32, 64, NT, 1, NPL, 4, true>), grid, dim3(256), lds, st, a);

@@ -893,8 +893,7 @@ extern "C" int64_t seg_igemm_wgrad_workspace_bytes(const seg_igemm_wgrad_args* a
 // taps handled per block by the weight-gradient kernels (1 = the per-tap kernel); exported so that the host can
 // size the pixel split with the same rule
 extern "C" int seg_wgrad_taps_per_block(int tile_m, int tile_n, int ntaps, int variant) {
-  static const bool force_v1 = std::getenv("SEG_WGRAD_V1") != nullptr;
-  if (force_v1 || variant != 0 || tile_m != 64) return 1;
+  if (variant != 0 || tile_m != 64) return 1;
   if (tile_n == 64) return (ntaps == 9 || ntaps == 4 || ntaps == 3) ? ntaps : 1;
   if (tile_n == 128) return ntaps == 4 ? 4 : (ntaps == 9 || ntaps == 3) ? 3 : 1;
   return 1;
@@ -978,14 +977,10 @@ extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t strea
       // Measured (tools/op_bench.py, C3 layers, same box): when the grid has at most ~1 block per CU anyway (deep layers:
       // few patches, many weight tiles) it is 25-45 % faster than the round-1 kernel (X23 488 -> 352 us, X32 474 -> 339 us,
       // enc3 92 -> 73 us); when the round-1 kernel can keep two blocks per CU it is 0-12 % slower (X14, X05).
-      // SEG_WGRAD_WS=0 / 1 forces one.
-      static const char* ws_env = std::getenv("SEG_WGRAD_WS");
       const long nblk = (long)gridh.x * gridh.y * gridh.z;
-      const bool ws = ws_env != nullptr ? std::atoi(ws_env) != 0 : nblk <= 320;
-      // larger grids: tap-split generation (igemm_wgrad3.hip: an input fragment feeds two MFMAs, -30 % LDS reads);
-      // SEG_WGRAD_TS=0 keeps the round-1 kernel
-      static const char* ts_env = std::getenv("SEG_WGRAD_TS");
-      const bool ts = ts_env == nullptr || std::atoi(ts_env) != 0;
+      const bool ws = nblk <= 320;
+      // larger grids: tap-split generation (igemm_wgrad3.hip: an input fragment feeds two MFMAs, -30 % LDS reads)
+      const bool ts = true;
       const int force = a->variant >> 8;                            // tests: 0x40 wave-specialised, 0x80 round 1, 0x100 tap-split
       if (a->g.ncls == 1 && (force == 0x40 || (ws && force != 0x80 && !(force & 0x100)))) {
         seg_launch_wgrad_halo_ws(*a, pc, gridh, sth);

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(TPB) void cast_bf16_kernel(const float* x, uint16_t
 
 // The optimiser streams 30 B per parameter next to the forward GEMMs of the following step (SegModel runs it on the side
 // stream): 1024 blocks keep the HBM busy and leave CUs to the GEMMs - measured on C3 against 256 / 512 / 2048 / 4096 blocks
-// (25.2 / 24.1 / 23.7 / 23.8 ms per step; 1024: 23.5).  SEG_ADAM_BLOCKS overrides.
+// (25.2 / 24.1 / 23.7 / 23.8 ms per step; 1024: 23.5).
 int optimizer_grid(int64_t n) {
-  static const int cap = getenv("SEG_ADAM_BLOCKS") ? atoi(getenv("SEG_ADAM_BLOCKS")) : 1024;
+  constexpr int cap = 1024;
   int64_t blocks = (n + TPB - 1) / TPB;
   if (blocks < 1) blocks = 1;
   if (cap > 0 && blocks > cap) blocks = cap;
