@@ -716,15 +716,20 @@ class SegModel:
         training = self.training if training is None else training
         self._x = self._check_x(x)
         self._enter()
-        ev, k = self._param_events, 0          # optimiser slices still being updated on the side stream (forward order)
+        # optimiser slices still being updated on the side stream: (need, event) in the order the side stream processes them, `need` =
+        # the first op that READS a parameter of the slice - the slice's own first op, or the Conv_Block that carries a fused output
+        # head whose weights live in the slice (_slice_need).  The side stream is in order, so the last event an op needs implies
+        # the earlier ones
+        ev = self._param_events
         main = None if _DryRun.on else torch.cuda.current_stream()
+        plan = self._wait_plan(tuple(e[0] for e in ev)) if ev else {}
         for i, op in enumerate(self.ops):
-            while k < len(ev) and ev[k][0] <= i:       # the optimiser slice that holds this op's parameters has been updated
-                main.wait_event(ev[k][1])
-                k += 1
+            j = plan.get(i)
+            if j is not None:
+                main.wait_event(ev[j][1])
             op.forward(training)
-        for _first, e in ev[k:]:
-            main.wait_event(e)
+        if ev and plan.get(-1) is not None:
+            main.wait_event(ev[-1][1])
         self._param_events = []
         outs = [h.y for h in self.out_heads]
         return [o.squeeze(1) for o in outs] if self.graph.ndim == 1 else outs
@@ -775,6 +780,37 @@ class SegModel:
             out[0][0], out[-1][1] = 0, self.store.P.numel()
             self._adam_slices = [tuple(o) for o in out]
         return self._adam_slices
+
+    def _wait_plan(self, needs: Tuple[int, ...]) -> Dict[int, int]:
+        """{op index: position of the event to wait for in front of that op} for optimiser events with these `need` indices (in
+        side-stream order; the same every step, hence cached); key -1: events nobody needed are awaited at the end of the pass."""
+        cache = getattr(self, "_wait_plan_cache", None)
+        if cache is None or cache[0] != needs:
+            plan, k = {}, 0
+            for i in range(len(self.ops)):
+                j = -1
+                for q in range(k, len(needs)):
+                    if needs[q] <= i:
+                        j = q
+                if j >= 0:
+                    plan[i] = j
+                    k = j + 1
+            if k < len(needs):
+                plan[-1] = len(needs) - 1
+            self._wait_plan_cache = cache = (needs, plan)
+        return cache[1]
+
+    def _slice_need(self, lo: int, hi: int, first_op: int) -> int:
+        """The first op of the forward pass that reads a parameter in [lo, hi) of the flat buffers: the slice's own first op, or -
+        earlier - a Conv_Block whose bn_act_apply pass carries the forward of an output head (ConvOp.heads) whose kernel / bias sit
+        in the slice.  The next forward pass may start an op only after the optimiser has updated every slice it needs."""
+        if getattr(self, "_head_needs", None) is None:
+            self._head_needs = []
+            for i, op in enumerate(self.ops):
+                for h in getattr(op, "heads", ()):
+                    for nm in (h.wname, h.bname):
+                        self._head_needs.append((self.store.slots[nm].off, i))
+        return min([first_op] + [i for off, i in self._head_needs if lo <= off < hi])
 
     def grad_buckets(self) -> List[Tuple[int, int, int]]:
         """[(lo, hi, op_index)]: contiguous slices of the flat gradient buffer, each complete once the backward sweep
@@ -967,7 +1003,7 @@ class SegModel:
                     pos = hi
                     e = torch.cuda.Event()
                     e.record(side)
-                    events.append((first_of.get(lo, 0), e))
+                    events.append((self._slice_need(lo, hi, first_of.get(lo, 0)), e))
                 if pos < n:                        # alignment padding behind the last parameter
                     adam(pos, n)
                     e = torch.cuda.Event()
@@ -995,12 +1031,15 @@ class SegModel:
             side = self.side_stream
             side.wait_stream(torch.cuda.current_stream())
             events = []
+            # (slices in the order the next forward pass needs them: a slice holding the weights of a fused output head is needed by
+            # the Conv_Block that carries the head - level d of UNet++ rides on the FIRST encoder block)
+            order = sorted(self.adam_slices(), key=lambda t: (self._slice_need(*t), t[0]))
             with torch.cuda.stream(side):
-                for lo, hi, first_op in self.adam_slices():
+                for lo, hi, first_op in order:
                     adam(lo, hi)
                     e = torch.cuda.Event()
                     e.record(side)
-                    events.append((first_op, e))
+                    events.append((self._slice_need(lo, hi, first_op), e))
             self._param_events = events
         else:
             if self.allreduce is not None:

@@ -18,6 +18,8 @@ def run():
     torch.cuda.synchronize()
     acts = {n: t.buf.clone() for n, t in model.tensors.items()}
     acts["P16"] = model.store.P16.clone(); acts["P"] = model.store.P.clone(); acts["S"] = model.store.S.clone()
+    for i, h in enumerate(model.out_heads):
+        acts[f"head{i}.y"] = h.y.clone(); acts[f"head{i}.dy"] = h.dy.clone()
     agr = {n: t.grad.clone() for n, t in model.tensors.items() if t.grad is not None}
     return model, model.store.G.clone(), acts, agr
 
