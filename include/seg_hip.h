@@ -227,6 +227,15 @@ int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, con
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate,
                              const seg_head_inject* inj, seg_stream_t stream);
+/* pass 2 for TWO Conv_Blocks that received the same dOut (the 1x1 shortcut block and the 3x3 block of a ResPath iteration,
+ * unet_variants.py:110-112: the add fans one gradient out): dy [npix][C] dense is read once, sets[j].dx = the block's dz (may
+ * alias dy), from its raw conv output sets[j].x and its own coefficients (training-mode form).                           */
+typedef struct {
+  const void* x; void* dx;
+  const float *scale, *shift, *mean, *invstd, *c1, *c2;
+  int32_t act; float alpha;
+} seg_bn_bwd_set;
+int seg_bn_act_bwd_apply2(const void* dy, const seg_bn_bwd_set* sets, int64_t npix, int32_t C, seg_stream_t stream);
 /* pass 2: dx = scale * (g - c1 - xhat*c2)   (training)   or   dx = scale * g   (c1 == NULL: inference BN)     */
 int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
                          int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C,
@@ -491,6 +500,7 @@ int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff,
                                  const float* scale, const float* shift, const float* mean, const float* invstd,
                                  const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate,
                                  const seg_head_inject* inj, seg_stream_t stream);
+int seg_bn_act_bwd_apply2_f32(const void* dy, const seg_bn_bwd_set* sets, int64_t npix, int32_t C, seg_stream_t stream);
 int seg_bn_act_bwd_reduce_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs,
                               int32_t x_coff, int64_t npix, int32_t C, const float* scale, const float* shift,
                               const float* mean, const float* invstd, int32_t act, float alpha, float* partial,

@@ -174,6 +174,38 @@ def test_output_heads_ride_on_the_block_they_read(Cc, pool, nheads, f32):
         assert float((va - vb).abs().max()) < tol * float(va.abs().max())
 
 
+@pytest.mark.parametrize("f32", [True, False])
+def test_pair_apply_equals_two_single_passes(f32):
+    """seg_bn_act_bwd_apply2: the dz of two Conv_Blocks that received the same dOut from ONE pass (the second set writing in place
+    over dOut) - equal to two seg_bn_act_bwd_apply launches up to the contraction of the fused multiply-adds."""
+    sfx = "_f32" if f32 else ""
+    dt = F32 if f32 else torch.float16
+    N, H, W, Cc = 2, 6, 10, 40
+    cs, npix = U.r8(Cc), N * H * W
+    g = torch.Generator().manual_seed(5)
+    dyd = U.to_dev_nhwc(torch.randn(N, H, W, Cc, generator=g), dt)
+    sets = (ffi.BnBwdSet * 2)()
+    keep, singles = [], []
+    for j in range(2):
+        zd = U.to_dev_nhwc(torch.randn(N, H, W, Cc, generator=g), dt)
+        co = [fdev(np.concatenate([torch.randn(Cc, generator=g).numpy() * 0.5 + (1.0 if k in (0, 3) else 0.0), np.zeros(cs - Cc, np.float32)])) for k in range(6)]
+        act = ACT["relu"] if j == 0 else ACT[None]
+        ref = torch.zeros_like(zd)
+        ffi.call("seg_bn_act_bwd_apply" + sfx, P(dyd), cs, 0, P(zd), cs, 0, P(ref), cs, 0, npix, cs, *[P(t) for t in co], act, 0.0, 0, stream())
+        dx = torch.zeros_like(zd) if j == 0 else dyd.clone()       # (set 1: in place over its own copy of dOut)
+        keep += [zd, co, dx]
+        singles.append(ref)
+        d = sets[j]
+        d.x, d.dx, d.scale, d.shift, d.mean, d.invstd, d.c1, d.c2, d.act, d.alpha = (zd.data_ptr(), dx.data_ptr(), *[t.data_ptr() for t in co], act, 0.0)
+    # the pass reads sets[1].dx as dOut: hand it that very buffer
+    ffi.call("seg_bn_act_bwd_apply2" + sfx, P(keep[5]), sets, npix, cs, stream())
+    torch.cuda.synchronize()
+    for got, want in ((keep[2], singles[0]), (keep[5], singles[1])):
+        a, b = U.dev_values(got), U.dev_values(want)
+        assert float((a - b).abs().max()) < (2e-6 if f32 else 2e-3) * float(b.abs().max())
+        assert float(a[..., Cc:].abs().max()) == 0.0
+
+
 def test_fused_tail_add_relu_statistics_and_fanout_backward():
     """seg_add_act_stats_fwd_f32 / seg_bn_bwd_apply_fanout_f32: BN2(ReLU(a + BN1(b))) with BN1 normalised on the fly."""
     N, H, W, Cc = 2, 8, 16, 24

@@ -95,7 +95,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
         lazy = sum(1 for o in m.ops if isinstance(o, M.ConvOp) and o.lazy)
         virt = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.pieces is not None)
         return c, tails, folded, lazy, virt, m
-    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS"):
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS", "TAIL_PAIR_APPLY"):
         monkeypatch.setattr(M.F, sw, False)
     c1, tails, folded, lazy, virt, _m = counts()                                # the round-3 form
     assert tails > 0 and folded > 0 and lazy == 0 and virt == 0
@@ -109,7 +109,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     assert c0["seg_bn_act_bwd_apply"] - c1["seg_bn_act_bwd_apply"] == tails    # replaced by the fan-out form
     # ---- round 4
     monkeypatch.setattr(M.F, "FUSE_BN_TAILS", True)
-    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS"):
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS", "TAIL_PAIR_APPLY"):
         monkeypatch.setattr(M.F, sw, True)
     c2, tails2, folded2, lazy, virt, m = counts()
     assert (tails2, folded2) == (tails, folded) and virt == folded            # every BN(cat) of this model is a virtual concatenation
@@ -121,7 +121,9 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     # BN(cat)'s sums ride on the fan-out launch, and so do those of the Conv_Blocks normalised on load (their dOut is written there)
     assert c1["seg_bn_act_bwd_reduce"] - c2["seg_bn_act_bwd_reduce"] == folded + lazy
     assert c1["seg_bn_bwd_finalize"] == c2["seg_bn_bwd_finalize"]
-    assert c1["seg_bn_act_bwd_apply"] - c2["seg_bn_act_bwd_apply"] == folded    # ... and its input gradient is the scatter
+    # ... its input gradient is the scatter, and the two blocks of a ResPath tail get their dz from ONE pass over the shared gradient
+    pairs = tails - folded
+    assert c1["seg_bn_act_bwd_apply"] - c2["seg_bn_act_bwd_apply"] == folded + 2 * pairs and c2["seg_bn_act_bwd_apply2"] == pairs
     assert not any(isinstance(o, M.ConcatOp) and not o.virtual for o in m.ops)
     # the add's gradient is written once: every second input reads the first one's buffer
     shared = [o for o in m.ops if isinstance(o, M.ConvOp) and o.grad_src is not None]

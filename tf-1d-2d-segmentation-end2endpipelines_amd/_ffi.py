@@ -80,6 +80,11 @@ class LazyBN(C.Structure):
                 ("relu", C.c_int32), ("partial", C.c_void_p)]
 
 
+class BnBwdSet(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dx", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("c1", C.c_void_p), ("c2", C.c_void_p), ("act", C.c_int32), ("alpha", C.c_float)]
+
+
 class HeadFwdDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("w", C.c_void_p * 2), ("b", C.c_void_p * 2), ("act", C.c_int32 * 2), ("y", C.c_void_p * 2)]
 
@@ -108,6 +113,7 @@ _PROTOS = {
     "seg_bn_act_apply_head": ([vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, f32, vp, i32, i32, C.POINTER(HeadFwdDesc), vp], C.c_int),
     "seg_bn_act_bwd_reduce_inj": ([vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, f32, vp, i32, C.POINTER(HeadInject), vp], C.c_int),
     "seg_bn_act_bwd_apply_inj": ([vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, C.POINTER(HeadInject), vp], C.c_int),
+    "seg_bn_act_bwd_apply2": ([vp, C.POINTER(BnBwdSet), i64, i32, vp], C.c_int),
     "seg_bn_act_bwd_reduce": ([vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, f32, vp, i32, vp], C.c_int),
     "seg_bn_bwd_finalize": ([vp, i32, i32, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),
     "seg_bn_act_bwd_apply": ([vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp], C.c_int),
@@ -152,7 +158,7 @@ _PROTOS = {
 }
 
 # entry points that touch activation tensors exist twice: fp16 (throughput mode) and *_f32 (parity mode: split fp16 pairs, 4 B per element)
-DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_apply_head", "seg_bn_act_bwd_reduce_inj", "seg_bn_act_bwd_apply_inj", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
+DUAL = ("seg_igemm_fwd", "seg_igemm_wgrad", "seg_bn_stats", "seg_bn_act_apply", "seg_bn_act_apply_head", "seg_bn_act_bwd_reduce_inj", "seg_bn_act_bwd_apply_inj", "seg_bn_act_bwd_apply2", "seg_bn_act_bwd_reduce", "seg_bn_act_bwd_apply",
         "seg_act_bwd", "seg_maxpool_fwd", "seg_maxpool_bwd", "seg_upsample_fwd", "seg_upsample_bwd", "seg_add_act_fwd",
         "seg_add_act_bwd", "seg_add_act_stats_fwd", "seg_bn_bwd_apply_fanout", "seg_cat_bn_bwd_scatter", "seg_mul_bcast_fwd", "seg_mul_bcast_bwd", "seg_convlstm_gate_fwd", "seg_convlstm_gate_bwd",
         "seg_head_fwd", "seg_head_bwd", "seg_head_act_fwd", "seg_head_act_bwd", "seg_transpose_w", "seg_transpose_w_multi", "seg_pack_input", "seg_unpack_f32", "seg_copy_channels")

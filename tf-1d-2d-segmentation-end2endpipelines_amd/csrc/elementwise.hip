@@ -477,6 +477,62 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const T* dy, int 
   }
 }
 
+// The same pass for TWO Conv_Blocks that received the SAME dOut (the two inputs of a fused ResPath tail, unet_variants.py:110-112:
+// the add hands one gradient to the 1x1 shortcut block and to the 3x3 block): dOut is read once, both dz are written.  dx of a set
+// may alias dy (each thread reads its elements before it writes them).
+struct BwdSet { const void* x; void* dx; const float *scale, *shift, *mean, *invstd, *c1, *c2; int act; float alpha; };
+struct BwdSet2 { BwdSet s[2]; };
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_act_bwd_apply2_kernel(const T* dy, BwdSet2 bs, int64_t npix, int C, ColLayout L) {
+  constexpr int UN = 2;
+  const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
+  const int64_t chunk = (int64_t)L.RP * UN;
+  for (int grp = 0; grp < L.ngrp; ++grp) {
+    const int ch = grp * L.CHP + col;
+    if (ch >= L.CH) continue;
+    float sc[2][8], sh[2][8], ka[2][8], kb[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c = ch * 8 + t;
+        sc[j][t] = bs.s[j].scale[c];
+        sh[j][t] = bs.s[j].shift[c];
+        const float k = bs.s[j].invstd[c] * bs.s[j].c2[c];
+        ka[j][t] = -sc[j][t] * k;
+        kb[j][t] = sc[j][t] * (bs.s[j].mean[c] * k - bs.s[j].c1[c]);
+      }
+    for (int64_t pb = blockIdx.x * chunk + rowi; pb < npix; pb += chunk * gridDim.x) {
+      float g[UN][8], xv[2][UN][8];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int64_t pix = pb + (int64_t)u * L.RP;
+        if (pix < npix) {
+          load8(dy + pix * C + ch * 8, g[u]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) load8((const T*)bs.s[j].x + pix * C + ch * 8, xv[j][u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int64_t pix = pb + (int64_t)u * L.RP;
+        if (pix >= npix) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float o[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float yv = seg_act(xv[j][u][t] * sc[j][t] + sh[j][t], bs.s[j].act, bs.s[j].alpha);
+            const float gg = g[u][t] * seg_act_grad_from_out(yv, bs.s[j].act, bs.s[j].alpha);
+            o[t] = gg * sc[j][t] + xv[j][u][t] * ka[j][t] + kb[j][t];
+          }
+          store8((T*)bs.s[j].dx + pix * C + ch * 8, o);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ activation backward
 template <typename T>
 __global__ __launch_bounds__(TPB) void act_bwd_kernel(const T* dy, const T* y, T* dx, int64_t npix, int cs, int C,
@@ -2083,6 +2139,25 @@ extern "C" int seg_bn_act_bwd_apply(const void* dy, int32_t dy_cs, int32_t dy_co
 extern "C" int seg_bn_act_bwd_apply_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, nullptr, stream); }
 extern "C" int seg_bn_act_bwd_apply_inj(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<half_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
 extern "C" int seg_bn_act_bwd_apply_inj_f32(const void* dy, int32_t dy_cs, int32_t dy_coff, const void* x, int32_t x_cs, int32_t x_coff, void* dx, int32_t dx_cs, int32_t dx_coff, int64_t npix, int32_t C, const float* scale, const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, int32_t act, float alpha, int32_t accumulate, const seg_head_inject* inj, seg_stream_t stream) { return seg_bn_act_bwd_apply_impl<split_t>(dy, dy_cs, dy_coff, x, x_cs, x_coff, dx, dx_cs, dx_coff, npix, C, scale, shift, mean, invstd, c1, c2, act, alpha, accumulate, inj, stream); }
+
+template <typename T>
+static int seg_bn_act_bwd_apply2_impl(const void* dy, const seg_bn_bwd_set* sets, int64_t npix, int32_t C, seg_stream_t stream) {
+  SEG_CHECK_ARG(dy && sets && npix > 0 && C > 0 && (C & 7) == 0, "seg_bn_act_bwd_apply2: bad arguments");
+  BwdSet2 bs;
+  for (int j = 0; j < 2; ++j) {
+    const seg_bn_bwd_set& q = sets[j];
+    SEG_CHECK_ARG(q.x && q.dx && q.scale && q.shift && q.mean && q.invstd && q.c1 && q.c2, "seg_bn_act_bwd_apply2: set %d", j);
+    bs.s[j] = BwdSet{q.x, q.dx, q.scale, q.shift, q.mean, q.invstd, q.c1, q.c2, q.act, q.alpha};
+  }
+  const ColLayout L = col_layout(C);
+  int64_t blocks = (npix + (int64_t)L.RP * 2 - 1) / ((int64_t)L.RP * 2);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL((bn_act_bwd_apply2_kernel<T>), dim3((int)blocks), dim3(TPB), 0, ST(stream), (const T*)dy, bs, npix, C, L);
+  SEG_CHECK_LAUNCH("seg_bn_act_bwd_apply2");
+  return SEG_OK;
+}
+extern "C" int seg_bn_act_bwd_apply2(const void* dy, const seg_bn_bwd_set* sets, int64_t npix, int32_t C, seg_stream_t stream) { return seg_bn_act_bwd_apply2_impl<half_t>(dy, sets, npix, C, stream); }
+extern "C" int seg_bn_act_bwd_apply2_f32(const void* dy, const seg_bn_bwd_set* sets, int64_t npix, int32_t C, seg_stream_t stream) { return seg_bn_act_bwd_apply2_impl<split_t>(dy, sets, npix, C, stream); }
 
 template <typename T>
 static int seg_act_bwd_impl(const void* dy, const void* y, void* dx, int64_t npix, int32_t cs, int32_t C, int32_t act, float alpha,

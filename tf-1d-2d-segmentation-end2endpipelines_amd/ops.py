@@ -298,6 +298,7 @@ class ConvOp(Op):
         self.lazy = False            # training: `out` is never written - its only consumer (a fused add) normalises z on load
         self.grad_src: Optional[DevTensor] = None      # backward: dOut is read from this tensor's gradient (shared with a sibling)
         self.tail_sums = 0           # backward: > 0 = a fused tail's fan-out launch already left this BN's two sums in `bpart` (that many rows)
+        self.bn_bwd_done = False     # backward: the tail also ran this block's finalize + apply (one pass for both blocks of a ResPath tail)
         self.heads: List["HeadOp"] = []            # one-channel output heads on `out` (at most two) whose forward rides on this block's bn_act_apply
         self._head_desc = None
         self.head_done = False                     # ... did so in the forward pass just run (not in the one-launch inference form)
@@ -521,15 +522,16 @@ class ConvOp(Op):
             inj = self.head_inj
             if inj is not None and not self.has_dout:
                 src = None                    # the injected head is the only consumer: no gradient tensor to read
-            if not self.tail_sums:
-                call("seg_bn_act_bwd_reduce" + ("_inj" if inj is not None else ""), src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0,
-                     self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act],
-                     float(self.alpha), _p(self.bpart), F.BN_PARTS_BWD, *((C.byref(inj),) if inj is not None else ()), s)
-            call("seg_bn_bwd_finalize", _p(self.bpart), self.tail_sums or F.BN_PARTS_BWD, self.n_rows, self.z.npix, st.ptr(bn + "/gamma", "G"),
-                 st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
-            call("seg_bn_act_bwd_apply" + ("_inj" if inj is not None else ""), src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA),
-                 self.out.cs, 0, self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
-                 _p(self.c2), ACT[self.act], float(self.alpha), 0, *((C.byref(inj),) if inj is not None else ()), s)
+            if not self.bn_bwd_done:          # (else: dz is already in dA - AddOp.pair ran the finalize and one apply pass for both blocks)
+                if not self.tail_sums:
+                    call("seg_bn_act_bwd_reduce" + ("_inj" if inj is not None else ""), src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0,
+                         self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), ACT[self.act],
+                         float(self.alpha), _p(self.bpart), F.BN_PARTS_BWD, *((C.byref(inj),) if inj is not None else ()), s)
+                call("seg_bn_bwd_finalize", _p(self.bpart), self.tail_sums or F.BN_PARTS_BWD, self.n_rows, self.z.npix,
+                     st.ptr(bn + "/gamma", "G"), st.ptr(bn + "/beta", "G"), 1.0, gs_inv, _p(self.c1), _p(self.c2), s)
+                call("seg_bn_act_bwd_apply" + ("_inj" if inj is not None else ""), src, self.out.cs, 0, _p(self.z.buf), self.z.cs, 0, _p(dA),
+                     self.out.cs, 0, self.z.npix, self.n_rows, _p(self.scale), _p(self.shift), _p(self.mean), _p(self.invstd), _p(self.c1),
+                     _p(self.c2), ACT[self.act], float(self.alpha), 0, *((C.byref(inj),) if inj is not None else ()), s)
             dz = dA
         elif self.kind == "convlstm":
             dz = self.z.ensure_grad()
@@ -902,6 +904,13 @@ class BNOp(Op):
                  C.byref(vb.cat) if vb is not None else None, _p(vb.mean) if vb is not None else None,
                  _p(vb.invstd) if vb is not None else None, _p(vb.bpart) if vb is not None else None,
                  a.lazy_descs, a.n_lazy_descs, self.cat_parts, s)
+            if a.pair is not None:
+                # both Conv_Blocks behind the add read this one gradient: their finalize launches, then ONE pass that reads it
+                # once and writes both dz (ConvOp.backward then goes straight to the weight / data gradients)
+                for cv in a.pair:
+                    call("seg_bn_bwd_finalize", _p(cv.bpart), cv.tail_sums, cv.n_rows, cv.z.npix, st.ptr(cv.bn_name + "/gamma", "G"),
+                         st.ptr(cv.bn_name + "/beta", "G"), 1.0, gs_inv, _p(cv.c1), _p(cv.c2), s)
+                call("seg_bn_act_bwd_apply2", _p(a.tail_grad.grad), a.pair_sets, x.npix, self.C, s)
             return
         if self.acc is None:          # the input needs no gradient (a BN placed on the network input): gamma / beta are done
             return
@@ -957,6 +966,7 @@ class AddOp(Op):
         self.virtual_bn: Optional[BNOp] = None        # the folded BatchNormalization whose input is a virtual concatenation
         self.tail_grad: Optional[DevTensor] = None    # backward: the input whose gradient buffer holds THE gradient of the add
         self.lazy_descs, self.n_lazy_descs = None, 0  # backward: seg_lazy_bn of the Conv_Blocks whose BN-backward sums ride on the fan-out
+        self.pair, self.pair_sets = None, None        # backward: the two Conv_Blocks whose dz come out of one pass over the shared gradient
 
     def fuse(self, bn: "BNOp"):
         """Argument sets of the fused forward launch: [training] reads lazy Conv_Blocks from their raw conv output, [inference]
@@ -1041,6 +1051,16 @@ class AddOp(Op):
                     d.relu, d.partial = (1 if ACT[cv.act] == ACT["relu"] else 0), cv.bpart.data_ptr()
                     cv.tail_sums = parts
                 self.lazy_descs, self.n_lazy_descs = arr, len(cvs)
+                # the ResPath form - two blocks, one shared gradient buffer (the second block reads the first one's): one apply pass
+                if (F.TAIL_PAIR_APPLY and share and len(cvs) == 2 and len(self.xs) == 2 and cvs[1].grad_src is self.xs[0]
+                        and cvs[0].out is self.xs[0] and all(cv.head_inj is None for cv in cvs)):
+                    sets = (_ffi.BnBwdSet * 2)()
+                    for d, cv in zip(sets, cvs):
+                        d.x, d.dx = cv.z.buf.data_ptr(), cv.out.ensure_grad().data_ptr()
+                        d.scale, d.shift, d.mean, d.invstd = cv.scale.data_ptr(), cv.shift.data_ptr(), cv.mean.data_ptr(), cv.invstd.data_ptr()
+                        d.c1, d.c2, d.act, d.alpha = cv.c1.data_ptr(), cv.c2.data_ptr(), ACT[cv.act], float(cv.alpha)
+                        cv.bn_bwd_done = True
+                    self.pair, self.pair_sets = cvs, sets
 
     def backward(self):
         if self.live and self.fused_bn is None:       # (fused tail: the BatchNormalization's backward wrote the inputs' gradients)
