@@ -471,6 +471,9 @@ def main():
                     "traffic_source": traffic_src, "launches": d_["launches"],
                     "avg_launch_us": d_["seconds"] / d_["launches"] * 1e6,
                     "algorithmic_flops_per_launch": d_["flops"] / d_["launches"],
+                    "algorithmic_bytes_per_launch": d_["bytes"] / d_["launches"],
+                    "algorithmic_bytes_what": "input + output + weights of the launch, logical channels, every operand once, in the storage format "
+                                              "(compare with `traffic`, the PMC figure)",
                     "step_share": d_["seconds"] / tot_s,
                     "gemm": gemm_summary(KP, peak),
                     "gemm_seconds_of_each_profiled_pass": gemm_pass_s, "pass_reported": "median",

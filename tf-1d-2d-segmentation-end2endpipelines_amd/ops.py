@@ -292,6 +292,11 @@ class ConvOp(Op):
         pix_taps = self.N * self.g_fwd.Hl * self.g_fwd.Wl * self.g_fwd.ncls * self.g_fwd.ntaps
         self.flops_fwd = 2.0 * pix_taps * sum(cin_l) * self.cout
         self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
+        # algorithmic HBM bytes of a launch (logical channels, every operand once): input + output + weights, in the storage format
+        esz = self.esz = 2 if m.dtype == "f16" else 4
+        self.in_pix, self.out_pix = N * H * W, N * Ho * Wo
+        self.bytes_fwd = float(esz * (self.in_pix * sum(cin_l) + self.out_pix * self.cout + self.T * sum(cin_l) * self.cout))
+        self.bytes_seg = [float(esz * (self.in_pix * c + self.out_pix * self.cout + self.T * c * self.cout)) for c in cin_l]
         self.wt = torch.zeros(Kpad * self.T * self.rows_pad, dtype=DevTensor.dtype, device=dev) if any(self.need_dgrad) else None
         self.fwd_args = None
         self.gathered: Dict[int, "GatherDgrad"] = {}      # segment index -> gathered data gradient that covers it
@@ -399,7 +404,7 @@ class ConvOp(Op):
                      st.ptr(bn + "/moving_variance"), self.eps, st.ptr(self.bname, "P") if self.bname else None, self.n_rows,
                      _p(self.inf_scale), _p(self.inf_shift), s)
                 self._infer_valid = True
-            call("seg_igemm_fwd", C.byref(self.fwd_args_infer), s, flops=self.flops_fwd, tag="fwd:" + self.node.name)
+            call("seg_igemm_fwd", C.byref(self.fwd_args_infer), s, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="fwd:" + self.node.name)
             if self.pooled is not None:
                 call("seg_maxpool_fwd", _p(self.out.buf), _p(self.pooled.buf), self.out.N, self.out.H, self.out.W, self.out.cs,
                      self.pool_size[0], self.pool_size[1], s)
@@ -407,7 +412,7 @@ class ConvOp(Op):
         a = self.fwd_args if (training and self.has_bn) else self.fwd_args_eval
         if training and self.has_bn:
             self._infer_valid = False      # (this pass updates the moving statistics)
-        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, tag="fwd:" + self.node.name)
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="fwd:" + self.node.name)
         if self.has_bn:
             bn = self.bn_name
             call("seg_bn_finalize", _p(self.stats), self.nparts, self.n_rows, self.z.npix, st.ptr(bn + "/gamma"),
@@ -470,7 +475,7 @@ class ConvOp(Op):
         # split back onto the segment tensors by the epilogue.  Segments whose tensor is handled by a gathered data
         # gradient (GatherDgrad: one launch per tensor over all its consuming convs) or needs no gradient are left
         # out: each run of consecutive remaining segments is one launch on that row range of the transposed weight
-        self.dg_args = []
+        self.dg_args, self.dg_bytes = [], []
         own = [t.needs_grad and s_i not in self.gathered for s_i, (t, _c) in enumerate(self.segs)]
         s_i = 0
         while s_i < len(self.segs):
@@ -491,18 +496,20 @@ class ConvOp(Op):
             a.out, a.out_cs, a.out_coff, a.accumulate = None, 0, 0, 0
             a.bias, a.act, a.alpha, a.stats = None, 0, 0.0, None
             a.nout = e_i - s_i
-            zero_first, fl = [], 0.0
+            zero_first, fl, nb = [], 0.0, 0.0
             for o_i, (t, _c) in enumerate(self.segs[s_i:e_i]):
                 a.out_span[o_i], a.out_cs_o[o_i] = _r32(t.cs), t.cs
                 acc = t.claim((a, o_i))
                 a.out_ptr[o_i], a.out_acc[o_i] = t.grad.data_ptr(), acc
                 fl += self.flops_seg[s_i + o_i]
+                nb += self.esz * (self.in_pix * _c + self.T * _c * self.cout)          # dx of the segment written, its weight slice read
                 if self.strided and not acc:
                     zero_first.append(t)
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
             a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
             self.m.fwd_ws_users.append(a)
             self.dg_args.append((a, zero_first, fl))
+            self.dg_bytes.append(float(nb + self.esz * self.out_pix * self.cout))          # ... and dz read once
             s_i = e_i
         for grp in self.gather_launch:       # gathered data gradients this op launches (it is their last-running consumer)
             grp.plan()
@@ -545,7 +552,7 @@ class ConvOp(Op):
             self._bias_grad(dz, s, gs_inv)
         self.wg_args.dz = dz.data_ptr()
         def wgrad(stream):
-            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, tag="wgrad:" + self.node.name)
+            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="wgrad:" + self.node.name)
             if self.bias_from_wgrad:
                 call("seg_bn_bwd_finalize", _p(self.wg_bpart), self.wg_bias_parts, self.n_rows, self.z.npix, None, st.ptr(self.bname, "G"),
                      1.0, gs_inv, _p(self.c1), _p(self.c2), stream)
@@ -559,11 +566,11 @@ class ConvOp(Op):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 wgrad(_stream())
-        for a, zero_first, fl in self.dg_args:
+        for (a, zero_first, fl), nb in zip(self.dg_args, self.dg_bytes):
             for t in zero_first:
                 t.grad.zero_()
             a.seg_ptr[0] = dz.data_ptr()
-            call("seg_igemm_fwd", C.byref(a), s, flops=fl, tag="dgrad:" + self.node.name)
+            call("seg_igemm_fwd", C.byref(a), s, flops=fl, nbytes=nb, tag="dgrad:" + self.node.name)
         self.dz_ptr = dz.data_ptr()
         for grp in self.gather_launch:
             grp.launch(s)
@@ -620,12 +627,14 @@ class GatherDgrad:
         self.m.fwd_ws_users.append(a)
         self.args = a
         self.flops = sum(op.flops_seg[si] for op, si in self.members)
+        op0_ = self.members[0][0]
+        self.nbytes = float(op0_.esz * (op0_.in_pix * self.t.C + sum(op.out_pix * op.cout + op.T * self.t.C * op.cout for op, _si in self.members)))
 
     def launch(self, s):
         a = self.args
         for j, (op, _si) in enumerate(self.members):
             a.seg_ptr[j] = op.dz_ptr
-        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops, tag="dgrad:gather:" + self.t.name)
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops, nbytes=self.nbytes, tag="dgrad:gather:" + self.t.name)
 
 
 def plan_gathers(m, ops) -> List[GatherDgrad]:
