@@ -180,7 +180,7 @@ def test_pair_apply_equals_two_single_passes(f32):
     over dOut) - equal to two seg_bn_act_bwd_apply launches up to the contraction of the fused multiply-adds."""
     sfx = "_f32" if f32 else ""
     dt = F32 if f32 else torch.float16
-    N, H, W, Cc = 2, 6, 10, 40
+    N, H, W, Cc = 2, 6, 10, 44
     cs, npix = U.r8(Cc), N * H * W
     g = torch.Generator().manual_seed(5)
     dyd = U.to_dev_nhwc(torch.randn(N, H, W, Cc, generator=g), dt)
