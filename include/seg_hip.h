@@ -306,7 +306,12 @@ typedef struct {
 } seg_lazy_bn;
 int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n,
                           const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,
-                          int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
+                          int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff,
+                          seg_stream_t stream);
+/* stats_ld / stats_coff (0 / 0 = the tensor's own rows [nparts][2][cs]): the partial rows have stats_ld columns and this launch fills
+ * columns stats_coff .. stats_coff + c_valid - with n = 1, one pre-affine input and act = none the call is "bn_act_apply that also
+ * delivers the statistics of what it writes": a piece of a virtual concatenation (c3 / c5 / c7 of a MultiResBlock) hands its sums to
+ * the BatchNormalization over the concatenation on its way out (same nparts for all pieces), no pass over the pieces afterwards.   */
 int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
                             int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
                             int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,
@@ -526,7 +531,8 @@ int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t
                         float alpha, int32_t accumulate_mask, seg_stream_t stream);
 int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus,
                               int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix,
-                              int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream);
+                              int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, int32_t stats_ld,
+                              int32_t stats_coff, seg_stream_t stream);
 int seg_bn_bwd_apply_fanout_f32(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix,
                                 int32_t cs, const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
                                 int32_t relu_mask, const seg_cat_desc* cat, const float* cat_mean, const float* cat_invstd,

@@ -221,7 +221,7 @@ def test_fused_tail_add_relu_statistics_and_fanout_backward():
     y = torch.zeros_like(ad)
     nparts = 5
     stats = torch.zeros(nparts * 2 * cs, device="cuda")
-    ffi.call("seg_add_act_stats_fwd_f32", xs, scs, shs, None, 2, None, None, None, P(y), npix, cs, Cc, ACT["relu"], 0.0, P(stats), nparts, stream())
+    ffi.call("seg_add_act_stats_fwd_f32", xs, scs, shs, None, 2, None, None, None, P(y), npix, cs, Cc, ACT["relu"], 0.0, P(stats), nparts, 0, 0, stream())
     torch.cuda.synchronize()
     s = torch.relu(a + b * s1 + h1)
     assert rel(val(y, Cc), s) < TOL
@@ -282,11 +282,27 @@ def test_multires_tail_over_a_virtual_concatenation(chans, W, f32):
     # ---- statistics of the concatenation (the operand of BN1's finalize)
     nparts = 6
     st1 = torch.full((nparts * 2 * cs,), 9.0, device="cuda")
-    ffi.call("seg_add_act_stats_fwd" + sfx, None, None, None, None, 0, C.byref(cat), None, None, None, npix, cs, Cc, 0, 0.0, P(st1), nparts, stream())
+    ffi.call("seg_add_act_stats_fwd" + sfx, None, None, None, None, 0, C.byref(cat), None, None, None, npix, cs, Cc, 0, 0.0, P(st1), nparts, 0, 0, stream())
     catv = torch.cat(pieces, -1)
     s1 = st1.reshape(nparts, 2, cs).sum(0).cpu()
     assert rel(s1[0, :Cc], catv.sum((0, 1, 2))) < 1e-5 and rel(s1[1, :Cc], (catv * catv).sum((0, 1, 2))) < 1e-5
     assert float(s1[:, Cc:].abs().max()) == 0.0 if cs > Cc else True
+    # ... and the same rows written piece by piece from the pieces' own apply passes (n = 1, stats_ld / stats_coff): the form the engine
+    # uses - here with an identity affine, so that the pass re-writes the piece and its sums are the piece's
+    st3 = torch.zeros(nparts * 2 * cs, device="cuda")
+    off = 0
+    for t, c in zip(pdev, chans):
+        pcs_ = t.shape[3]
+        one, zero = fdev(np.ones(pcs_, np.float32)), fdev(np.zeros(pcs_, np.float32))
+        outp = torch.full_like(t, 6.0)
+        x1 = (C.c_void_p * 4)(t.data_ptr(), None, None, None)
+        s1_, h1_ = (C.c_void_p * 4)(one.data_ptr(), None, None, None), (C.c_void_p * 4)(zero.data_ptr(), None, None, None)
+        ffi.call("seg_add_act_stats_fwd" + sfx, x1, s1_, h1_, (C.c_int32 * 4)(0, 0, 0, 0), 1, None, None, None, P(outp), npix, pcs_, c, 0, 0.0, P(st3), nparts, cs, off, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(U.dev_values(outp)[..., :c], U.dev_values(t)[..., :c]) and (pcs_ == c or float(U.dev_values(outp)[..., c:].abs().max()) == 0.0)
+        off += c
+    s3 = st3.reshape(nparts, 2, cs).sum(0).cpu()
+    assert rel(s3[:, :Cc], s1[:, :Cc]) < 1e-5 and (cs == Cc or float(s3[:, Cc:].abs().max()) == 0.0)
     # ---- reference graph
     prs = [t.clone().requires_grad_(True) for t in pieces]
     zar = za.clone().requires_grad_(True)
@@ -310,7 +326,7 @@ def test_multires_tail_over_a_virtual_concatenation(chans, W, f32):
     relus = (C.c_int32 * 4)(1, 0, 0, 0)
     y = torch.full_like(zad, 5.0)
     st2 = torch.zeros(nparts * 2 * cs, device="cuda")
-    ffi.call("seg_add_act_stats_fwd" + sfx, xs, scs, shs, relus, 1, C.byref(cat), P(keep[2]), P(keep[3]), P(y), npix, cs, Cc, ACT["relu"], 0.0, P(st2), nparts, stream())
+    ffi.call("seg_add_act_stats_fwd" + sfx, xs, scs, shs, relus, 1, C.byref(cat), P(keep[2]), P(keep[3]), P(y), npix, cs, Cc, ACT["relu"], 0.0, P(st2), nparts, 0, 0, stream())
     torch.cuda.synchronize()
     yv = U.dev_values(y)
     assert rel(yv[..., :Cc], s.detach()) < (2e-6 if f32 else 2e-3)

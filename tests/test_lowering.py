@@ -95,7 +95,7 @@ def test_multires_tails_are_fused_passes(monkeypatch):
         lazy = sum(1 for o in m.ops if isinstance(o, M.ConvOp) and o.lazy)
         virt = sum(1 for o in m.ops if isinstance(o, M.BNOp) and o.pieces is not None)
         return c, tails, folded, lazy, virt, m
-    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS", "TAIL_PAIR_APPLY"):
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS", "TAIL_PAIR_APPLY", "TAIL_PIECE_STATS"):
         monkeypatch.setattr(M.F, sw, False)
     c1, tails, folded, lazy, virt, _m = counts()                                # the round-3 form
     assert tails > 0 and folded > 0 and lazy == 0 and virt == 0
@@ -109,14 +109,16 @@ def test_multires_tails_are_fused_passes(monkeypatch):
     assert c0["seg_bn_act_bwd_apply"] - c1["seg_bn_act_bwd_apply"] == tails    # replaced by the fan-out form
     # ---- round 4
     monkeypatch.setattr(M.F, "FUSE_BN_TAILS", True)
-    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS", "TAIL_PAIR_APPLY"):
+    for sw in ("TAIL_LAZY_INPUTS", "TAIL_SHARED_GRAD", "TAIL_VIRTUAL_CAT", "TAIL_LAZY_SUMS", "TAIL_PAIR_APPLY", "TAIL_PIECE_STATS"):
         monkeypatch.setattr(M.F, sw, True)
     c2, tails2, folded2, lazy, virt, m = counts()
     assert (tails2, folded2) == (tails, folded) and virt == folded            # every BN(cat) of this model is a virtual concatenation
     assert lazy == 2 * (tails - folded) + folded                                # ResPath: shortcut + conv; MultiResBlock: the shortcut
-    assert c1["seg_bn_act_apply"] - c2["seg_bn_act_apply"] == lazy
+    # (the three pieces of every virtual concatenation run their apply pass in the tail kernel's one-input form, which also delivers
+    # their columns of BN(cat)'s statistics: no separate pass over the pieces)
+    assert c1["seg_bn_act_apply"] - c2["seg_bn_act_apply"] == lazy + 3 * folded
     assert c2["seg_copy_channels"] == 0 and c1["seg_copy_channels"] == 2 * 3 * folded      # three pieces, forward and backward
-    assert c2["seg_bn_stats"] == c1["seg_bn_stats"] - folded and c2["seg_add_act_stats_fwd"] == tails + folded
+    assert c2["seg_bn_stats"] == c1["seg_bn_stats"] - folded and c2["seg_add_act_stats_fwd"] == tails + 3 * folded
     assert c2["seg_cat_bn_bwd_scatter"] == folded
     # BN(cat)'s sums ride on the fan-out launch, and so do those of the Conv_Blocks normalised on load (their dOut is written there)
     assert c1["seg_bn_act_bwd_reduce"] - c2["seg_bn_act_bwd_reduce"] == folded + lazy

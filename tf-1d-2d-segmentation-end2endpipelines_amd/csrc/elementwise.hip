@@ -867,11 +867,15 @@ __device__ __forceinline__ void cat_gather(const CatDev* cd, int64_t p0, int TP,
 
 template <typename T, bool GATHER, int NIN>
 __global__ __launch_bounds__(TPB) void tail_fwd_kernel(Ptr4<T> xs, Aff4 aff, int n, CatDev cdv, const float* cat_sc, const float* cat_sh, T* y,
-                                                       int64_t npix, int cs, int c_valid, int act, float alpha, float* stats, ColLayout L) {
-  __shared__ float sm[GATHER ? TPB * 8 * UNR : TPB * 8];
+                                                       int64_t npix, int cs, int c_valid, int act, float alpha, float* stats, int stats_ld,
+                                                       int stats_coff, ColLayout L) {
+  // (gathering form: two pixels per thread instead of four - 16 KB instead of 32 KB of LDS tile and ~60 registers less, so that
+  // three or four blocks per CU overlap one block's gather phase with another's compute phase)
+  constexpr int UN = GATHER ? 2 : UNR;
+  __shared__ float sm[GATHER ? TPB * 8 * UN : TPB * 8];
   __shared__ CatDev scd;
   const int col = threadIdx.x % L.CHP, rowi = threadIdx.x / L.CHP;
-  const int TP = L.RP * UNR;
+  const int TP = L.RP * UN;
   const int ch = col;                       // (the host launches this kernel for cs <= 8 * TPB only: one column group)
   if (GATHER) {
     if (threadIdx.x == 0) scd = cdv;
@@ -900,16 +904,16 @@ __global__ __launch_bounds__(TPB) void tail_fwd_kernel(Ptr4<T> xs, Aff4 aff, int
       __syncthreads();
     }
     if (ch >= L.CH) continue;
-    float f[NIN][UNR][8];
+    float f[NIN][UN][8];
 #pragma unroll
     for (int k = 0; k < NIN; ++k)
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
+      for (int u = 0; u < UN; ++u) {
         const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
         if (k < n && pix < npix) load8(xs.p[k] + pix * cs + ch * 8, f[k][u]);
       }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int64_t pix = p0 + rowi + (int64_t)u * L.RP;
       if (pix >= npix) continue;
       float o[8];
@@ -941,11 +945,14 @@ __global__ __launch_bounds__(TPB) void tail_fwd_kernel(Ptr4<T> xs, Aff4 aff, int
   }
   __syncthreads();
   block_col_reduce<2>(acc, sm, rowi, col, L.CHP, L.RP);
+  // (stats_ld / stats_coff: the rows of another tensor's statistics - a piece of a virtual concatenation writes its VALID channels into
+  // the columns of the concatenation, the operand of the BatchNormalization over it)
   if (rowi == 0 && ch < L.CH) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      stats[((size_t)blockIdx.x * 2 + 0) * cs + ch * 8 + t] = acc[0][t];
-      stats[((size_t)blockIdx.x * 2 + 1) * cs + ch * 8 + t] = acc[1][t];
+      if (stats_ld != cs && ch * 8 + t >= c_valid) continue;
+      stats[((size_t)blockIdx.x * 2 + 0) * stats_ld + stats_coff + ch * 8 + t] = acc[0][t];
+      stats[((size_t)blockIdx.x * 2 + 1) * stats_ld + stats_coff + ch * 8 + t] = acc[1][t];
     }
   }
 }
@@ -2273,7 +2280,10 @@ static int cat_to_dev(const seg_cat_desc* cat, int32_t cs, bool backward, CatDev
 template <typename T>
 static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n,
                                       const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,
-                                      int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) {
+                                      int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff,
+                                      seg_stream_t stream) {
+  if (stats_ld <= 0) { stats_ld = cs; stats_coff = 0; }
+  SEG_CHECK_ARG(stats_coff >= 0 && stats_coff + (stats_ld == cs ? cs : c_valid) <= stats_ld, "seg_add_act_stats_fwd: statistics columns %d + %d of %d", stats_coff, c_valid, stats_ld);
   SEG_CHECK_ARG(stats && n >= 0 && n <= 4 && (n > 0 || cat != nullptr) && (n == 0 || xs != nullptr) && npix > 0 && cs > 0 && (cs & 7) == 0 &&
                 cs <= 8 * TPB && nparts > 0 && c_valid > 0 && c_valid <= cs && (cat_scale == nullptr) == (cat_shift == nullptr),
                 "seg_add_act_stats_fwd: bad arguments (n=%d cs=%d)", n, cs);
@@ -2291,15 +2301,15 @@ static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const*
   const ColLayout L = col_layout(cs);
 #define LAUNCH_TAIL_FWD(G, NIN)                                                                                                          \
   hipLaunchKernelGGL((tail_fwd_kernel<T, G, NIN>), dim3(nparts), dim3(TPB), 0, ST(stream), p, a, n, cd, cat_scale, cat_shift, (T*)y, npix, cs, \
-                     c_valid, act, alpha, stats, L)
+                     c_valid, act, alpha, stats, stats_ld, stats_coff, L)
   if (cat != nullptr) { if (n <= 2) LAUNCH_TAIL_FWD(true, 2); else LAUNCH_TAIL_FWD(true, 4); }
   else { if (n <= 2) LAUNCH_TAIL_FWD(false, 2); else LAUNCH_TAIL_FWD(false, 4); }
 #undef LAUNCH_TAIL_FWD
   SEG_CHECK_LAUNCH("seg_add_act_stats_fwd");
   return SEG_OK;
 }
-extern "C" int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<half_t>(xs, scales, shifts, relus, n, cat, cat_scale, cat_shift, y, npix, cs, c_valid, act, alpha, stats, nparts, stream); }
-extern "C" int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<split_t>(xs, scales, shifts, relus, n, cat, cat_scale, cat_shift, y, npix, cs, c_valid, act, alpha, stats, nparts, stream); }
+extern "C" int seg_add_act_stats_fwd(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<half_t>(xs, scales, shifts, relus, n, cat, cat_scale, cat_shift, y, npix, cs, c_valid, act, alpha, stats, nparts, stats_ld, stats_coff, stream); }
+extern "C" int seg_add_act_stats_fwd_f32(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n, const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs, int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff, seg_stream_t stream) { return seg_add_act_stats_fwd_impl<split_t>(xs, scales, shifts, relus, n, cat, cat_scale, cat_shift, y, npix, cs, c_valid, act, alpha, stats, nparts, stats_ld, stats_coff, stream); }
 
 template <typename T>
 static int seg_bn_bwd_apply_fanout_impl(const void* dy, const void* x, void* const* dxs, int32_t n, int32_t accumulate_mask, int64_t npix, int32_t cs,

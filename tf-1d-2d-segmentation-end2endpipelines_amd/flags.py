@@ -21,6 +21,7 @@ TAIL_LAZY_INPUTS = os.environ.get("SEG_TAIL_LAZY_INPUTS", "1") != "0"       # a 
 TAIL_SHARED_GRAD = os.environ.get("SEG_TAIL_SHARED_GRAD", "1") != "0"       # the add's gradient is written once; the Conv_Blocks behind it read the one buffer
 TAIL_VIRTUAL_CAT = os.environ.get("SEG_TAIL_VIRTUAL_CAT", "1") != "0"       # MultiResBlock's cat[c3, c5, c7] exists only in the tail kernels' LDS tiles
 TAIL_LAZY_SUMS = os.environ.get("SEG_TAIL_LAZY_SUMS", "1") != "0"           # the BN-backward sums of those Conv_Blocks ride on the tail's fan-out launch (no reduce pass)
+TAIL_PIECE_STATS = os.environ.get("SEG_TAIL_PIECE_STATS", "1") != "0"       # the pieces of a virtual concatenation hand BN(cat) their sums from their own apply pass
 TAIL_PAIR_APPLY = os.environ.get("SEG_TAIL_PAIR_APPLY", "1") != "0"         # ... and the two blocks of a ResPath tail get their dz from ONE pass over the shared dOut
 GATHER_DGRAD = os.environ.get("SEG_GATHER_DGRAD", "1") != "0"
 GATHER_DGRAD_1X1 = os.environ.get("SEG_GATHER_DGRAD_1X1", "1") != "0"       # the 1x1 shortcut conv joins the gathered data gradient of its 3x3 sibling

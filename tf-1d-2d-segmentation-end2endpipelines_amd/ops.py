@@ -303,6 +303,8 @@ class ConvOp(Op):
         self.lazy = False            # training: `out` is never written - its only consumer (a fused add) normalises z on load
         self.grad_src: Optional[DevTensor] = None      # backward: dOut is read from this tensor's gradient (shared with a sibling)
         self.tail_sums = 0           # backward: > 0 = a fused tail's fan-out launch already left this BN's two sums in `bpart` (that many rows)
+        self._piece_args = None
+        self.cat_stats = None        # (BNOp, column): this block's output is a piece of a virtual concatenation whose BN takes the piece's sums from here
         self.bn_bwd_done = False     # backward: the tail also ran this block's finalize + apply (one pass for both blocks of a ResPath tail)
         self.heads: List["HeadOp"] = []            # one-channel output heads on `out` (at most two) whose forward rides on this block's bn_act_apply
         self._head_desc = None
@@ -422,6 +424,17 @@ class ConvOp(Op):
             if self.lazy and training:
                 return                   # (the fused add that consumes this block applies scale / shift / ReLU on load)
             ph, pw = self.pool_size if self.pooled is not None else (1, 1)
+            if self.cat_stats is not None and training:
+                # a piece of a virtual concatenation: the apply pass in its tail-kernel form (one pre-affine input) also delivers the
+                # piece's columns of the statistics of the BatchNormalization over the concatenation
+                b, off = self.cat_stats
+                if self._piece_args is None:
+                    self._piece_args = ((C.c_void_p * 4)(self.z.buf.data_ptr(), None, None, None), (C.c_void_p * 4)(self.scale.data_ptr(), None, None, None),
+                                        (C.c_void_p * 4)(self.shift.data_ptr(), None, None, None), (C.c_int32 * 4)(1 if ACT[self.act] == ACT["relu"] else 0, 0, 0, 0))
+                ptr, sc, sh, relu = self._piece_args
+                call("seg_add_act_stats_fwd", ptr, sc, sh, relu, 1, None, None, None, _p(self.out.buf), self.z.npix, self.n_rows, self.cout, 0, 0.0,
+                     _p(b.stats), b.nparts, b.C, off, s)
+                return
             if self.heads:                   # the heads' dot products over the channels come out of this pass
                 if self._head_desc is None:
                     d = _ffi.HeadFwdDesc()
@@ -837,6 +850,7 @@ class BNOp(Op):
         self.fused_add: Optional["AddOp"] = None
         self.folded_into: Optional["AddOp"] = None
         self.pieces: Optional[List[Tuple[DevTensor, int]]] = None
+        self.piece_stats = False      # (virtual) the pieces' producing Conv_Blocks write this BN's statistics from their apply passes
         self.cat: Optional[_ffi.CatDesc] = None
         self.cat_parts = _tail_parts(x.npix, self.C)
 
@@ -849,15 +863,28 @@ class BNOp(Op):
             d.p[k].x, d.p[k].dx, d.p[k].cs, d.p[k].C, d.p[k].coff, d.p[k].acc = t.buf.data_ptr(), None, t.cs, c, off, 0
             off += c
         self.cat = d
+        # the statistics of the concatenation are the statistics of the pieces side by side: where every piece is the output of a
+        # Conv_Block (plain bn_act_apply, no pooling, no head riding on it) that block's apply pass - run as the one-input form of the
+        # tail kernel - writes the piece's sums into this BN's partial rows on its way out: no pass over the pieces afterwards
+        prods = [next((o for o in self.m.ops if isinstance(o, ConvOp) and o.out is t), None) for t, _c in pieces]
+        if F.TAIL_PIECE_STATS and all(p is not None and p.has_bn and p.pooled is None and not p.lazy and not p.heads and p.cat_stats is None
+                                      for p in prods):
+            off = 0
+            for p, (_t, c) in zip(prods, pieces):
+                p.cat_stats = (self, off)
+                off += c
+            self.piece_stats = True
         self.x.materialised = False
         self.x.buf = torch.empty((0,), dtype=self.x.buf.dtype, device=self.x.buf.device)      # (nothing reads or writes the concatenated tensor any more)
 
     def forward(self, training):
         st, s, bn, x = self.m.store, _stream(), self.bn_name, self.x
         if training and self.fused_add is None:
-            if self.pieces is not None:       # statistics of the virtual concatenation: one gathering pass over the pieces
+            if self.pieces is not None and self.piece_stats:
+                pass                          # every piece delivered its columns of `stats` from its own apply pass (ConvOp.cat_stats)
+            elif self.pieces is not None:     # statistics of the virtual concatenation: one gathering pass over the pieces
                 call("seg_add_act_stats_fwd", None, None, None, None, 0, C.byref(self.cat), None, None, None, x.npix, self.C, self.cl,
-                     0, 0.0, _p(self.stats), self.nparts, s)
+                     0, 0.0, _p(self.stats), self.nparts, 0, 0, s)
             else:
                 call("seg_bn_stats", _p(x.buf), x.npix, x.cs, 0, self.C, _p(self.stats), self.nparts, self.C, 0, s)
         call("seg_bn_finalize", _p(self.stats), self.nparts, self.C, x.npix, st.ptr(bn + "/gamma"), st.ptr(bn + "/beta"),
@@ -1005,7 +1032,7 @@ class AddOp(Op):
             ptr, sc, sh, relu, n = self.fsets[bool(training)]
             call("seg_add_act_stats_fwd", ptr, sc, sh, relu, n, C.byref(vb.cat) if vb is not None else None,
                  _p(vb.scale) if vb is not None else None, _p(vb.shift) if vb is not None else None, _p(self.out.buf), self.out.npix,
-                 self.out.cs, self.out.C, ACT[self.act], float(self.alpha), _p(b.stats), b.nparts, _stream())
+                 self.out.cs, self.out.C, ACT[self.act], float(self.alpha), _p(b.stats), b.nparts, 0, 0, _stream())
             return
         call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
              float(self.alpha), _stream())
