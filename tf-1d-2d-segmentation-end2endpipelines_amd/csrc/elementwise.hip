@@ -950,9 +950,10 @@ __global__ __launch_bounds__(TPB) void tail_fwd_kernel(Ptr4<T> xs, Aff4 aff, int
   if (rowi == 0 && ch < L.CH) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (stats_ld != cs && ch * 8 + t >= c_valid) continue;
-      stats[((size_t)blockIdx.x * 2 + 0) * stats_ld + stats_coff + ch * 8 + t] = acc[0][t];
-      stats[((size_t)blockIdx.x * 2 + 1) * stats_ld + stats_coff + ch * 8 + t] = acc[1][t];
+      if (stats_coff >= 0 && ch * 8 + t >= c_valid) continue;      // (foreign rows: only this tensor's valid channels)
+      const int sc0 = stats_coff >= 0 ? stats_coff : 0;
+      stats[((size_t)blockIdx.x * 2 + 0) * stats_ld + sc0 + ch * 8 + t] = acc[0][t];
+      stats[((size_t)blockIdx.x * 2 + 1) * stats_ld + sc0 + ch * 8 + t] = acc[1][t];
     }
   }
 }
@@ -2282,8 +2283,10 @@ static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const*
                                       const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,
                                       int32_t c_valid, int32_t act, float alpha, float* stats, int32_t nparts, int32_t stats_ld, int32_t stats_coff,
                                       seg_stream_t stream) {
-  if (stats_ld <= 0) { stats_ld = cs; stats_coff = 0; }
-  SEG_CHECK_ARG(stats_coff >= 0 && stats_coff + (stats_ld == cs ? cs : c_valid) <= stats_ld, "seg_add_act_stats_fwd: statistics columns %d + %d of %d", stats_coff, c_valid, stats_ld);
+  // (the kernel takes stats_coff = -1 for the tensor's own rows - all cs columns written - and >= 0 for another tensor's rows, of
+  // which only the c_valid columns of this tensor are written)
+  if (stats_ld <= 0) { stats_ld = cs; stats_coff = -1; }
+  else SEG_CHECK_ARG(stats_coff >= 0 && stats_coff + c_valid <= stats_ld, "seg_add_act_stats_fwd: statistics columns %d + %d of %d", stats_coff, c_valid, stats_ld);
   SEG_CHECK_ARG(stats && n >= 0 && n <= 4 && (n > 0 || cat != nullptr) && (n == 0 || xs != nullptr) && npix > 0 && cs > 0 && (cs & 7) == 0 &&
                 cs <= 8 * TPB && nparts > 0 && c_valid > 0 && c_valid <= cs && (cat_scale == nullptr) == (cat_shift == nullptr),
                 "seg_add_act_stats_fwd: bad arguments (n=%d cs=%d)", n, cs);
