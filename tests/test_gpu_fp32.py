@@ -255,11 +255,17 @@ def test_halo_weight_gradient_in_the_parity_mode(shape, cins, cout, sk, partial)
     assert rel(torch.from_numpy(got), kz.grad + (0.0 if partial else 0.25)) < 1e-5
 
 
-@pytest.mark.parametrize("shape,cin,cout,sk", [((2, 16, 32), 40, 24, 1), ((1, 16, 16), 64, 72, 3), ((2, 8, 8), 96, 64, 5), ((2, 8, 32), 24, 32, 2)])
+@pytest.mark.parametrize("shape,cin,cout,sk", [
+    ((2, 16, 32), 40, 24, 1), ((2, 8, 32), 24, 32, 2),                  # <= 32 output channels: one class per block, one tap per wave
+    ((1, 16, 16), 64, 72, 3), ((2, 16, 32), 40, 40, 2),                 # class pair per block, 2x16 patches (ragged planes / row tiles)
+    ((2, 8, 8), 96, 64, 5),                                             # ... 4x8 patches, more patch ranges than patches
+    ((1, 6, 32), 33, 72, 2), ((1, 2, 64), 32, 64, 1), ((3, 2, 32), 64, 48, 1),      # ... 1x32 patches; one / three patches per block
+])
 def test_transposed_conv_weight_and_bias_gradient_from_one_launch(shape, cin, cout, sk):
-    """Parity mode, variant 2 on Conv2DTranspose(4x4, stride 2): one sub-pixel class per block, two taps per wave; the blocks of the
-    first input plane also contract dz with a ones operand - the bias gradient leaves the launch as one partial row per class and
-    patch range (seg_bn_bwd_finalize's layout).  Empty patch ranges (sk = 5 on 2 patches) write zero rows."""
+    """Parity mode, variant 2 on Conv2DTranspose(4x4, stride 2): the two classes of a class row per block against one halo tile
+    (igemm_wgrad_halo_split_tc2_kernel: 32-pixel patches, 3-stage ring, waves = row tile x tap row), one class per block for at most
+    32 output channels; the blocks of the first input plane also contract dz with a ones operand - the bias gradient leaves the
+    launch as partial rows per class and patch range (seg_bn_bwd_finalize's layout).  Empty patch ranges write zero rows."""
     N, H, W = shape
     x = torch.randn(N, H, W, cin)
     kshape = (4, 4, cout, cin)

@@ -518,6 +518,225 @@ template __global__ void igemm_wgrad_halo_split_kernel<32, true, true>(const seg
 template __global__ void igemm_wgrad_halo_split_kernel<16, true, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<8, true, true>(const seg_igemm_wgrad_args);
 
+// ---------------------------------------------------------------------------------------------------------
+// Conv2DTranspose(4x4, stride 2), parity mode, two sub-pixel classes per block (the class row py: classes (py, 0) and (py, 1);
+// tap table checked by seg_wgrad_halo_class_groups() == 2).  The per-class form above is bound by its LDS reads (6 fragment reads
+// for 6 MFMAs per K block and wave = 128 B per clock and CU at full MFMA rate).  Here a block owns 64 output channels x one
+// 32-channel input plane x BOTH classes of a class row and walks 32-pixel patches (R = 32 / C rows x C columns): per patch two dz
+// tiles [32 px][256 B] and ONE halo tile [(R+1)(C+2) px][128 B] - a class row needs only the input rows dy in {0,-1} (py = 0) or
+// {1,0} (py = 1) - in a 2-stage ring of 50 KB (a 3-stage ring with counted waits was slower alone and in the step: 282 against
+// 260 us on X05, +0.1 ms per C3 step).  Waves = (row tile wm) x (tap row iy): a wave reads both classes' dz
+// fragments and the three column shifts of its input row (10 fragment reads) for 4 MFMA triples per K block: dx = 0 feeds
+// both classes.  Per MFMA: 0.83 fragment reads instead of 1.0, 25 KB of LDS-DMA per 32 px and class pair instead of 2 x 16.5 KB.
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(const seg_igemm_wgrad_args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PX = 32, R = PX / C, HC = C + 2, HROWS = (R + 1) * HC;
+  constexpr int NI_IN = (HROWS + 7) / 8;                  // LDS-DMA wave instructions per halo tile (8 rows of 128 B each)
+  constexpr int NI_W = (NI_IN + 3) / 4;                   // ... per wave, at most
+  constexpr int Z_BYTES = PX * 256, IN_BYTES = NI_IN * 1024, STAGE = 2 * Z_BYTES + IN_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, iy = wave & 1;
+  const seg_geom& g = p.g;
+  const int H = g.Hin, W = g.Win;
+
+  const int rtiles = (p.n_rows + 63) / 64;
+  const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int bz = lin / (gridDim.x * gridDim.y);
+  const int lrem = lin - bz * (gridDim.x * gridDim.y);
+  const int py = lrem / gridDim.x, bx = lrem - py * gridDim.x;       // class row
+  const int rt = bx % rtiles;
+  int pl = bx / rtiles;
+  int seg = 0;
+  for (; seg < p.nseg; ++seg) {
+    const int t = (p.seg_c[seg] + 31) / 32;
+    if (pl < t) break;
+    pl -= t;
+  }
+  if (seg >= p.nseg) return;
+  const int r0 = rt * 64, c0 = pl * 32;
+  const int sc = p.seg_c[seg], cs4 = p.seg_cs[seg] * 4, dzcs4 = p.dz_cs * 4;
+  const int PW = W / C, PH = H / R;
+  const int npatch = g.N * PH * PW;
+  const int per = (npatch + p.splitk - 1) / p.splitk;
+  const int q0 = bz * per, q1 = min(npatch, q0 + per);
+  // bias gradient: both classes of the row are summed into the partial row of class (py, 0); the row of class (py, 1) is zero
+  const bool bias_blk = p.bias_part != nullptr && seg == 0 && c0 == 0;
+  float* const brow0 = bias_blk ? p.bias_part + ((size_t)((py * 2) * p.splitk + bz) * 2) * p.n_rows : nullptr;
+  float* const brow1 = bias_blk ? p.bias_part + ((size_t)((py * 2 + 1) * p.splitk + bz) * 2) * p.n_rows : nullptr;
+  if (bias_blk && tid < 64 && r0 + tid < p.n_rows) {
+    brow1[r0 + tid] = 0.f;
+    brow1[p.n_rows + r0 + tid] = 0.f;
+    if (q0 >= q1) {                                                  // an empty patch range still owns its partial rows
+      brow0[r0 + tid] = 0.f;
+      brow0[p.n_rows + r0 + tid] = 0.f;
+    }
+  }
+  if (q0 >= q1) return;
+  const int Ho = g.Hout, Wo = g.Wout, osy = g.osy, osx = g.osx;
+
+  const i4v rsrc_in = make_rsrc(p.seg_ptr[seg], g.N * H * W * cs4);
+  const i4v rsrc_dz = make_rsrc(p.dz, g.N * Ho * Wo * dzcs4);
+  const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+  // ---- LDS-DMA lane constants.  dz: an instruction fills 4 rows (lane >> 4) x 16 chunks (lane & 15); 8 instructions per class
+  // tile, waves 0-1 fetch class (py, 0), waves 2-3 class (py, 1)
+  const int zcls = wave >> 1;
+  unsigned z_voff[4];
+  {
+    const int lrow = lane >> 4, lch = lane & 15;
+    const int gch = lch ^ ((lrow & 1) | (((lrow >> 1) & 1) << 3));      // (rows of an instruction start at a multiple of 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = ((wave & 1) * 4 + i) * 4 + lrow;
+      const int yy = row / C, xx = row % C;
+      z_voff[i] = (r0 + (gch >> 1) * 8 < p.n_rows) ? (unsigned)((yy * osy * Wo + xx * osx) * dzcs4 + (p.dz_coff + r0) * 4 + gch * 16) : OOB_OFF;
+    }
+  }
+  // halo: an instruction fills 8 rows (lane >> 3) x 8 chunks (lane & 7); halo row hr is input row y0 + hr - 1 + py
+  int in_dy[NI_W], in_dx[NI_W], in_cb[NI_W];
+  {
+    const int lrow = lane >> 3, lch = lane & 7;
+#pragma unroll
+    for (int k = 0; k < NI_W; ++k) {
+      const int i = wave + 4 * k;
+      const int row = i * 8 + lrow;
+      const int gch = lch ^ ((row >> 1) & 1);
+      const int yy = row / HC, xx = row - yy * HC;
+      in_dy[k] = yy - 1 + py;
+      in_dx[k] = xx - 1;
+      in_cb[k] = (i < NI_IN && row < HROWS && c0 + (gch >> 1) * 8 < sc) ? c0 * 4 + gch * 16 : -1;
+    }
+  }
+  int pn_ = __builtin_amdgcn_readfirstlane(q0 / (PH * PW));
+  int py_ = __builtin_amdgcn_readfirstlane((q0 - pn_ * (PH * PW)) / PW);
+  int px_ = __builtin_amdgcn_readfirstlane(q0 - pn_ * (PH * PW) - py_ * PW);
+  auto issue = [&](int stage) {
+    const int n = pn_, y0 = py_ * R, x0 = px_ * C;
+    if (++px_ == PW) {
+      px_ = 0;
+      if (++py_ == PH) { py_ = 0; ++pn_; }
+    }
+    const unsigned sb = lds_base + (unsigned)(stage * STAGE);
+    const int cls = py * 2 + zcls;
+    const int zs = __builtin_amdgcn_readfirstlane(((n * Ho + y0 * osy + g.oy[cls]) * Wo + x0 * osx + g.ox[cls]) * dzcs4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(rsrc_dz, sb + (wave * 4 + i) * 1024, z_voff[i], zs);
+#pragma unroll
+    for (int k = 0; k < NI_W; ++k) {
+      if (wave + 4 * k < NI_IN) {
+        const int y = y0 + in_dy[k], x = x0 + in_dx[k];
+        const bool ok = in_cb[k] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)(((n * H + y) * W + x) * cs4 + in_cb[k]) : OOB_OFF;
+        lds_dma16(rsrc_in, sb + 2 * Z_BYTES + (wave + 4 * k) * 1024, voff, 0);
+      }
+    }
+  };
+
+  // ---- transposed-read lane offsets (as in the per-class kernel)
+  const int tg = lane >> 4, tt = lane & 15, tq = tt >> 2, tp = tt & 3;
+  const int j = 8 * (tg >> 1) + tq;
+  const int grp = 2 * (tg & 1) + (tp >> 1), sub = (tp & 1) * 8;
+  const int zsw = (tq & 1) | (((tq >> 1) & 1) << 3);
+  const int offAh = j * 256 + (((2 * (wm * 4 + grp)) ^ zsw) << 4) + sub;
+  const int offAl = j * 256 + (((2 * (wm * 4 + grp) + 1) ^ zsw) << 4) + sub;
+  const int jr = C >= 16 ? j : j + (j >> 3) * (HC - 8);
+  int offB[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) offB[r] = jr * 128 + (((2 * grp) ^ (((r + jr) >> 1) & 1)) << 4) + sub;
+
+  f16v acc[4], accl[4];        // [class px][ix]: (px 0: dx = 0, -1), (px 1: dx = 1, 0)
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; accl[t][q] = 0.f; }
+  const bool do_bias = bias_blk && iy == 0;
+  f16v accb, accbl;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { accb[q] = 0.f; accbl[q] = 0.f; }
+  const h8 ones = h8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+
+  auto compute = [&](auto iyc, int stage) {
+    constexpr int IY = decltype(iyc)::value;
+    const unsigned char* Zs = smem + stage * STAGE;
+    const unsigned char* Is = Zs + 2 * Z_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < PX / 16; ++kb) {
+      constexpr int KPR = C >= 16 ? C / 16 : 1;
+      const int yy = C >= 16 ? kb / KPR : 2 * kb, xx0 = C >= 16 ? (kb % KPR) * 16 : 0;
+      const h8 a0h = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256), a0l = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
+      const h8 a1h = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAh, 4 * 256), a1l = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAl, 4 * 256);
+      if (do_bias) {                                                 // wave-uniform
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, ones, accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, ones, accb, 0, 0, 0);
+        accbl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, ones, accbl, 0, 0, 0);
+        accbl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, ones, accbl, 0, 0, 0);
+      }
+      // tap row iy reads halo row yy + 1 - iy for either class row (dy = {0,-1} + py, halo row 0 = input row y0 - 1 + py)
+      const int hb0 = (yy + 1 - IY) * HC + xx0 + 1;                  // halo row of pixel 0 of this K block at dx = 0
+      const int om = (hb0 - 1) * 128 + offB[(hb0 - 1) & 3], oz = hb0 * 128 + offB[hb0 & 3], op = (hb0 + 1) * 128 + offB[(hb0 + 1) & 3];
+      const h8 bzh = trfrag(Is + oz, 4 * 128), bzl = trfrag(Is + (oz ^ 16), 4 * 128);
+      SEG_MMA_SPLIT(acc[0], accl[0], a0h, a0l, bzh, bzl);
+      SEG_MMA_SPLIT(acc[3], accl[3], a1h, a1l, bzh, bzl);
+      const h8 bmh = trfrag(Is + om, 4 * 128), bml = trfrag(Is + (om ^ 16), 4 * 128);
+      SEG_MMA_SPLIT(acc[1], accl[1], a0h, a0l, bmh, bml);
+      const h8 bph = trfrag(Is + op, 4 * 128), bpl = trfrag(Is + (op ^ 16), 4 * 128);
+      SEG_MMA_SPLIT(acc[2], accl[2], a1h, a1l, bph, bpl);
+    }
+  };
+  auto run = [&](auto iyc) {
+    int stage = 0;
+    issue(0);
+    for (int q = q0; q < q1; ++q) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the loads of this patch have landed
+      ring_release_barrier();
+      if (q + 1 < q1) issue(stage ^ 1);
+      compute(iyc, stage);
+      stage ^= 1;
+    }
+  };
+  if (iy == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] += accl[t][q] * SPLIT_INV;
+
+  float sc_mul = p.scale;
+  if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
+  float* part = (p.partial != nullptr && p.splitk > 1) ? p.partial + (size_t)bz * ((size_t)p.n_rows * g.T_total * p.Kpad) : nullptr;
+  const int fr = lane & 31, fh = lane >> 5;
+  if (do_bias && fr == 0) {          // every column of accb holds the same sums: the lanes of column 0 write the partial row
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = r0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+      if (row < p.n_rows) {
+        brow0[row] = accb[q] + accbl[q] * SPLIT_INV;
+        brow0[p.n_rows + row] = 0.f;
+      }
+    }
+  }
+  const int kcol = c0 + fr;
+  if (kcol < sc) {
+    const int stride = g.T_total * p.Kpad, row0 = r0 + wm * 32;
+    float* const wbase = (part != nullptr ? part : p.dw) + (size_t)(row0 + 4 * fh) * stride + p.seg_woff[seg] + kcol;
+    wgrad_mode_dispatch(wgrad_mode(p), [&](auto mc) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        wgrad_store_tile<decltype(mc)::value>(wbase + g.tap_w[(py * 2 + (t >> 1)) * 4 + iy * 2 + (t & 1)] * p.Kpad, acc[t], p.n_rows - row0, stride, sc_mul);
+    });
+  }
+#endif
+}
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<32>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<16>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<8>(const seg_igemm_wgrad_args);
+
 }  // namespace
 
 extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
@@ -540,6 +759,9 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
     const size_t lds = (size_t)2 * (16384 + ni * 1024);
     static const char* narrow_env = std::getenv("SEG_WGRAD_NARROW");
     const bool narrow = a->n_rows <= 32 && (narrow_env == nullptr || std::atoi(narrow_env) != 0);
+    // transposed conv whose taps follow the class-pair table: both classes of a class row per block
+    static const char* tc2_env = std::getenv("SEG_WGRAD_TC2");
+    const bool tc2 = !narrow && seg_wgrad_halo_class_groups(&a->g) == 2 && (tc2_env == nullptr || std::atoi(tc2_env) != 0);
     if (narrow && a->g.ncls == 1) {
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false, true>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false, true>), grid, dim3(256), lds, st, *a);
@@ -548,6 +770,11 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true, true>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true, true>), grid, dim3(256), lds, st, *a);
       else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true, true>), grid, dim3(256), lds, st, *a);
+    } else if (tc2) {
+      dim3 grid2(grid.x, 2, grid.z);
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<32>), grid2, dim3(256), (size_t)2 * (16384 + 9 * 1024), st, *a);
+      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<16>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<8>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
     } else if (a->g.ncls == 1) {
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false>), grid, dim3(256), lds, st, *a);

@@ -12,6 +12,7 @@ GRAD_TARGET = 1024.0      # max |dLoss/dOut| is rescaled to [512, 1024) before t
 WGRAD_VARIANT = 0         # 0: ds_read_b64_tr_b16 operand reads, 1: transposing LDS stores
 WGRAD_OVERWRITE = True   # single-writer weight-gradient tiles store into the cleared buffer
 WGRAD_HALO = os.environ.get("SEG_WGRAD_HALO", "1") != "0"      # variant 2 (LDS-DMA halo tiles) for the 3x3 stride-1 layers
+WGRAD_TC2_F32 = os.environ.get("SEG_WGRAD_TC2", "1") != "0"   # parity mode: class-pair kernel for the transposed convs (the library reads the same switch)
 WGRAD_DETERMINISTIC = os.environ.get("SEG_WGRAD_DETERMINISTIC", "1") != "0"   # pixel-split weight gradients through per-layer partial tiles + an ordered reduce (no float atomics)
 FUSE_ACT_BWD = os.environ.get("SEG_FUSE_ACT_BWD", "1") != "0"
 FUSE_BN_TAILS = os.environ.get("SEG_FUSE_BN_TAILS", "1") != "0"             # BN(ReLU(a + b)) tails of MultiResBlock / ResPath as fused passes

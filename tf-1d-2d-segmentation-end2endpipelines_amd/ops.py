@@ -362,7 +362,8 @@ class ConvOp(Op):
         if variant == 0 and F.WGRAD_HALO and wgrad_halo_patch(self.g_fwd):
             variant = 2         # 3x3 stride-1 layers and 4x4 / stride-2 transposed convs: LDS-DMA halo-tile kernel
         tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs],
-                                     wgrad_halo_class_groups(self.g_fwd) if (variant == 2 and f16) else self.g_fwd.ncls, self.g_fwd.ntaps,
+                                     wgrad_halo_class_groups(self.g_fwd) if (variant == 2 and (f16 or (F.WGRAD_TC2_F32 and self.n_rows > 32)))
+                                     else self.g_fwd.ncls, self.g_fwd.ntaps,
                                      variant, f16)
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
