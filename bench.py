@@ -22,7 +22,7 @@ Besides the contract fields the line carries (all measured in this
                   MFMA work actually issued (3 x) and the fraction of peak / 3
   throughput_mode the same workload, same steps / warm-up, in dtype f16 (or parity_mode when --dtype f16 was asked for)
   inference       forward-only images/s (inference-mode BN; 2DCNN/Test.py:161)
-  extra_workloads short runs of the other BASELINE configs (C2, C5, C4 at W=32 and W=64) with their own roofline figure
+  extra_workloads short runs of the other BASELINE configs (C2, C5, C4 at W=32 and W=64) with their own roofline figure; C3 at batch 64
   rccl            what torch.distributed saw (backend, world size, RCCL version); with more than one rank the time each rank's
                   optimiser spent waiting for gradient slices (exposed communication)
   cpu_baseline    the oracle (torch-CPU restatement) on the host cores, bounded sample
@@ -207,10 +207,11 @@ def time_loop(fn, warmup, steps, barrier):
     return time.perf_counter() - t0
 
 
-def short_run(workload, dtype, steps, warmup, profile=True):
-    """A short single-GPU run of another configuration / mode: ms per step, images/s, its roofline figure."""
+def short_run(workload, dtype, steps, warmup, profile=True, batch=0):
+    """A short single-GPU run of another configuration / mode (or another batch): ms per step, images/s, its roofline figure."""
     kw, H, W, Cin, bs, loss, desc = WORKLOADS[workload]
-    model = build_model(workload, dtype)
+    bs = batch or bs
+    model = build_model(workload, dtype, bs)
     x, targets = make_batch(model, bs, H, W, Cin, loss, 0)
     dt = time_loop(lambda: model.train_step(x, targets), warmup, steps, torch.cuda.synchronize)
     ms = dt / steps * 1e3
@@ -539,6 +540,13 @@ def main():
                 extras[wl] = short_run(wl, args.dtype, 10 if wl.startswith("C4") else 20, 3, profile=True)
             except Exception as e:
                 extras[wl] = {"error": repr(e)}
+        # ---- the same workload at four times the batch (not the metric's configuration: what the 288 GB of HBM allow; since round 4
+        # the LDS-DMA kernels address operands up to 1.875 GiB, i.e. this model up to batch 119)
+        if args.workload == "C3" and not args.batch:
+            try:
+                extras["C3_batch64"] = short_run("C3", args.dtype, 5, 2, profile=False, batch=64)
+            except Exception as e:
+                extras["C3_batch64"] = {"error": repr(e)}
     else:
         resident = torch.cuda.max_memory_allocated() / 1e9
 

@@ -164,6 +164,10 @@ int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t stream);
 /* bytes of the zero-initialised `partial` workspace for these arguments (splitk * n_rows * T_total * Kpad floats; 0 when
  * splitk == 1): the caller allocates it once per layer, the library allocates nothing                                   */
 int64_t seg_igemm_wgrad_workspace_bytes(const seg_igemm_wgrad_args* a);
+/* Largest operand (bytes, exclusive: 1.875 GiB) the LDS-DMA kernel families address - one buffer resource per tensor, 32-bit byte
+ * offsets: seg_igemm_fwd variant 3 and seg_igemm_wgrad variant 2 refuse larger inputs / gradients / weights; seg_igemm_fwd variant 0
+ * then runs its register-staged kernel (64-bit addresses, tile_m <= 128, no splitk), seg_igemm_wgrad variants 0 / 1 likewise.      */
+int64_t seg_lds_dma_operand_limit(void);
 /* patch width (32 / 16 pixels, patch = 64 pixels) the variant-2 kernel would use for this geometry; 0: not eligible */
 int seg_wgrad_halo_patch(const seg_geom* g);
 /* blocks along the class axis of the variant-2 kernel (1: conv; 2: transposed conv on the class-pair kernel; 4)     */

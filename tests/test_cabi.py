@@ -98,6 +98,12 @@ def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
         assert got == M.fwd_halo_patch(g)
         seen.add(got)
     assert seen == {0, 16, 32}
+    # operand size limit of the LDS-DMA kernels: the planner routes larger operands to the register-staged kernels
+    assert L.seg_lds_dma_operand_limit() == M.LDS_DMA_LIMIT == 0x78000000
+    g = M.geom_conv(119, 256, 256, 3, 3, 1, 1)
+    assert M.fits_lds_dma(g, [64], 64 * 9 * 64, False) and not M.fits_lds_dma(M.geom_conv(120, 256, 256, 3, 3, 1, 1), [64], 64 * 9 * 64, False)
+    assert M.plan_fwd(119 * 65536, 64, g, 9 * 64, False, [64], 64 * 9 * 64)[2] == 3
+    assert M.plan_fwd(120 * 65536, 64, M.geom_conv(120, 256, 256, 3, 3, 1, 1), 9 * 64, False, [64], 64 * 9 * 64) == (128, 64, 0, 1)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -279,6 +279,68 @@ def test_transposed_conv_weight_and_bias_gradient_from_one_launch(shape, cin, co
     assert rel(bias[:cout], bz.grad) < 1e-5
 
 
+@pytest.mark.parametrize("what,f32,N", [("fwd", True, 100), ("fwd", False, 100), ("wgrad", True, 72), ("fwd_beyond", True, 124)])
+def test_operands_between_1_and_2_gib(what, f32, N):
+    """The LDS-DMA kernels address an operand through one buffer resource with 32-bit offsets: up to seg_lds_dma_operand_limit()
+    (1.875 GiB; 1 GiB until round 4 - UNet++ w64 at 256 x 256 stops fitting at batch 64 there).  A 3x3 layer at 256 x 256 whose
+    input is 1.1 - 1.6 GiB: the halo kernels' first and last images against the CPU convolution (the last image sits at the highest
+    offsets); the weight gradient with an input that is zero except in those images, so that a mis-addressed read loses their
+    contribution (and picks up none: dz is dense).  `fwd_beyond`: 1.94 GiB - variant 0 falls through to the register-staged kernel."""
+    torch.manual_seed(3)
+    H = W = 256
+    cin = 64 if f32 else 128                       # 256 bytes per pixel in either storage format
+    cout = 16
+    kern = (torch.randn(3, 3, cin, cout) * 0.05).numpy()
+    ends = [0, 1, N - 2, N - 1]
+    if what in ("fwd", "fwd_beyond"):
+        x = torch.randn(N, H, W, cin)
+        assert (N * H * W * 256 >= U.M.LDS_DMA_LIMIT) == (what == "fwd_beyond") and N * H * W * 256 > (1 << 30)
+        tile, variant = ((256, 32 if f32 else 64), 3) if what == "fwd" else ((128, 64), 0)
+        out, _, _ = U.igemm_conv([x], kern, None, "conv", (1, 1), None, 0.0, False, tile, f32=f32, variant=variant)
+        xs = x[ends] if f32 else h16(x[ends])
+        want = K.conv2d_same(xs, torch.from_numpy(kern) if f32 else h16(torch.from_numpy(kern)), None, (1, 1))
+        assert rel(out[ends], want) < (1e-5 if f32 else 2e-3)
+        return
+    x = torch.zeros(N, H, W, cin)
+    x[ends] = torch.randn(4, H, W, cin)
+    dz = torch.randn(N, H, W, 64)                # dz: 64 channels x 4 bytes = the same 256 bytes per pixel
+    kz = torch.zeros(3, 3, cin, 64, requires_grad=True)
+    (K.conv2d_same(x[ends], kz, None) * dz[ends]).sum().backward()
+    got = U.igemm_wgrad([x], dz, (3, 3, cin, 64), "conv", (1, 1), 2, None, None, f32=True, partial=True)
+    assert rel(torch.from_numpy(got), kz.grad) < 1e-5
+
+
+def test_planner_routes_oversized_operands_to_the_register_staged_kernels(monkeypatch):
+    """With the limit lowered to one byte every launch of a small model takes the route of an operand beyond 1.875 GiB (variant 0, tiles of
+    at most 128 rows, no split; per-tap weight gradient): same loss, gradients and predictions as the default plan, to rounding."""
+    import importlib
+    P = importlib.import_module(U.M.__name__.rsplit(".", 1)[0] + ".planning")
+    res = []
+    for limit in (None, 1):
+        if limit is not None:
+            monkeypatch.setattr(P, "LDS_DMA_LIMIT", limit)
+        torch.manual_seed(5)
+        m, x, targets, loss = CASES["unetpp_ds_mse"]()
+        m.build(x.shape[0], dtype="f32")
+        if res:
+            m.set_weights(res[0][3])
+            assert all(op.fwd_variant == 0 and op.wg_args.variant != 2 for op in m.ops if isinstance(op, U.M.ConvOp))
+        else:
+            assert any(op.wg_args.variant == 2 for op in m.ops if isinstance(op, U.M.ConvOp))
+        w = m.get_weights()
+        m.forward(x, training=True)
+        lv = float(m.compute_loss(targets, loss).cpu())
+        m.backward(None)
+        g = m.get_grads()
+        m._join_side()
+        res.append((lv, g, m.predict(x), w))
+    assert abs(res[0][0] - res[1][0]) < 1e-5 * abs(res[0][0])
+    for k in res[0][1]:
+        assert rel(torch.as_tensor(res[1][1][k]), torch.as_tensor(res[0][1][k])) < 2e-4, k
+    for a, b in zip(res[0][2], res[1][2]):
+        assert float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["multiresunet_ag_bce", "multiresunet1d_mse"])
 def test_fused_bn_tails_equal_the_separate_passes(name, monkeypatch):
     """MultiResBlock / ResPath tails BN(ReLU(a + b)) as fused passes (SegModel._fuse_bn_tail) against the separate add / BN passes

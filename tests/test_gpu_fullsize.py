@@ -258,6 +258,47 @@ def test_c3_forward_and_backward_at_the_benched_batch_match_the_oracle():
     assert max(own.values()) < GRAD_L2.get("C3", 1e-2), max(own, key=own.get)
 
 
+def test_c3_at_batch_64_matches_the_register_staged_route(monkeypatch):
+    """UNet++ w64 at 256 x 256, batch 64: the level-0 tensors are 1.07 GB - beyond the 1 GiB the LDS-DMA kernels addressed until
+    round 4, inside today's 1.875 GiB.  One forward + backward on the default plan (halo / LDS-DMA kernels on every layer) against
+    the same model with the planner's limit set back to 1 GiB, which sends exactly the layers with such operands to the register-
+    staged kernels (64-bit addresses, other tiles, another summation order): same loss, same predictions, every parameter gradient to
+    2e-4 relative L2 - the offsets above 2^30 reach the right bytes in every kernel family (there is no oracle at this size: 64
+    images x 2.5 GB of autograd state)."""
+    import gc, importlib
+    P = importlib.import_module(U.M.__name__.rsplit(".", 1)[0] + ".planning")
+    res = []
+    for limit in (None, 1 << 30):
+        if limit is not None:
+            monkeypatch.setattr(P, "LDS_DMA_LIMIT", limit)
+        torch.manual_seed(33)
+        model, x, targets, loss = CONFIGS["C3"](64)
+        model.build(64, dtype="f32")
+        convs = [op for op in model.ops if isinstance(op, U.M.ConvOp)]
+        staged = sum(1 for op in convs if op.fwd_variant == 0 and op.M >= 64 * 256 * 256)
+        assert (staged == 0) if limit is None else (staged > 0)
+        if res:
+            model.set_weights(res[0][3])
+        w = model.get_weights() if not res else None
+        model.forward(x, training=True)
+        lv = float(model.compute_loss(targets, loss).cpu())
+        model.backward(None)
+        model._join_side()
+        g = {k: torch.as_tensor(v).clone() for k, v in model.get_grads().items()}
+        outs = [h.y.float().cpu().clone() for h in model.out_heads]
+        res.append((lv, g, outs, w))
+        del model, convs
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert abs(res[0][0] - res[1][0]) < 1e-5 * abs(res[0][0])
+    gn = max(float(v.norm()) for v in res[0][1].values())
+    worst = max((float((res[1][1][k] - v).norm()) / (float(v.norm()) + 1e-3 * gn), k) for k, v in res[0][1].items())
+    _record("C3", "f32_batch64_halo_vs_register_staged", {"loss": [res[0][0], res[1][0]], "grad_rel_l2_worst": worst[0], "tensor": worst[1]})
+    assert worst[0] < 2e-4, worst
+    for a, b in zip(res[0][2], res[1][2]):
+        assert float((a - b).abs().max()) < 1e-5
+
+
 def test_load_keras_model_walks_the_layer_graph_into_the_engine():
     """SegModel.load_keras_model / export_to_keras_model on the device: a (fake) tf.keras model of the reference - auto-named
     layers in shuffled order, pairwise-folded concatenates, only `inbound_nodes` telling the structure (tests/test_keras_map.py)

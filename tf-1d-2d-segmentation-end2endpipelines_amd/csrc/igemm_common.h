@@ -434,7 +434,13 @@ __device__ __forceinline__ void wgrad_mode_dispatch(int mode, F&& f) {
   else f(std::integral_constant<int, 3>{});
 }
 
-constexpr unsigned OOB_OFF = 0x60000000u;   // beyond any legal byte offset (operands are checked to be < 1 GiB)
+// Operands the LDS-DMA kernels address through one buffer resource with 32-bit byte offsets must stay below LDS_DMA_LIMIT
+// (seg_lds_dma_operand_limit(): 1.875 GiB).  A masked lane fetches at OOB_OFF = 2 GiB: at or beyond every legal num_records even
+// after a (negative) tap shift of up to 128 MiB has been added to it, and OOB_OFF + the largest scalar offset still below 4 GiB -
+// the hardware range check then returns zeros.  Larger operands take the register-staged kernels (64-bit addresses): the host
+// planner (planning.plan_fwd / ops.ConvOp) mirrors the limit.
+constexpr unsigned OOB_OFF = 0x80000000u;
+constexpr long LDS_DMA_LIMIT = 0x78000000L;
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

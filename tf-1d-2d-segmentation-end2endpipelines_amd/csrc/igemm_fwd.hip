@@ -147,8 +147,8 @@ extern "C" int seg_igemm_fwd(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   const int mblocks = (int)((M + a->tile_m - 1) / a->tile_m);
   const int nblocks = (a->n_rows + a->tile_n - 1) / a->tile_n;
   if (fwd2_eligible(*a, 2)) return launch_fwd2(*a, mblocks, nblocks, st);
-  SEG_CHECK_ARG(a->splitk <= 1, "seg_igemm_fwd: splitk needs the LDS-DMA kernel (tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
-  SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (taps in {1,2,3,4,9,16}, operands < 1 GiB)");
+  SEG_CHECK_ARG(a->splitk <= 1, "seg_igemm_fwd: splitk needs the LDS-DMA kernel (tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}, operands < 1.875 GiB)");
+  SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd: a 256-row tile needs the LDS-DMA kernel (taps in {1,2,3,4,9,16}, operands < 1.875 GiB)");
   dim3 grid((unsigned)(mblocks * nblocks), (unsigned)a->g.ncls, 1), block(256, 1, 1);
   const int lds_main = 2 * (a->tile_m + a->tile_n) * ROW_BYTES;
   const int lds_epi = STG_BYTES + 2 * a->tile_n * 2 * 4;

@@ -459,13 +459,13 @@ inline int check_fwd_args(const seg_igemm_fwd_args* a) {
                   "seg_igemm_fwd: tile %dx%d", a->tile_m, a->tile_n);
   return SEG_OK;
 }
-// the per-tap LDS-DMA kernel takes 128- and 256-row tiles, tap counts it is instantiated for, operands below 1 GiB
+// the per-tap LDS-DMA kernel takes 128- and 256-row tiles, tap counts it is instantiated for, operands below 1.875 GiB (seg_lds_dma_operand_limit)
 // (esz = bytes per element of the operands: 2, parity mode 4)
 inline bool fwd2_eligible(const seg_igemm_fwd_args& a, int esz) {
   if (!((a.tile_m == 128 && (a.tile_n == 128 || a.tile_n == 64)) || (a.tile_m == 256 && a.tile_n == 64))) return false;
   const int nt = a.g.ntaps;
   if (!(nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 9 || nt == 16)) return false;
-  const long lim = 1L << 30;
+  const long lim = LDS_DMA_LIMIT;
   const long pix = (long)a.g.N * a.g.Hin * a.g.Win;
   for (int s = 0; s < a.nseg; ++s)
     if (pix * a.seg_cs[s] * esz >= lim) return false;

@@ -38,8 +38,8 @@ extern "C" int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t strea
     }
     return SEG_OK;
   }
-  SEG_CHECK_ARG(a->splitk <= 1, "seg_igemm_fwd_f32: splitk needs the LDS-DMA kernel (tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}, operands < 1 GiB)");
-  SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd_f32: a 256-row tile needs the LDS-DMA kernel (taps in {1,2,3,4,9,16}, operands < 1 GiB)");
+  SEG_CHECK_ARG(a->splitk <= 1, "seg_igemm_fwd_f32: splitk needs the LDS-DMA kernel (tiles 128x128 / 128x64 / 256x64, taps in {1,2,3,4,9,16}, operands < 1.875 GiB)");
+  SEG_CHECK_ARG(a->tile_m <= 128, "seg_igemm_fwd_f32: a 256-row tile needs the LDS-DMA kernel (taps in {1,2,3,4,9,16}, operands < 1.875 GiB)");
   const int lds_main = 2 * (a->tile_m + a->tile_n) * ROW_BYTES * 2;      // two sub-tiles per K step
   const int lds_epi = STG_BYTES + 2 * a->tile_n * 2 * 4;
   const size_t lds = (size_t)(lds_main > lds_epi ? lds_main : lds_epi);

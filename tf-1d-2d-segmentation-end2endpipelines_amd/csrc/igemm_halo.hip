@@ -397,8 +397,8 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd: variant 3 needs a stride-1 3x3 'same' conv, a 4x4 / stride-2 transposed conv (or the data gradient of either), and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
   SEG_CHECK_ARG(a.tile_m == 256 && (a.tile_n == 64 || a.tile_n == 128), "seg_igemm_fwd: variant 3 tiles are 256x64 and 256x128, not %dx%d", a.tile_m, a.tile_n);
   const long pix = (long)a.g.N * a.g.Hin * a.g.Win;
-  for (int s = 0; s < a.nseg; ++s) SEG_CHECK_ARG(pix * a.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd: variant 3 needs operands below 1 GiB");
-  SEG_CHECK_ARG((long)a.n_rows * a.g.T_total * a.Kpad * 2 < (1L << 30), "seg_igemm_fwd: variant 3 needs operands below 1 GiB");
+  for (int s = 0; s < a.nseg; ++s) SEG_CHECK_ARG(pix * a.seg_cs[s] * 2 < LDS_DMA_LIMIT, "seg_igemm_fwd: variant 3 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
+  SEG_CHECK_ARG((long)a.n_rows * a.g.T_total * a.Kpad * 2 < LDS_DMA_LIMIT, "seg_igemm_fwd: variant 3 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
   const int npatch = (int)((long)a.g.N * a.g.Hl * a.g.Wl / 256);
   const int nblocks = (a.n_rows + a.tile_n - 1) / a.tile_n;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)a.g.ncls, 1);
@@ -438,8 +438,8 @@ int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st) {
   SEG_CHECK_ARG(pw != 0, "seg_igemm_fwd_f32: variant 3 needs a stride-1 3x3 'same' conv, a 4x4 / stride-2 transposed conv (or the data gradient of either), and W %% 32 == 0, H %% 8 == 0 (or W, H %% 16 == 0)");
   SEG_CHECK_ARG(v.tile_m == 256 && (v.tile_n == 64 || v.tile_n == 32), "seg_igemm_fwd_f32: the variant 3 tiles are 256x64 and 256x32, not %dx%d", v.tile_m, v.tile_n);
   const long pix = (long)v.g.N * v.g.Hin * v.g.Win;
-  for (int s = 0; s < v.nseg; ++s) SEG_CHECK_ARG(pix * v.seg_cs[s] * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
-  SEG_CHECK_ARG((long)v.n_rows * v.g.T_total * v.Kpad * 2 < (1L << 30), "seg_igemm_fwd_f32: variant 3 needs operands below 1 GiB");
+  for (int s = 0; s < v.nseg; ++s) SEG_CHECK_ARG(pix * v.seg_cs[s] * 2 < LDS_DMA_LIMIT, "seg_igemm_fwd_f32: variant 3 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
+  SEG_CHECK_ARG((long)v.n_rows * v.g.T_total * v.Kpad * 2 < LDS_DMA_LIMIT, "seg_igemm_fwd_f32: variant 3 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
   const int npatch = (int)((long)v.g.N * v.g.Hl * v.g.Wl / 256);
   const int nblocks = (v.n_rows + v.tile_n - 1) / v.tile_n;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)v.g.ncls, 1);

@@ -876,6 +876,10 @@ int seg_launch_wgrad_reduce(const seg_igemm_wgrad_args& a, hipStream_t st) {
   return SEG_OK;
 }
 
+// largest operand (bytes, exclusive) of the LDS-DMA kernel families - halo tiles (seg_igemm_fwd variant 3, seg_igemm_wgrad variant 2) and
+// the per-tap LDS-DMA kernel; beyond it seg_igemm_fwd variant 0 takes its register-staged kernel, seg_igemm_wgrad variants 0 / 1 theirs
+extern "C" int64_t seg_lds_dma_operand_limit(void) { return (int64_t)LDS_DMA_LIMIT; }
+
 // ---- workspace queries (no allocation inside the library - the caller asks, allocates, passes the pointer)
 // floats of the per-block partial BN statistics seg_igemm_fwd / seg_igemm_fwd_f32 write when args->stats != NULL:
 // [ncls * ceil(M / tile_m)][2][n_rows]
@@ -956,10 +960,10 @@ extern "C" int seg_igemm_wgrad(const seg_igemm_wgrad_args* a, seg_stream_t strea
     const int pc = seg_wgrad_halo_patch(&a->g);
     SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 32 == 0 and H %% 2 == 0, W %% 16 == 0 and H %% 4 == 0, or W and H %% 8 == 0");
     const long pix = (long)a->g.N * a->g.Hin * a->g.Win;
-    SEG_CHECK_ARG((long)a->g.N * a->g.Hout * a->g.Wout * a->dz_cs * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
+    SEG_CHECK_ARG((long)a->g.N * a->g.Hout * a->g.Wout * a->dz_cs * 2 < LDS_DMA_LIMIT, "seg_igemm_wgrad: variant 2 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
     int planes = 0;
     for (int s = 0; s < a->nseg; ++s) {
-      SEG_CHECK_ARG(pix * a->seg_cs[s] * 2 < (1L << 30), "seg_igemm_wgrad: variant 2 needs operands below 1 GiB");
+      SEG_CHECK_ARG(pix * a->seg_cs[s] * 2 < LDS_DMA_LIMIT, "seg_igemm_wgrad: variant 2 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
       planes += (a->seg_c[s] + 63) / 64;
     }
     if constexpr (sizeof(T) == 2) {

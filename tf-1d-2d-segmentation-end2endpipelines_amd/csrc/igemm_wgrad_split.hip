@@ -748,10 +748,10 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
     const int pc = seg_wgrad_halo_patch(&a->g);
     SEG_CHECK_ARG(pc != 0, "seg_igemm_wgrad_f32: variant 2 needs a 3x3 / stride-1 / 'same' conv or a 4x4 / stride-2 transposed conv, with W %% 32 == 0 and H %% 2 == 0, W %% 16 == 0 and H %% 4 == 0, or W and H %% 8 == 0");
     const long pix = (long)a->g.N * a->g.Hin * a->g.Win;
-    SEG_CHECK_ARG((long)a->g.N * a->g.Hout * a->g.Wout * a->dz_cs * 4 < (1L << 30), "seg_igemm_wgrad_f32: variant 2 needs operands below 1 GiB");
+    SEG_CHECK_ARG((long)a->g.N * a->g.Hout * a->g.Wout * a->dz_cs * 4 < LDS_DMA_LIMIT, "seg_igemm_wgrad_f32: variant 2 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
     int planes = 0;
     for (int s = 0; s < a->nseg; ++s) {
-      SEG_CHECK_ARG(pix * a->seg_cs[s] * 4 < (1L << 30), "seg_igemm_wgrad_f32: variant 2 needs operands below 1 GiB");
+      SEG_CHECK_ARG(pix * a->seg_cs[s] * 4 < LDS_DMA_LIMIT, "seg_igemm_wgrad_f32: variant 2 needs operands below 1.875 GiB (seg_lds_dma_operand_limit)");
       planes += (a->seg_c[s] + 31) / 32;
     }
     dim3 grid((unsigned)(((a->n_rows + 63) / 64) * planes), (unsigned)a->g.ncls, (unsigned)a->splitk);

@@ -43,7 +43,7 @@ from .splitfmt import split_pack, split_unpack
 # flags.py (switches); their names stay importable from here (tests, tools and bench.py address them as `model.<name>`)
 from .planning import (_r8, _r32, _cdiv, _same_pad, _fill_geom, geom_conv, geom_conv_dgrad, geom_convT, geom_convT_dgrad, pack_gemm_weight,
                        unpack_gemm_weight, pick_tile_fwd, wgrad_taps_per_block, fwd_halo_patch, pick_fwd, plan_fwd, fwd_workspace_bytes,
-                       wgrad_halo_patch, wgrad_halo_class_groups, pick_split_halo, pick_tile_wgrad, _tail_parts)
+                       wgrad_halo_patch, wgrad_halo_class_groups, pick_split_halo, pick_tile_wgrad, fits_lds_dma, LDS_DMA_LIMIT, _tail_parts)
 from .ops import (_DryRun, _dev, KernelProfile, _Mode, call, _stream, _p, DevTensor, Slot, ParamStore, Op, InputOp, ConvOp, GatherDgrad,
                   plan_gathers, _pad_to, HeadOp, WideHeadOp, ReshapeOp, BNOp, ConcatOp, AddOp, MulOp, UpsampleOp, PoolOp)
 

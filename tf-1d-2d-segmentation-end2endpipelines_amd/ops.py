@@ -15,7 +15,7 @@ from . import flags as F
 from ._ffi import ACT, Geom, IgemmFwdArgs, IgemmWgradArgs
 from .graph import Node
 from .planning import (_r8, _r32, _cdiv, geom_conv, geom_conv_dgrad, geom_convT, geom_convT_dgrad, pack_gemm_weight, unpack_gemm_weight,
-                       fwd_halo_patch, plan_fwd, wgrad_halo_patch, wgrad_halo_class_groups, pick_tile_wgrad, _tail_parts)
+                       fwd_halo_patch, plan_fwd, fits_lds_dma, wgrad_halo_patch, wgrad_halo_class_groups, pick_tile_wgrad, _tail_parts)
 from .splitfmt import split_unpack
 
 
@@ -276,7 +276,8 @@ class ConvOp(Op):
             self.bn_name = bn.name
             self.eps, self.momentum = float(bn.attrs["eps"]), float(bn.attrs["momentum"])
         # ---- tiles and scratch
-        self.tm, self.tn, self.fwd_variant, self.fwd_splitk = plan_fwd(self.M, n_rows, self.g_fwd, self.g_fwd.ntaps * self.Kpad, m.dtype == "f16")
+        self.tm, self.tn, self.fwd_variant, self.fwd_splitk = plan_fwd(self.M, n_rows, self.g_fwd, self.g_fwd.ntaps * self.Kpad, m.dtype == "f16",
+                                                                       [t.cs for t, _c in self.segs], n_rows * self.g_fwd.T_total * self.Kpad)
         self.nparts = self.g_fwd.ncls * _cdiv(self.M, self.tm)
         dev = _dev()
         if self.has_bn:
@@ -359,7 +360,8 @@ class ConvOp(Op):
         wg.Kpad, wg.n_rows = self.Kpad, self.n_rows
         variant = F.WGRAD_VARIANT
         f16 = self.m.dtype == "f16"
-        if variant == 0 and F.WGRAD_HALO and wgrad_halo_patch(self.g_fwd):
+        if (variant == 0 and F.WGRAD_HALO and wgrad_halo_patch(self.g_fwd)
+                and fits_lds_dma(self.g_fwd, [t.cs for t, _c in self.segs], 0, f16, self.N * self.g_fwd.Hout * self.g_fwd.Wout * self.z.cs)):
             variant = 2         # 3x3 stride-1 layers and 4x4 / stride-2 transposed convs: LDS-DMA halo-tile kernel
         tm, tn, sk = pick_tile_wgrad(self.M, self.n_rows, [t.cs for t, _c in self.segs],
                                      wgrad_halo_class_groups(self.g_fwd) if (variant == 2 and (f16 or (F.WGRAD_TC2_F32 and self.n_rows > 32)))
@@ -520,7 +522,8 @@ class ConvOp(Op):
                 if self.strided and not acc:
                     zero_first.append(t)
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
-            a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16")
+            a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16",
+                                                               [a.seg_cs[j] for j in range(a.nseg)], width * self.g_dgrad.T_total * self.rows_pad)
             self.m.fwd_ws_users.append(a)
             self.dg_args.append((a, zero_first, fl))
             self.dg_bytes.append(float(nb + self.esz * self.out_pix * self.cout))          # ... and dz read once
@@ -637,7 +640,8 @@ class GatherDgrad:
         a.out, a.out_cs, a.out_coff, a.accumulate = self.t.grad.data_ptr(), self.t.cs, 0, acc
         a.bias, a.act, a.alpha, a.stats, a.nout = None, 0, 0.0, None, 0
         Md = op0.N * op0.g_dgrad.Hl * op0.g_dgrad.Wl
-        a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16")
+        a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16",
+                                                           [a.seg_cs[j] for j in range(a.nseg)], self.t.cs * op0.g_dgrad.T_total * self.Kg)
         self.m.fwd_ws_users.append(a)
         self.args = a
         self.flops = sum(op.flops_seg[si] for op, si in self.members)

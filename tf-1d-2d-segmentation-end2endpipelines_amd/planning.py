@@ -4,7 +4,7 @@ sweep (tools/op_bench.py).  Pure host arithmetic: no device memory, no kernel ca
 the mirrors of the library's own eligibility functions in step)."""
 from __future__ import annotations
 
-from typing import Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -187,6 +187,17 @@ def fwd_halo_patch(g: Geom) -> int:
     return 0
 
 
+LDS_DMA_LIMIT = 0x78000000       # mirror of seg_lds_dma_operand_limit() (tests/test_cabi.py keeps the two in step)
+
+
+def fits_lds_dma(g: Geom, seg_cs: Sequence[int], w_elems: int, f16: bool, dz_elems: int = 0) -> bool:
+    """Every operand the LDS-DMA kernels would address through a buffer resource - the input segments (N x Hin x Win pixels of seg_cs
+    channels each), the weight operand, for a weight gradient also dz - is below the 32-bit offset limit of those kernels."""
+    esz = 2 if f16 else 4
+    pix = g.N * g.Hin * g.Win
+    return all(pix * cs * esz < LDS_DMA_LIMIT for cs in seg_cs) and w_elems * esz < LDS_DMA_LIMIT and dz_elems * esz < LDS_DMA_LIMIT
+
+
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     """(tile_m, tile_n, variant) of a forward / data-gradient launch.  f16 = False: the parity mode (split-pair tensors, csrc
     igemm_fwd_split.hip / igemm_halo.hip SPLIT): the same kernel families with two accumulator sets per wave, hence the halo
@@ -205,13 +216,17 @@ def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
     return tm, tn, 0
 
 
-def plan_fwd(M, n_rows, g: Geom, ktot, f16: bool):
+def plan_fwd(M, n_rows, g: Geom, ktot, f16: bool, seg_cs: Optional[Sequence[int]] = None, w_elems: int = 0):
     """(tile_m, tile_n, variant, splitk) of a forward / data-gradient launch: pick_fwd, then the split of the reduction
     (seg_igemm_fwd_args.splitk) for grids that leave CUs idle - the 8x8 / 16x16 levels of a depth-5 encoder: M = 1 024 .. 4 096
     pixels against K = 4 608 .. 18 432.  Measured on MI355X, parity mode (tools/op_bench.py --splitk, 128x128 tile): enc6 data
     gradient (64 blocks) 291 -> 129 us, latent convs (128 blocks) 308 -> 220, X41 transposed conv 318 -> 212, enc5 data gradient
     (the halo kernel at 128 blocks: 194) -> 124, X31 transposed-conv data gradient (halo, 256 blocks: 278) -> 214; a 256-block
     grid with K = 4 608 (enc5 forward) does not gain, hence the floor on the slice."""
+    if seg_cs is not None and not fits_lds_dma(g, seg_cs, w_elems, f16):
+        # an operand of 1.875 GiB or more (C3 beyond batch 119): the register-staged kernel with 64-bit addresses - 128-row tiles, no split
+        tm, tn = pick_tile_fwd(M, n_rows, g.ncls, ktot)
+        return min(tm, 128), tn, 0, 1
     tm, tn, variant = pick_fwd(M, n_rows, g, ktot, f16)
     if not F.FWD_SPLITK or g.ntaps not in (1, 2, 3, 4, 9, 16):
         return tm, tn, variant, 1
