@@ -977,6 +977,41 @@ def test_adam_matches_keras_adam_three_steps():
     assert torch.equal(p16.cpu(), p.cpu().half())
 
 
+@pytest.mark.parametrize("fmt", ["f16", "split"])
+@pytest.mark.parametrize("gdt", ["f32", "bf16"])
+def test_adam_eight_per_thread_equals_the_scalar_kernel(fmt, gdt):
+    """seg_adam_step_ex updates eight parameters per thread where every stream is 32-byte aligned (plus a scalar launch for a tail
+    that is not a multiple of eight) and falls back to the scalar kernel otherwise.  The same update through both routes - aligned
+    buffers against copies shifted by one element - gives the same bits in the parameters, both moments and the GEMM operand copy
+    (fp16 or split pair), skips and counts the same non-finite gradients."""
+    torch.manual_seed(11)
+    n = 10003
+    p0 = torch.randn(n) * (10.0 ** torch.randint(-3, 2, (n,)).float())
+    m0, v0 = torch.randn(n) * 1e-2, torch.rand(n) * 1e-3
+    g = torch.randn(n) * (10.0 ** torch.randint(-6, 1, (n,)).float())
+    g[torch.tensor([5, 77, 4001, 10001])] = torch.tensor([float("nan"), float("inf"), -float("inf"), float("nan")])
+    gd = g.bfloat16() if gdt == "bf16" else g
+    ofmt = ffi.OPERAND_F16 if fmt == "f16" else ffi.OPERAND_SPLIT
+    res = []
+    for shift in (0, 1):
+        bufs = [torch.zeros(n + 8, dtype=t.dtype, device="cuda") for t in (p0, gd, m0, v0)]
+        for b, t in zip(bufs, (p0, gd, m0, v0)):
+            b[shift:shift + n] = t.cuda()
+        ptr = lambda b: C.c_void_p(b.data_ptr() + shift * b.element_size())
+        op = torch.zeros(n + 8, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ffi.call("seg_adam_step_ex", ptr(bufs[0]), ptr(bufs[1]), ffi.GRAD_BF16 if gdt == "bf16" else ffi.GRAD_F32, ptr(bufs[2]), ptr(bufs[3]), P(op), ofmt,
+                 n, 1e-3, None, 0.9, 0.999, 1e-7, 0.5, P(cnt), stream())
+        torch.cuda.synchronize()
+        assert int(cnt.cpu()) == 4
+        res.append([bufs[0][shift:shift + n].cpu(), bufs[2][shift:shift + n].cpu(), bufs[3][shift:shift + n].cpu(), op.cpu().view(torch.int32)])
+        assert float(bufs[0][shift + n:].abs().max()) == 0.0 and (shift == 0 or float(bufs[0][0]) == 0.0)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    bad = torch.tensor([5, 77, 4001, 10001])
+    assert torch.equal(res[0][0][bad], p0[bad]) and not torch.equal(res[0][0], p0)
+
+
 @pytest.mark.parametrize("kind,variant,f32", [("conv", 2, False), ("convT", 2, False), ("conv", 0, False), ("conv", 1, True)])
 def test_deterministic_pixel_split_of_the_weight_gradient(kind, variant, f32):
     """splitk > 1 with a partial-tile workspace: same gradient as the atomic form (to summation-order rounding), identical
