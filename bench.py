@@ -22,7 +22,7 @@ Besides the contract fields the line carries (all measured in this
                   MFMA work actually issued (3 x) and the fraction of peak / 3
   throughput_mode the same workload, same steps / warm-up, in dtype f16 (or parity_mode when --dtype f16 was asked for)
   inference       forward-only images/s (inference-mode BN; 2DCNN/Test.py:161)
-  extra_workloads short runs of the other BASELINE configs (C2, C5, C4 at W=32 and W=64) with their own roofline figure; C3 at batch 64
+  extra_workloads short runs of the other BASELINE configs (C2, C5, C4 at W=32 and W=64) with their own roofline figure; C3 at batch 64; C1 (1D, the reference's CPU case)
   rccl            what torch.distributed saw (backend, world size, RCCL version); with more than one rank the time each rank's
                   optimiser spent waiting for gradient slices (exposed communication)
   cpu_baseline    the oracle (torch-CPU restatement) on the host cores, bounded sample
@@ -70,13 +70,16 @@ WORKLOADS = {
     "C4w64": (dict(decoder_name="MultiResUNet", model_width=64, model_depth=5, ag=1, alpha=1.0), 512, 512, 3, 8, "bce",
               "MultiResUNet alpha 1.0 d5 W=64 + attention gates 512x512x3 bs8/GPU (BASELINE.json configs[3], wide variant)"),
     "tiny": (dict(decoder_name="UNetPP", model_width=16, model_depth=3, ds=1), 64, 64, 3, 4, "mse", "UNet++ d3 w16 64x64 bs4 (plumbing check)"),
+    # the reference's own CPU-runnable case (1DCNN/unet_variants.py: UNet(length, model_depth, num_channel, model_width, kernel_size, ...).UNet())
+    "C1": (dict(one_d=True, model_depth=3, model_width=16, kernel_size=3, problem_type="Classification", output_nums=2, ds=0), 1, 1024, 1, 8, "cce",
+           "1D UNet d3 w16 L=1024 1ch 2-class bs8 (BASELINE.json configs[0]: the reference's plumbing case; launch-bound on a GPU)"),
 }
 HBM_BOUND = ("C4", "C4w64")      # arithmetic intensity below the fp16 ridge even when fully fused
 
 
 def make_batch(model, N, H, W, Cin, loss, rank):
     gen = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand((N, H, W, Cin), generator=gen, dtype=torch.float32)
+    x = torch.rand((N, W, Cin) if model.graph.ndim == 1 else (N, H, W, Cin), generator=gen, dtype=torch.float32)
     targets = []
     first = None
     for h in model.out_heads:
@@ -98,7 +101,10 @@ def make_batch(model, N, H, W, Cin, loss, rank):
 def build_model(workload, dtype, bs=0):
     pkg = importlib.import_module(PKG)
     kw, H, W, Cin, bs0, loss, _desc = WORKLOADS[workload]
-    model = pkg.unet_model_builder(length=H, width=W, num_channels=Cin, train_mode="from_scratch", **kw).ResNet50()
+    if kw.get("one_d"):
+        model = pkg.UNet1D(W, kw["model_depth"], Cin, kw["model_width"], kw["kernel_size"], kw["problem_type"], output_nums=kw["output_nums"], ds=kw["ds"]).UNet()
+    else:
+        model = pkg.unet_model_builder(length=H, width=W, num_channels=Cin, train_mode="from_scratch", **kw).ResNet50()
     model.build(bs or bs0, dtype=dtype)
     model.compile(loss=loss, lr=2e-4)
     return model
@@ -207,13 +213,15 @@ def time_loop(fn, warmup, steps, barrier):
     return time.perf_counter() - t0
 
 
-def short_run(workload, dtype, steps, warmup, profile=True, batch=0):
-    """A short single-GPU run of another configuration / mode (or another batch): ms per step, images/s, its roofline figure."""
+def short_run(workload, dtype, steps, warmup, profile=True, batch=0, graph=False):
+    """A short single-GPU run of another configuration / mode (or another batch): ms per step, images/s, its roofline figure.
+    graph: the step replayed as one captured hipGraph (launch-bound small models)."""
     kw, H, W, Cin, bs, loss, desc = WORKLOADS[workload]
     bs = batch or bs
     model = build_model(workload, dtype, bs)
     x, targets = make_batch(model, bs, H, W, Cin, loss, 0)
-    dt = time_loop(lambda: model.train_step(x, targets), warmup, steps, torch.cuda.synchronize)
+    step = model.graphed_train_step(x, targets) if graph else model.train_step
+    dt = time_loop(lambda: step(x, targets), warmup, steps, torch.cuda.synchronize)
     ms = dt / steps * 1e3
     fl = flops_per_image(model, Cin)
     peak = PEAK_TFLOPS_F16
@@ -547,6 +555,12 @@ def main():
                 extras["C3_batch64"] = short_run("C3", args.dtype, 5, 2, profile=False, batch=64)
             except Exception as e:
                 extras["C3_batch64"] = {"error": repr(e)}
+        # ---- the reference's CPU-runnable 1D case (about 150 dependent launches of 5 - 10 us each: 1.53 ms per step launch by launch,
+        # 1.54 ms replayed as one captured hipGraph - it is bound by the kernels' own latency, not by their launches)
+        try:
+            extras["C1"] = short_run("C1", args.dtype, 200, 20, profile=False)
+        except Exception as e:
+            extras["C1"] = {"error": repr(e)}
     else:
         resident = torch.cuda.max_memory_allocated() / 1e9
 
