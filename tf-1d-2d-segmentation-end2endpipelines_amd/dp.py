@@ -34,8 +34,17 @@ def init_process_group_from_env(backend: Optional[str] = None) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
+    kw = {}
+    if backend == "gloo":
+        # one node by contract: gloo's pairwise connections over the loopback interface, whatever the container's hostname resolves to
+        # (a hostname that resolves to an unreachable address makes the connect sit in its 30-minute default), and a rendezvous that
+        # fails does so within minutes
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        import datetime
+        kw["timeout"] = datetime.timedelta(minutes=5)
     dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", 0)),
-                            world_size=int(os.environ.get("WORLD_SIZE", 1)))
+                            world_size=int(os.environ.get("WORLD_SIZE", 1)), **kw)
     return local_rank
 
 
