@@ -326,32 +326,27 @@ def cpu_baseline(workload, gpu_batch):
                       f"workload, {cores} threads = the best of the recorded sweep on a box with {nproc} hardware threads, {dt:.1f} s"}
 
 
-def launch_plan(gpus, env, argv, free_port=None):
-    """What `python bench.py --gpus N ...` has to do BEFORE anything touches the GPU (pure host logic; tests/test_bench_launcher.py):
-      ("run", None)      this process is the (only / torchrun-started) rank: carry on;
-      ("spawn", cmd)     --gpus N > 1 without a torchrun environment: start `cmd` - one fresh child
-                         `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one rank per
-                         GPU - relay its output and exit with its code (a child process, never an exec: no HIP call has been made yet
-                         here, and none will be);
-      ("error", text)    WORLD_SIZE is set and differs from --gpus: the line would report a job that was not run."""
+def launch_plan(gpus, env, argv):
+    """What `python bench.py [--gpus N] ...` has to do BEFORE anything touches the GPU (pure host logic; tests/test_bench_launcher.py).
+    `gpus` is None when --gpus was not given.  Returns (what, payload, job size):
+      ("run", None, N)     this process is the (only / torchrun-started) rank of a job of N ranks: carry on.  Under torchrun without
+                           an explicit --gpus the job size IS WORLD_SIZE (`torchrun --nproc-per-node N bench.py` keeps working);
+      ("spawn", cmd, N)    --gpus N > 1 without a torchrun environment: start `cmd` - one fresh child
+                           `python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N bench.py
+                           <same arguments>`, one rank per GPU (torchrun picks the rendezvous port itself: no pick-then-bind race; the
+                           loopback address because the container's hostname may not resolve) - relay its output and exit with its
+                           code (a child process, never an exec: no HIP call has been made yet here, and none will be);
+      ("error", text, N)   --gpus was given AND disagrees with WORLD_SIZE: the line would report a job that was not run."""
     ws = env.get("WORLD_SIZE")
     if ws is not None:
-        if int(ws) != gpus:
-            return "error", f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus} (or drop WORLD_SIZE)"
-        return "run", None
-    if gpus <= 1:
-        return "run", None
-    port = free_port() if free_port is not None else 29500
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return "spawn", cmd
-
-
-def _free_port():
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+        if gpus is not None and int(ws) != gpus:
+            return "error", f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus} (or drop --gpus / WORLD_SIZE)", gpus
+        return "run", None, int(ws)
+    if gpus is None or gpus <= 1:
+        return "run", None, 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={gpus}",
+           os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd, gpus
 
 
 def spawn_ranks(cmd):
@@ -378,7 +373,7 @@ def spawn_ranks(cmd):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="job size (ranks, one per GPU); default: WORLD_SIZE under torchrun, else 1")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
@@ -397,7 +392,7 @@ def main():
 
     # --gpus N is the job size.  N > 1 without torchrun's environment: this process becomes the launcher of N ranks (before any
     # torch.cuda call); with it, WORLD_SIZE must agree - a scaling run must never silently measure another job.
-    what, payload = launch_plan(args.gpus, os.environ, sys.argv[1:], _free_port)
+    what, payload, args.gpus = launch_plan(args.gpus, os.environ, sys.argv[1:])
     if what == "error":
         raise SystemExit(payload)
     if what == "spawn":

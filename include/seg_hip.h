@@ -322,6 +322,9 @@ int seg_bn_bwd_apply_fanout(const void* dy, const void* x, void* const* dxs, int
                             float* cat_partial, const seg_lazy_bn* lazy, int32_t nlazy, int32_t nparts, seg_stream_t stream);
 int seg_cat_bn_bwd_scatter(const void* g, const seg_cat_desc* cat, int64_t npix, int32_t cs, const float* scale, const float* mean,
                            const float* invstd, const float* c1, const float* c2, seg_stream_t stream);
+/* widest row (cs, channels) the three fused-tail entry points above take: one column group of 8 channels per thread of a block.
+ * Wider tails (MultiResUNet with model_width >= 128 at depth 5) are lowered to the separate passes by the host planner.            */
+int32_t seg_tail_row_limit(void);
 
 /* ---- channel-slice copy (materialised concatenate(axis=-1), unet_variants.py:95, when a consumer cannot walk the
  * pieces: BatchNormalization over cat[c3x3,c5x5,c7x7] in MultiResBlock).  dst[p][dst_coff+c] (+)= src[p][src_coff+c],

@@ -17,19 +17,37 @@ def _bench():
 
 def test_launch_plan():
     b = _bench()
-    assert b.launch_plan(1, {}, ["--gpus", "1"]) == ("run", None)
-    assert b.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, ["--gpus", "8"]) == ("run", None)
-    what, msg = b.launch_plan(8, {"WORLD_SIZE": "1"}, ["--gpus", "8"])
+    assert b.launch_plan(1, {}, ["--gpus", "1"]) == ("run", None, 1)
+    assert b.launch_plan(None, {}, []) == ("run", None, 1)
+    assert b.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, ["--gpus", "8"]) == ("run", None, 8)
+    what, msg, _n = b.launch_plan(8, {"WORLD_SIZE": "1"}, ["--gpus", "8"])
     assert what == "error" and "WORLD_SIZE=1" in msg
-    what, msg = b.launch_plan(1, {"WORLD_SIZE": "4"}, [])
+    what, msg, _n = b.launch_plan(1, {"WORLD_SIZE": "4"}, ["--gpus", "1"])          # an EXPLICIT --gpus that disagrees
     assert what == "error"
-    what, cmd = b.launch_plan(4, {}, ["--gpus", "4", "--steps", "3", "--warmup", "1"], lambda: 12345)
-    assert what == "spawn"
+    # `torchrun --nproc-per-node 4 bench.py` without --gpus: the job size is WORLD_SIZE (an external scaling driver may launch that way)
+    assert b.launch_plan(None, {"WORLD_SIZE": "4", "RANK": "1"}, ["--steps", "3"]) == ("run", None, 4)
+    what, cmd, n = b.launch_plan(4, {}, ["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert what == "spawn" and n == 4
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    # torchrun picks the rendezvous port itself (no pick-then-bind race) and the workers meet on the loopback address
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+
+
+def test_standalone_child_runs_two_ranks_on_the_loopback_address(tmp_path):
+    """The spawn form itself, with a stand-in for bench.py: two gloo ranks rendezvous through `--standalone --local-addr 127.0.0.1`."""
+    b = _bench()
+    child = tmp_path / "rk.py"
+    child.write_text("import os, sys, torch.distributed as dist\ndist.init_process_group('gloo')\n"
+                     "open(os.path.join(sys.argv[1], f'rank{dist.get_rank()}'), 'w').write(f\"{dist.get_world_size()} {os.environ['MASTER_ADDR']}\")\n"
+                     "dist.barrier()\ndist.destroy_process_group()\n")
+    _what, cmd, _n = b.launch_plan(2, {}, [str(tmp_path)])
+    cmd[cmd.index(os.path.join(ROOT, "bench.py"))] = str(child)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, GLOO_SOCKET_IFNAME="lo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "rank0").read_text() == "2 127.0.0.1" and (tmp_path / "rank1").read_text() == "2 127.0.0.1"
 
 
 def test_world_size_mismatch_exits_nonzero_before_touching_the_gpu():

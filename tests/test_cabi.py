@@ -40,6 +40,26 @@ def test_ffi_table_matches_header(built):
     assert L.seg_last_error() is not None
 
 
+def test_abi_version_ignores_comments_and_survives_a_missing_header(built, tmp_path, monkeypatch):
+    """The ABI version is the hash of the header's DECLARATIONS (a comment or white-space edit must not invalidate every prebuilt
+    SEG_LIB); a deployment that ships the package without include/ falls back to the version the build recorded in _abi.py, and
+    with neither the loader says which file is missing (an ImportError, not a bare FileNotFoundError from open())."""
+    be = importlib.import_module(PKG + ".build_ext")
+    want = be.abi_version()
+    hdr = open(be.ABI_HEADER).read()
+    edited = tmp_path / "seg_hip.h"
+    edited.write_text("/* a new comment */\n" + hdr.replace("\n", "\n   ", 3) + "\n// trailing remark\n")
+    monkeypatch.setattr(be, "ABI_HEADER", str(edited))
+    assert be.abi_version() == want
+    edited.write_text(hdr.replace("int32_t seg_tail_row_limit(void);", "int64_t seg_tail_row_limit(void);"))
+    assert be.abi_version() != want                              # a signature change IS a new version
+    monkeypatch.setattr(be, "ABI_HEADER", str(tmp_path / "absent.h"))
+    assert os.path.exists(be.ABI_STAMP) and be.abi_version() == want == be.recorded_abi_version()
+    monkeypatch.setattr(be, "ABI_STAMP", str(tmp_path / "absent.py"))
+    with pytest.raises(ImportError, match="seg_hip.h"):
+        be.abi_version()
+
+
 def test_struct_layout_matches_header():
     """ctypes mirrors of seg_geom / seg_igemm_*_args: field order and sizes as declared in the header."""
     ffi = importlib.import_module(PKG + "._ffi")
@@ -100,6 +120,10 @@ def test_host_and_library_agree_on_wgrad_halo_eligibility(built):
     assert seen == {0, 16, 32}
     # operand size limit of the LDS-DMA kernels: the planner routes larger operands to the register-staged kernels
     assert L.seg_lds_dma_operand_limit() == M.LDS_DMA_LIMIT == 0x78000000
+    # a row of Win * cs >= 32 M elements: a tap's byte shift would carry a masked lane's offset (2 GiB) back below the operand's end
+    wide = M.geom_conv(1, 8, 16384, 3, 3, 1, 1)
+    assert M.fits_lds_dma(wide, [1024], 9 * 1024 * 64, False) and not M.fits_lds_dma(wide, [2048], 9 * 2048 * 64, False)
+    assert L.seg_tail_row_limit() == M.TAIL_ROW_LIMIT == 2048      # widest fused BN(ReLU(a + b)) tail; wider ones take the separate passes
     g = M.geom_conv(119, 256, 256, 3, 3, 1, 1)
     assert M.fits_lds_dma(g, [64], 64 * 9 * 64, False) and not M.fits_lds_dma(M.geom_conv(120, 256, 256, 3, 3, 1, 1), [64], 64 * 9 * 64, False)
     assert M.plan_fwd(119 * 65536, 64, g, 9 * 64, False, [64], 64 * 9 * 64)[2] == 3

@@ -341,8 +341,8 @@ def test_planner_routes_oversized_operands_to_the_register_staged_kernels(monkey
         assert float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["multiresunet_ag_bce", "multiresunet1d_mse"])
-def test_fused_bn_tails_equal_the_separate_passes(name, monkeypatch):
+@pytest.mark.parametrize("name,row_limit", [("multiresunet_ag_bce", None), ("multiresunet1d_mse", None), ("multiresunet_ag_bce", "narrowest")])
+def test_fused_bn_tails_equal_the_separate_passes(name, row_limit, monkeypatch):
     """MultiResBlock / ResPath tails BN(ReLU(a + b)) as fused passes (SegModel._fuse_bn_tail) against the separate add / BN passes
     (SEG_FUSE_BN_TAILS=0): the same training step (loss, every parameter gradient) and the same predictions (inference-mode BN: the
     folded BatchNormalization takes its coefficients from the moving statistics) to rounding."""
@@ -351,6 +351,17 @@ def test_fused_bn_tails_equal_the_separate_passes(name, monkeypatch):
     m1, x, targets, loss = CASES[name]()
     m1.build(x.shape[0], dtype="f32")
     assert any(isinstance(o, M.BNOp) and o.fused_add is not None for o in m1.ops)
+    if row_limit is not None:
+        # tails wider than seg_tail_row_limit() (2 048 channels; MultiResUNet at model_width 128, depth 5) take the separate passes
+        # while the narrower ones of the same model stay fused - emulated by lowering the planner's mirror of the limit to this
+        # model's narrowest tail
+        cs_min = min(o.x.cs for o in m1.ops if isinstance(o, M.BNOp) and o.fused_add is not None)
+        monkeypatch.setattr(M.planning, "TAIL_ROW_LIMIT", cs_min)
+        torch.manual_seed(5)
+        m1, x, targets, loss = CASES[name]()
+        m1.build(x.shape[0], dtype="f32")
+        fused = [o.x.cs for o in m1.ops if isinstance(o, M.BNOp) and o.fused_add is not None]
+        assert fused and max(fused) == cs_min and any(isinstance(o, M.AddOp) and o.fused_bn is None and len(o.xs) > 1 for o in m1.ops)
     w = m1.get_weights()
     monkeypatch.setattr(M.F, "FUSE_BN_TAILS", False)
     m0, _x, _t, _l = CASES[name]()

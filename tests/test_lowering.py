@@ -78,6 +78,31 @@ def test_predict_is_one_launch_per_conv_block():
         assert Counter(M._DryRun.log)["seg_bn_fold_inference"] == convs
 
 
+def test_tails_wider_than_the_kernels_row_limit_take_the_separate_passes(monkeypatch):
+    """The fused tail kernels handle ONE column group of 8 channels per thread (seg_tail_row_limit() = 2048 channels); a MultiResBlock /
+    ResPath tail wider than that (model_width 128 at depth 5: ~3 400 channels - the reference takes any width,
+    unet_variants.py:85-122) must be lowered to the un-fused passes instead of raising in the first forward().  Checked by lowering the
+    limit below this small model's widths: every tail - BN(cat) fold, lazy inputs, virtual concatenation - falls back, none is half-fused."""
+    planning = importlib.import_module("tf-1d-2d-segmentation-end2endpipelines_amd.planning")
+    def lowered(limit):
+        monkeypatch.setattr(planning, "TAIL_ROW_LIMIT", limit)
+        m = B("MultiResUNet", 32, 32, 16, 2, alpha=1.0).build(2, dtype="f32")
+        c = Counter(n.replace("_f32", "") for n in step(m, torch.rand(2, 32, 32, 3)).elements())
+        return m, c
+    m_all, c_all = lowered(2048)
+    widths = sorted({o.x.cs for o in m_all.ops if isinstance(o, M.BNOp) and o.fused_add is not None})
+    assert len(widths) >= 2
+    m, c = lowered(widths[0])                               # only the narrowest tails still fit
+    fused = [o for o in m.ops if isinstance(o, M.BNOp) and o.fused_add is not None]
+    assert fused and all(o.x.cs <= widths[0] for o in fused)
+    assert 0 < c["seg_add_act_stats_fwd"] < c_all["seg_add_act_stats_fwd"] and c["seg_add_act_fwd"] > c_all["seg_add_act_fwd"]
+    m, c = lowered(widths[0] - 8)                           # nothing fits: the round-2 lowering, no tail kernel at all
+    assert not any(isinstance(o, M.BNOp) and (o.fused_add is not None or o.folded_into is not None or o.pieces is not None) for o in m.ops)
+    assert not any(isinstance(o, M.ConvOp) and o.lazy for o in m.ops)
+    assert c["seg_add_act_stats_fwd"] == 0 and c["seg_bn_bwd_apply_fanout"] == 0 and c["seg_cat_bn_bwd_scatter"] == 0
+    assert c["seg_add_act_fwd"] > 0 and c["seg_add_act_bwd"] > 0
+
+
 def test_multires_tails_are_fused_passes(monkeypatch):
     """BN(ReLU(a + b)) - the tail of a MultiResBlock and of every ResPath iteration (unet_variants.py:97-99, :118-120): the add
     kernel applies the ReLU, normalises a BatchNormalization input on the fly (BN(cat) is never written) and delivers the statistics

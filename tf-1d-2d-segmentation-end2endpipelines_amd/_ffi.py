@@ -106,6 +106,7 @@ _PROTOS = {
     "seg_wgrad_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_wgrad_halo_class_groups": ([C.POINTER(Geom)], C.c_int),
     "seg_lds_dma_operand_limit": ([], C.c_int64),
+    "seg_tail_row_limit": ([], C.c_int32),
     "seg_fwd_halo_patch": ([C.POINTER(Geom)], C.c_int),
     "seg_bn_stats": ([vp, i64, i32, i32, i32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_finalize": ([vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp], C.c_int),

@@ -2278,6 +2278,8 @@ static int cat_to_dev(const seg_cat_desc* cat, int32_t cs, bool backward, CatDev
   return SEG_OK;
 }
 
+extern "C" int32_t seg_tail_row_limit(void) { return 8 * TPB; }
+
 template <typename T>
 static int seg_add_act_stats_fwd_impl(const void* const* xs, const float* const* scales, const float* const* shifts, const int32_t* relus, int32_t n,
                                       const seg_cat_desc* cat, const float* cat_scale, const float* cat_shift, void* y, int64_t npix, int32_t cs,

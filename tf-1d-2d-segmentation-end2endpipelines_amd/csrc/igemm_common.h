@@ -441,6 +441,19 @@ __device__ __forceinline__ void wgrad_mode_dispatch(int mode, F&& f) {
 // planner (planning.plan_fwd / ops.ConvOp) mirrors the limit.
 constexpr unsigned OOB_OFF = 0x80000000u;
 constexpr long LDS_DMA_LIMIT = 0x78000000L;
+// The per-tap LDS-DMA kernels add a tap's byte shift (tap_dy * Win + tap_dx) * cs * esz to a lane offset that may already be OOB_OFF
+// (channel padding): the sum must stay at or beyond every legal num_records, i.e. the largest shift below OOB_OFF - LDS_DMA_LIMIT
+// (128 MiB: a row of Win * cs >= 32 M elements) - otherwise a masked lane would fetch live data instead of zeros.  Checked by
+// fwd2_eligible() and mirrored by planning.fits_lds_dma(); such a geometry takes the register-staged kernels (64-bit addresses).
+constexpr long LDS_DMA_MAX_SHIFT = (long)OOB_OFF - LDS_DMA_LIMIT;
+inline long max_tap_shift_elems(const seg_geom& g) {
+  long m = 0;
+  for (int e = 0; e < g.ncls * g.ntaps && e < SEG_MAX_TAPS; ++e) {
+    const long d = (long)g.tap_dy[e] * g.Win + g.tap_dx[e];
+    m = d < 0 ? (m < -d ? -d : m) : (m < d ? d : m);
+  }
+  return m;
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

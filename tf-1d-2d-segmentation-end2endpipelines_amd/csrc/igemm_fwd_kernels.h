@@ -466,9 +466,9 @@ inline bool fwd2_eligible(const seg_igemm_fwd_args& a, int esz) {
   const int nt = a.g.ntaps;
   if (!(nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 9 || nt == 16)) return false;
   const long lim = LDS_DMA_LIMIT;
-  const long pix = (long)a.g.N * a.g.Hin * a.g.Win;
+  const long pix = (long)a.g.N * a.g.Hin * a.g.Win, shift = max_tap_shift_elems(a.g);
   for (int s = 0; s < a.nseg; ++s)
-    if (pix * a.seg_cs[s] * esz >= lim) return false;
+    if (pix * a.seg_cs[s] * esz >= lim || shift * a.seg_cs[s] * esz >= LDS_DMA_MAX_SHIFT) return false;
   if ((long)a.n_rows * a.g.T_total * a.Kpad * esz >= lim) return false;
   return true;
 }

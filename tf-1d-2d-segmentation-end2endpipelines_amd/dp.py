@@ -38,11 +38,16 @@ def init_process_group_from_env(backend: Optional[str] = None) -> int:
     if backend == "gloo":
         # one node by contract: gloo's pairwise connections over the loopback interface, whatever the container's hostname resolves to
         # (a hostname that resolves to an unreachable address makes the connect sit in its 30-minute default), and a rendezvous that
-        # fails does so within minutes
-        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+        # fails does so within minutes.  The value is also the timeout of every gloo collective afterwards, so it must cover the
+        # longest stretch one rank may spend alone between two collectives (rank 0 validating / writing a checkpoint in harness.fit,
+        # a first-step library build): 15 minutes unless SEG_DIST_TIMEOUT_S says otherwise.
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import datetime
-        kw["timeout"] = datetime.timedelta(minutes=5)
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("SEG_DIST_TIMEOUT_S", "900")))
+    elif os.environ.get("SEG_DIST_TIMEOUT_S"):
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ["SEG_DIST_TIMEOUT_S"]))
     dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", 0)),
                             world_size=int(os.environ.get("WORLD_SIZE", 1)), **kw)
     return local_rank

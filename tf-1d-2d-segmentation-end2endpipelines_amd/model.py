@@ -36,6 +36,7 @@ import torch
 
 from . import _ffi
 from . import flags as F
+from . import planning
 from ._ffi import TransposeDesc, ACT, LOSS, OPTIMIZER, Geom, IgemmFwdArgs, IgemmWgradArgs
 from .graph import Graph, Node, ParamSpec
 from .splitfmt import split_pack, split_unpack
@@ -43,7 +44,7 @@ from .splitfmt import split_pack, split_unpack
 # flags.py (switches); their names stay importable from here (tests, tools and bench.py address them as `model.<name>`)
 from .planning import (_r8, _r32, _cdiv, _same_pad, _fill_geom, geom_conv, geom_conv_dgrad, geom_convT, geom_convT_dgrad, pack_gemm_weight,
                        unpack_gemm_weight, pick_tile_fwd, wgrad_taps_per_block, fwd_halo_patch, pick_fwd, plan_fwd, fwd_workspace_bytes,
-                       wgrad_halo_patch, wgrad_halo_class_groups, pick_split_halo, pick_tile_wgrad, fits_lds_dma, LDS_DMA_LIMIT, _tail_parts)
+                       wgrad_halo_patch, wgrad_halo_class_groups, pick_split_halo, pick_tile_wgrad, fits_lds_dma, LDS_DMA_LIMIT, TAIL_ROW_LIMIT, _tail_parts)
 from .ops import (_DryRun, _dev, KernelProfile, _Mode, call, _stream, _p, DevTensor, Slot, ParamStore, Op, InputOp, ConvOp, GatherDgrad,
                   plan_gathers, _pad_to, HeadOp, WideHeadOp, ReshapeOp, BNOp, ConcatOp, AddOp, MulOp, UpsampleOp, PoolOp)
 
@@ -485,6 +486,8 @@ class SegModel:
         g = self.graph
         if not F.FUSE_BN_TAILS or bop.act is not None:
             return
+        if bop.x.cs > planning.TAIL_ROW_LIMIT:                # wider than the tail kernels' one column group: the separate passes
+            return
         add = next((o for o in reversed(self.ops[:-1]) if isinstance(o, AddOp) and o.out is bop.x), None)
         if add is None or len(add.xs) < 2 or add.fused_bn is not None or ACT[add.act] not in (ACT[None], ACT["relu"]):
             return
@@ -505,7 +508,7 @@ class SegModel:
                 # the add's gradient for the backward scatter: input 0, checked in AddOp.plan_backward)
                 co = next((o for o in self.ops if isinstance(o, ConcatOp) and o.out is b1.x), None)
                 bn1 = g.nodes[addn.inputs[k]]
-                if (F.TAIL_VIRTUAL_CAT and F.TAIL_SHARED_GRAD and co is not None and k > 0 and len(co.segs) <= 4 and b1.C <= 2048
+                if (F.TAIL_VIRTUAL_CAT and F.TAIL_SHARED_GRAD and co is not None and k > 0 and len(co.segs) <= 4 and b1.C <= planning.TAIL_ROW_LIMIT
                         and list(cons[bn1.inputs[0]]) == [bn1.idx]
                         and any(isinstance(o, ConvOp) and o.out is add.xs[0] and o.has_bn for o in self.ops)):
                     co.virtual = True

@@ -188,6 +188,8 @@ def fwd_halo_patch(g: Geom) -> int:
 
 
 LDS_DMA_LIMIT = 0x78000000       # mirror of seg_lds_dma_operand_limit() (tests/test_cabi.py keeps the two in step)
+LDS_DMA_MAX_SHIFT = 0x80000000 - LDS_DMA_LIMIT      # largest tap byte shift of the per-tap LDS-DMA kernels (igemm_common.h)
+TAIL_ROW_LIMIT = 2048            # mirror of seg_tail_row_limit(): widest BN(ReLU(a + b)) tail the fused tail kernels take (same test)
 
 
 def fits_lds_dma(g: Geom, seg_cs: Sequence[int], w_elems: int, f16: bool, dz_elems: int = 0) -> bool:
@@ -195,7 +197,10 @@ def fits_lds_dma(g: Geom, seg_cs: Sequence[int], w_elems: int, f16: bool, dz_ele
     channels each), the weight operand, for a weight gradient also dz - is below the 32-bit offset limit of those kernels."""
     esz = 2 if f16 else 4
     pix = g.N * g.Hin * g.Win
-    return all(pix * cs * esz < LDS_DMA_LIMIT for cs in seg_cs) and w_elems * esz < LDS_DMA_LIMIT and dz_elems * esz < LDS_DMA_LIMIT
+    # ... and the largest tap shift of the per-tap kernels keeps a masked lane (offset 2 GiB) beyond every operand: below 128 MiB
+    shift = max([abs(g.tap_dy[e] * g.Win + g.tap_dx[e]) for e in range(g.ncls * g.ntaps)] + [0])
+    return (all(pix * cs * esz < LDS_DMA_LIMIT and shift * cs * esz < LDS_DMA_MAX_SHIFT for cs in seg_cs) and w_elems * esz < LDS_DMA_LIMIT
+            and dz_elems * esz < LDS_DMA_LIMIT)
 
 
 def pick_fwd(M, n_rows, g: Geom, ktot, f16: bool):
