@@ -88,11 +88,8 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
 // sizeof(split_t) == 4: element-granular pointer arithmetic (pix * cs + coff with coff % 8 == 0) addresses a group's 32 bytes
 // exactly like an fp32 tensor would; only access INSIDE a group differs (load1 / store1 below).
 struct split_t { uint32_t raw; };
-#ifndef SEG_SPLIT_SCALE_F
-#define SEG_SPLIT_SCALE_F 2048.f
-#endif
-constexpr float SPLIT_SCALE = SEG_SPLIT_SCALE_F;
-constexpr float SPLIT_INV = 1.f / SEG_SPLIT_SCALE_F;
+constexpr float SPLIT_SCALE = 2048.f;
+constexpr float SPLIT_INV = 1.f / 2048.f;
 
 template <> __device__ __forceinline__ void load8<split_t>(const split_t* p, float* f) {
   const h8 hi = __builtin_bit_cast(h8, ld16(p)), lo = __builtin_bit_cast(h8, ld16(p + 4));

@@ -6,11 +6,9 @@ channels of an 8-aligned group are stored as [8 hi | 8 lo] = 32 bytes, so that e
 torch sees such a buffer as float32 of the same shape (opaque bits); these two functions convert whole tensors whose last
 axis is a multiple of 8.  They are used by tests and tools to hand operands to / read results from single kernels - the
 engine itself converts at its boundary on the device (seg_pack_input_f32 / the fp32 output heads / seg_unpack_f32_f32)."""
-import os
-
 import torch
 
-SPLIT_SCALE = float(os.environ.get("SEG_SPLIT_SCALE", "2048"))
+SPLIT_SCALE = 2048.0
 
 
 def split_pack(x: torch.Tensor) -> torch.Tensor:
