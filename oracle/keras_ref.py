@@ -87,6 +87,23 @@ def same_pad(n_in: int, k: int, s: int) -> Tuple[int, int]:
     return total // 2, total - total // 2
 
 
+_NARROW = 16
+
+
+def _conv(xin, w, bias, stride, transposed=False):
+    """F.conv2d / F.conv_transpose2d on the NHWC tensor's NCHW view (channels-last strides: oneDNN's fast path, ~1.6 x the NCHW
+    kernels on wide layers).  NARROW layers get a contiguous NCHW copy instead: with torch 2.10 / oneDNN on this image the
+    channels-last BACKWARD of a convolution with a handful of channels (the attention gate's theta / phi / psi convs at model
+    widths 4 - 8, unet_variants.py:69-78) corrupts the heap when it runs on several threads - "double free or corruption",
+    "corrupted size vs. prev_size" or a segmentation fault in about one of six random attention-gate models
+    (tools/fuzz_models.py; reproducible with the oracle alone, never with one thread, with oneDNN off or with NCHW inputs).
+    Same arithmetic either way; the copy costs nothing at these widths."""
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    if min(cin, cout) <= _NARROW:
+        xin = xin.contiguous()
+    return (F.conv_transpose2d if transposed else F.conv2d)(xin, w, bias, stride=stride)
+
+
 def conv2d_same(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tensor], strides=(1, 1)) -> torch.Tensor:
     """tf.keras.layers.Conv2D(padding='same') - cross-correlation, kernel (kh,kw,Cin,Cout).
     Call sites: `2D/models/unet_variants.py:9,69,71,75,136,1106`; 1D `1D/unet_variants.py:55`."""
@@ -94,7 +111,7 @@ def conv2d_same(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[torch.Tens
     pt, pb = same_pad(x.shape[1], kh, strides[0])
     pl, pr = same_pad(x.shape[2], kw, strides[1])
     xin = F.pad(_nchw(x), (pl, pr, pt, pb))
-    y = F.conv2d(xin, kernel.permute(3, 2, 0, 1), bias, stride=strides)
+    y = _conv(xin, kernel.permute(3, 2, 0, 1).contiguous(), bias, strides)
     return _nhwc(y)
 
 
@@ -105,7 +122,7 @@ def conv2d_transpose_same(x: torch.Tensor, kernel: torch.Tensor, bias: Optional[
     kh, kw = kernel.shape[0], kernel.shape[1]
     sh, sw = strides
     H, W = x.shape[1], x.shape[2]
-    full = F.conv_transpose2d(_nchw(x), kernel.permute(3, 2, 0, 1), None, stride=strides)   # (in-1)*s + k
+    full = _conv(_nchw(x), kernel.permute(3, 2, 0, 1).contiguous(), None, strides, transposed=True)   # (in-1)*s + k
     pbh = max(kh - sh, 0) // 2
     pbw = max(kw - sw, 0) // 2
     need_h, need_w = pbh + H * sh, pbw + W * sw

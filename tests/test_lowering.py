@@ -177,7 +177,10 @@ def test_accumulate_flags_follow_consumer_count():
                                 lambda: B("UNetPP", 32, 32, 16, 3, ds=1, ag=1),
                                 lambda: B("UNet3P", 32, 32, 8, 2, ds=1),
                                 lambda: segamd.UNet1D(64, 2, 1, 16, 3, ds=1, ag=1).UNet(),
-                                lambda: segamd.BCDUNet(64, 2, 1, 16, 3, lstm=1, dense_loop=2).BCDUNet()])
+                                lambda: segamd.BCDUNet(64, 2, 1, 16, 3, lstm=1, dense_loop=2).BCDUNet(),
+                                # ConvLSTM filter counts that are not multiples of 8 (4, 12 / 3): gate blocks padded to 8 in the engine
+                                lambda: B("UNet", 16, 16, 4, 2, num_channels=5, lstm=1),
+                                lambda: B("UNetP", 6, 2, 6, 1, num_channels=3, ds=1, lstm=1, dense_loop=2)])
 def test_weight_layout_roundtrip(mk):
     m = mk().build(2, dtype="f16")
     w = m.get_weights()
@@ -226,8 +229,21 @@ def test_unsupported_layers_say_so():
     m.build(2, dtype="f16")
     kinds = [type(o).__name__ for o in m.ops]
     assert kinds.count("ReshapeOp") == 2 and m.store.slots["ae/features/kernel"].spec.shape == (8 * 8 * 32, 16)
-    with pytest.raises(NotImplementedError, match="ConvLSTM filters"):
-        B("UNet", 32, 32, 8, 2, lstm=1).build(2, dtype="f16")
+    # ... also when the flattened sample H*W*C is not a multiple of 8 (until round 5: NotImplementedError): one copy per sample then
+    m = B("MultiResUNet", 8, 8, 6, 2, num_channels=3, ae=1, feature_number=24, alpha=1.67, is_transconv=False).build(3, dtype="f32")
+    rs = [o for o in m.ops if type(o).__name__ == "ReshapeOp"]
+    assert len(rs) == 2 and rs[0].per_sample and rs[0].hwc == 156 and not rs[1].per_sample and rs[1].hwc % 8 == 0
+    c = step(m, torch.rand(3, 8, 8, 3))
+    assert c["seg_copy_channels_f32"] == 2 * 3 + 2           # forward and backward: one launch per sample for the padded row, one otherwise
+    # a ConvLSTM whose filter count is not a multiple of 8 lowers too (gate blocks padded to 8 channels in the engine; until round 5
+    # this raised NotImplementedError although the reference takes any model_width, unet_variants.py:148)
+    m = B("UNet", 32, 32, 12, 2, lstm=1).build(2, dtype="f16")
+    lstm = [o for o in m.ops if isinstance(o, M.ConvOp) and o.kind == "convlstm"]
+    assert lstm and all(o.F8 == (o.F + 7) // 8 * 8 and o.cout == 4 * o.F8 and o.cout_logical == 4 * o.F for o in lstm)
+    assert any(o.z.gate_pad is not None for o in lstm)
+    # what Keras refuses at construction is refused the same way: MultiResUNet with alpha * model_width < 6 asks for 0 filters
+    with pytest.raises(ValueError, match="filters"):
+        B("MultiResUNet", 24, 32, 6, 3, num_channels=1, alpha=0.5).build(2, dtype="f16")
 
 
 def test_parity_mode_tiles_have_a_kernel_instance():

@@ -69,6 +69,14 @@ def _pair(v) -> Tuple[int, int]:
     return (int(v), int(v))
 
 
+def _check_filters(filters, name):
+    """Keras refuses a convolution without output channels when the layer is constructed (keras/layers/convolutional/base_conv.py:
+    "Invalid value for argument `filters`. Expected a strictly positive value."): MultiResUNet with alpha * model_width < 6 asks for
+    int(W * 0.167) = 0 filters (unet_variants.py:89) - the same ValueError here, not a division by zero in the planner."""
+    if int(filters) <= 0:
+        raise ValueError(f"Invalid value for argument `filters`. Expected a strictly positive value. Received filters={filters} ({name}).")
+
+
 class Graph:
     """Append-only layer graph with Keras shape inference for the ops the hot path uses."""
 
@@ -108,6 +116,7 @@ class Graph:
         kh, kw = _pair(kernel) if self.ndim == 2 else (1, int(kernel if not isinstance(kernel, (tuple, list)) else kernel[0]))
         sh, sw = _pair(strides) if self.ndim == 2 else (1, int(strides if not isinstance(strides, (tuple, list)) else strides[0]))
         H, W, C = x.shape
+        _check_filters(filters, name)
         Ho, Wo = -(-H // sh), -(-W // sw)
         fan = (kh * kw * C, kh * kw * filters)
         ps = [ParamSpec(f"{name}/kernel", (kh, kw, C, filters), init, True, fan)]
@@ -121,6 +130,7 @@ class Graph:
         kh, kw = _pair(kernel) if self.ndim == 2 else (1, int(kernel if not isinstance(kernel, (tuple, list)) else kernel[0]))
         sh, sw = _pair(strides) if self.ndim == 2 else (1, int(strides if not isinstance(strides, (tuple, list)) else strides[0]))
         H, W, C = x.shape
+        _check_filters(filters, name)
         # keras fan computation for a (kh,kw,Cout,Cin) kernel: receptive*shape[-2] , receptive*shape[-1]
         fan = (kh * kw * filters, kh * kw * C)
         ps = [ParamSpec(f"{name}/kernel", (kh, kw, filters, C), init, True, fan),

@@ -360,8 +360,6 @@ class SegModel:
                     act, alpha, last = an.attrs["fn"], an.attrs["alpha"], an
                     chain.append(an)
                 F = n.attrs["filters"] if k == "convlstm" else 0
-                if k == "convlstm" and (F % 8):
-                    raise NotImplementedError(f"{n.name}: ConvLSTM filters must be a multiple of 8 (got {F})")
                 out = DevTensor(last.name, N, last.shape[0], last.shape[1], last.shape[2])
                 pooled, psize, pool_node = None, (1, 1), None
                 for c in cons[last.idx]:

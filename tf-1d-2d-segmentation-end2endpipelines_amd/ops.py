@@ -114,11 +114,20 @@ class DevTensor:
         """fp32 values of a storage tensor (fp16, or split pairs typed float32)."""
         return split_unpack(t) if t.dtype == torch.float32 else t.float()
 
+    gate_pad: Optional[Tuple[int, int]] = None      # (F, F8): the four ConvLSTM gate blocks are stored F8 channels apart (ConvOp)
+
+    def _logical(self, v: torch.Tensor) -> torch.Tensor:
+        v = v[..., :self.C]
+        if self.gate_pad is not None:
+            Fl, F8 = self.gate_pad
+            v = torch.cat([v[..., gi * F8:gi * F8 + Fl] for gi in range(4)], dim=-1)
+        return v
+
     def values(self) -> torch.Tensor:
-        return self.decode(self.buf)[..., :self.C]
+        return self._logical(self.decode(self.buf))
 
     def grad_values(self) -> Optional[torch.Tensor]:
-        return None if self.grad is None else self.decode(self.grad)[..., :self.C]
+        return None if self.grad is None else self._logical(self.decode(self.grad))
 
     def claim(self, owner: Optional[tuple] = None) -> int:
         """Returns the accumulate flag for the next producer of this tensor's gradient."""
@@ -222,7 +231,13 @@ class ConvOp(Op):
         N, H, W = t0.N, t0.H, t0.W
         self.N, self.H, self.W = N, H, W
         self.T = kh * kw
-        self.cout = node.shape[2] if kind != "convlstm" else 4 * lstm_F
+        # ConvLSTM: the conv produces the four gate pre-activations [i | f | c | o].  The gate kernel walks 8-channel groups, so a
+        # gate block is padded to F8 = F rounded up to 8 (the reference takes any filter count, unet_variants.py:148): engine
+        # channel g * F8 + c is Keras column g * F + c, the padding rows have zero weights and bias, z = 0 there, h = 0.5 tanh(0) = 0
+        # and their gradients are exactly zero, so they stay zero under every optimiser.
+        self.F8 = _r8(lstm_F)
+        self.cout = node.shape[2] if kind != "convlstm" else 4 * self.F8
+        self.cout_logical = node.shape[2] if kind != "convlstm" else 4 * lstm_F
         self.n_rows = _r8(self.cout)
         # ---- K layout over the (virtual) concat
         self.woff, k = [], 0
@@ -246,6 +261,8 @@ class ConvOp(Op):
         self.has_bn = bn is not None
         if self.has_bn or kind == "convlstm":
             self.z = DevTensor(node.name + ":z", N, Ho, Wo, self.cout)
+            if kind == "convlstm" and self.F8 != lstm_F:
+                self.z.gate_pad = (lstm_F, self.F8)       # values() / grad_values() hand out the Keras gate layout [i | f | c | o] x F
         else:
             self.z = out
         assert self.z.cs == self.n_rows, (node.name, self.z.cs, self.n_rows)
@@ -254,10 +271,26 @@ class ConvOp(Op):
         n_rows, T, Kpad, woff, cout = self.n_rows, self.T, self.Kpad, list(self.woff), self.cout
         transposed = kind == "convT"
 
+        Fl, F8 = lstm_F, self.F8
+        gate_pad = kind == "convlstm" and Fl != F8
+
+        def spread(a):      # [..., 4 F] (Keras gate columns) -> [..., 4 F8]
+            o = np.zeros(a.shape[:-1] + (4 * F8,), a.dtype)
+            for gi in range(4):
+                o[..., gi * F8:gi * F8 + Fl] = a[..., gi * Fl:(gi + 1) * Fl]
+            return o
+
+        def gather(a):      # the inverse
+            return np.concatenate([a[..., gi * F8:gi * F8 + Fl] for gi in range(4)], axis=-1)
+
         def to_engine(kern):
+            if gate_pad:
+                kern = spread(np.asarray(kern))
             return pack_gemm_weight(kern, cin_l, woff, n_rows, Kpad, transposed).reshape(-1)
 
         def from_engine(flat, shape=node.params[0].shape):
+            if gate_pad:
+                return gather(unpack_gemm_weight(flat, tuple(shape[:-1]) + (4 * F8,), cin_l, woff, n_rows, Kpad, transposed)).copy()
             return unpack_gemm_weight(flat, shape, cin_l, woff, n_rows, Kpad, transposed)
 
         kspec = node.params[0]
@@ -267,7 +300,10 @@ class ConvOp(Op):
         for ps in node.params[1:]:
             if ps.name.endswith("/bias"):
                 self.bname = ps.name
-                st.add(ps, n_rows, lambda b: np.pad(b, (0, n_rows - b.shape[0])), lambda f, c=cout: f[:c].copy())
+                if gate_pad:
+                    st.add(ps, n_rows, lambda b: np.pad(spread(np.asarray(b)), (0, n_rows - 4 * F8)), lambda f: gather(f[:4 * F8]).copy())
+                else:
+                    st.add(ps, n_rows, lambda b: np.pad(b, (0, n_rows - b.shape[0])), lambda f, c=cout: f[:c].copy())
             else:   # ConvLSTM recurrent kernel: a weight of the Keras layer that the T = 1 forward never reads
                 st.add(ps, int(np.prod(ps.shape)), lambda a: a.reshape(-1), lambda f, sh_=ps.shape: f.reshape(sh_).copy())
         if self.has_bn:
@@ -291,8 +327,8 @@ class ConvOp(Op):
         self.need_dgrad = [t.needs_grad for t, _c in segs]
         # algorithmic FLOPs (2*MAC over logical channels): forward == weight gradient; data gradient per segment
         pix_taps = self.N * self.g_fwd.Hl * self.g_fwd.Wl * self.g_fwd.ncls * self.g_fwd.ntaps
-        self.flops_fwd = 2.0 * pix_taps * sum(cin_l) * self.cout
-        self.flops_seg = [2.0 * pix_taps * c * self.cout for c in cin_l]
+        self.flops_fwd = 2.0 * pix_taps * sum(cin_l) * self.cout_logical
+        self.flops_seg = [2.0 * pix_taps * c * self.cout_logical for c in cin_l]
         # algorithmic HBM bytes of a launch (logical channels, every operand once): input + output + weights, in the storage format
         esz = self.esz = 2 if m.dtype == "f16" else 4
         self.in_pix, self.out_pix = N * H * W, N * Ho * Wo
@@ -454,7 +490,7 @@ class ConvOp(Op):
                  self.z.W, self.n_rows, self.cout, _p(self.scale), _p(self.shift), ACT[self.act], float(self.alpha),
                  _p(self.pooled.buf) if self.pooled is not None else None, ph, pw, s)
         elif self.kind == "convlstm":
-            call("seg_convlstm_gate_fwd", _p(self.z.buf), self.z.cs, _p(self.out.buf), self.out.cs, self.z.npix, self.F, s)
+            call("seg_convlstm_gate_fwd", _p(self.z.buf), self.z.cs, _p(self.out.buf), self.out.cs, self.z.npix, self.F8, s)
         elif self.pooled is not None:
             call("seg_maxpool_fwd", _p(self.out.buf), _p(self.pooled.buf), self.out.N, self.out.H, self.out.W, self.out.cs,
                  self.pool_size[0], self.pool_size[1], s)
@@ -559,7 +595,7 @@ class ConvOp(Op):
             dz = dA
         elif self.kind == "convlstm":
             dz = self.z.ensure_grad()
-            call("seg_convlstm_gate_bwd", _p(self.out.grad), self.out.cs, _p(self.z.buf), self.z.cs, _p(dz), self.z.npix, self.F, s)
+            call("seg_convlstm_gate_bwd", _p(self.out.grad), self.out.cs, _p(self.z.buf), self.z.cs, _p(dz), self.z.npix, self.F8, s)
             self._bias_grad(dz, s, gs_inv)
         else:
             dz = self.out.grad
@@ -809,16 +845,32 @@ class ReshapeOp(Op):
     def __init__(self, m, x: DevTensor, out: DevTensor, to_flat: bool):
         self.m, self.x, self.out, self.to_flat = m, x, out, to_flat
         img, flat = (x, out) if to_flat else (out, x)
-        if flat.cs != img.H * img.W * img.C:
-            raise NotImplementedError(f"{flat.name}: the flattened extent H*W*C = {img.H * img.W * img.C} must be a multiple of 8")
         self.img, self.flat = img, flat
+        self.hwc = img.H * img.W * img.C
+        assert flat.C == self.hwc and flat.cs >= self.hwc
+        # flat.cs == H*W*C: the whole batch is ONE copy (the flat tensor read as N*H*W rows of C elements).  Otherwise (H*W*C not a
+        # multiple of 8: the row of a sample is padded) one copy per sample, each from / to the start of that sample's row; the
+        # padding of the flat row is never written and stays zero
+        self.per_sample = flat.cs != self.hwc
 
     def _copy(self, src_is_img: bool, src, dst, accumulate: int):
-        img = self.img
-        if src_is_img:
-            call("seg_copy_channels", _p(src), img.cs, 0, _p(dst), img.C, 0, img.C, img.npix, accumulate, _stream())
-        else:
-            call("seg_copy_channels", _p(src), img.C, 0, _p(dst), img.cs, 0, img.C, img.npix, accumulate, _stream())
+        img, flat = self.img, self.flat
+        esz = src.element_size()
+        if not self.per_sample:
+            if src_is_img:
+                call("seg_copy_channels", _p(src), img.cs, 0, _p(dst), img.C, 0, img.C, img.npix, accumulate, _stream())
+            else:
+                call("seg_copy_channels", _p(src), img.C, 0, _p(dst), img.cs, 0, img.C, img.npix, accumulate, _stream())
+            return
+        hw = img.H * img.W
+        for n in range(img.N):
+            io, fo = n * hw * img.cs * esz, n * flat.cs * esz
+            if src_is_img:
+                call("seg_copy_channels", C.c_void_p(src.data_ptr() + io), img.cs, 0, C.c_void_p(dst.data_ptr() + fo), img.C, 0, img.C, hw,
+                     accumulate, _stream())
+            else:
+                call("seg_copy_channels", C.c_void_p(src.data_ptr() + fo), img.C, 0, C.c_void_p(dst.data_ptr() + io), img.cs, 0, img.C, hw,
+                     accumulate, _stream())
 
     def forward(self, training):
         self._copy(self.to_flat, self.x.buf, self.out.buf, 0)

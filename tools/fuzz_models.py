@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the builder API surface: random constructor arguments (decoder, depth, width, image size, channel / class
+counts, the ds / ae / ag / lstm / is_transconv / alpha / dense_loop / feature_number flags, 1D and 2D, odd batches) -> the engine in
+the parity mode (forward + loss + backward through the C ABI) against the oracle run on the same graph, weights and inputs.
+
+    python tools/fuzz_models.py --n 200 --seed 1 [--dtype f32] [--only 2d|1d] > gpurun_out/fuzz.log
+
+Every case prints one line (OK / FAIL / RAISED with the constructor call); the summary at the end lists what to look at.  A case
+counts as failed when an output is off by more than 1e-3 (the north-star bound; the kernels deliver ~1e-5), the loss by more than
+1e-5 relative, a parameter gradient with the GPU's branch decisions imposed by more than 5e-4 relative L2 (measured ~1e-5), or
+when the engine raises where the oracle's graph runs.  Build-authored test tooling; needs an MI355X."""
+import argparse
+import os
+import random
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+
+import segamd
+import gpu_util as U
+
+
+def targets_for(model, x, loss, rng):
+    g = model.graph
+    tg = []
+    for o in g.outputs:
+        H, W, C = g.nodes[o].shape
+        shape = (x.shape[0], W, C) if g.ndim == 1 else (x.shape[0], H, W, C)
+        if loss == "cce":
+            idx = torch.randint(0, C, shape[:-1])
+            tg.append(torch.nn.functional.one_hot(idx, C).float())
+        elif loss == "bce":
+            tg.append((torch.rand(shape) > 0.5).float())
+        else:
+            tg.append(torch.rand(shape))
+    return tg
+
+
+def sample_2d(rng):
+    dec = rng.choice(["UNet", "UNet", "UNetE", "UNetP", "UNetPP", "UNetPP", "UNet3P", "MultiResUNet", "MultiResUNet"])
+    depth = rng.choice([1, 2, 2, 3, 3, 4])
+    unit = 2 ** depth
+    H = unit * rng.choice([1, 2, 3, 4, 5, 8])
+    W = unit * rng.choice([1, 2, 3, 4, 6, 8])
+    while H * W > 96 * 96:
+        H, W = max(unit, H // 2), max(unit, W // 2)
+    width = rng.choice([4, 6, 8, 12, 16, 20, 32, 40])
+    kw = dict(num_channels=rng.choice([1, 3, 3, 4, 5]), output_nums=rng.choice([1, 1, 1, 2, 4, 9]), ds=rng.choice([0, 0, 1]),
+              ae=rng.choice([0, 0, 0, 1]), ag=rng.choice([0, 0, 1]), lstm=rng.choice([0, 0, 1]), dense_loop=rng.choice([1, 1, 2, 3]),
+              feature_number=rng.choice([8, 24, 50]), is_transconv=rng.choice([True, True, False]),
+              alpha=rng.choice([1.0, 1.0, 1.67, 0.5]))
+    fa = "softmax" if kw["output_nums"] > 1 and rng.random() < 0.6 else rng.choice(["sigmoid", "sigmoid", "linear"]) if kw["output_nums"] == 1 else "sigmoid"
+    kw["final_activation"] = fa
+    loss = "cce" if fa == "softmax" else rng.choice(["bce", "mse"]) if fa == "sigmoid" else "mse"
+    if kw["ds"] == 1 and loss == "cce":
+        loss = "mse"                      # the deep-supervision levels are one-channel maps
+    N = rng.choice([1, 2, 2, 3])
+    call = f'unet_model_builder({dec!r}, {H}, {W}, {width}, {depth}, ' + ", ".join(f"{k}={v!r}" for k, v in kw.items()) + f', train_mode="from_scratch").ResNet50()  batch {N} loss {loss}'
+    make = lambda: segamd.unet_model_builder(dec, H, W, width, depth, train_mode="from_scratch", **kw).ResNet50()
+    x = lambda: torch.rand(N, H, W, kw["num_channels"])
+    return call, make, x, loss
+
+
+def sample_1d(rng):
+    kind = rng.choice(["UNet", "UNet", "UNetPP", "MultiResUNet", "BCDUNet"])
+    depth = rng.choice([1, 2, 3, 3, 4])
+    L = 2 ** depth * rng.choice([2, 4, 5, 8, 16, 25, 32])
+    width = rng.choice([4, 8, 12, 16, 24])
+    ksz = rng.choice([3, 3, 3, 5, 7])
+    kw = dict(output_nums=rng.choice([1, 1, 2, 3]), ds=rng.choice([0, 1]), ae=rng.choice([0, 0, 1]), ag=rng.choice([0, 0, 1]),
+              lstm=rng.choice([0, 0, 1]), feature_number=rng.choice([8, 40]), is_transconv=rng.choice([True, True, False]))
+    ptype = rng.choice(["Regression", "Regression", "Classification"])
+    cin = rng.choice([1, 1, 2, 3])
+    N = rng.choice([1, 2, 4, 5])
+    if kind == "BCDUNet":
+        kw["dense_loop"] = rng.choice([1, 2, 3])
+        make = lambda: segamd.BCDUNet(L, depth, cin, width, ksz, ptype, **kw).BCDUNet()
+        call = f"BCDUNet({L}, {depth}, {cin}, {width}, {ksz}, {ptype!r}, " + ", ".join(f"{k}={v!r}" for k, v in kw.items()) + f").BCDUNet()  batch {N}"
+    else:
+        kw["alpha"] = rng.choice([1, 1, 1.67])
+        make = lambda: getattr(segamd.UNet1D(L, depth, cin, width, ksz, ptype, **kw), kind)()
+        call = f"UNet1D({L}, {depth}, {cin}, {width}, {ksz}, {ptype!r}, " + ", ".join(f"{k}={v!r}" for k, v in kw.items()) + f").{kind}()  batch {N}"
+    loss = "cce" if (ptype == "Classification" and kw["output_nums"] > 1 and kw["ds"] == 0) else "mse"
+    x = lambda: torch.rand(N, L, cin)
+    return call + f" loss {loss}", make, x, loss
+
+
+def run_case(call, make, xf, loss, dtype, rng):
+    model = make()
+    x = xf()
+    model.build(x.shape[0], dtype=dtype)
+    tg = targets_for(model, x, loss, rng)
+    r = U.compare_model(model, x, tg, loss, emulate_fp16=False, impose_decisions=True)
+    out = max(e / max(1.0, m) for e, m in zip(r["outs"], r["out_mag"]))
+    lossrel = abs(r["loss"][0] - r["loss"][1]) / max(1.0, abs(r["loss"][1]))
+    gn = max((n for _e, n in r["gl2"].values()), default=0.0)
+    rel = lambda e, n: (e / (n + 1e-3 * gn + 1e-30)) if e == e else float("inf")
+    arith = {k: rel(e, n) for k, (e, n) in r["gl2_imposed"].items() if k not in r.get("zero_grad_params", ())}
+    garith = max(arith.values(), default=0.0)
+    worst = max(arith, key=arith.get) if arith else "-"
+    gown = max((rel(e, n) for e, n in r["gl2"].values()), default=0.0)
+    flips = sum(a for a, _b in r["flips"].values())
+    nonfinite = model.nonfinite_updates() if hasattr(model, "nonfinite_updates") else 0
+    tol_out, tol_g = (1e-3, 5e-4) if dtype == "f32" else (5e-2, 1.0)
+    bad = out > tol_out or lossrel > (1e-5 if dtype == "f32" else 1e-2) or garith > tol_g or not all(map(lambda v: v == v, (out, lossrel, garith)))
+    return bad, f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips}"
+
+
+EXPECTED = (("NameError", "reference MultiResUNet has no working lstm branch"),       # the reference raises the same NameError
+            ("ValueError", "Invalid value for argument `filters`"))                     # Keras refuses 0 filters at construction
+
+
+def worker(args):
+    """Cases [args.start, args.n): every case prints '[i] STATUS ...' lines; a crash of the process is the parent's to record."""
+    rng = random.Random(args.seed)
+    t0 = time.time()
+    torch.set_num_threads(16)          # the oracle is torch-CPU: the GPU box's 256 hardware threads oversubscribe its small convolutions
+    for i in range(args.n):
+        two_d = rng.random() < 0.65 if not args.only else args.only == "2d"
+        call, make, xf, loss = (sample_2d if two_d else sample_1d)(rng)
+        if i < args.start:
+            continue
+        if args.seconds and time.time() - t0 > args.seconds:
+            break
+        print(f"[{i}] BEGIN {call}", flush=True)
+        torch.manual_seed(args.seed * 100003 + i)
+        try:
+            bad, msg = run_case(call, make, xf, loss, args.dtype, rng)
+        except Exception as e:          # noqa: BLE001 - the point is to see what raises
+            tb = traceback.format_exc().strip().splitlines()
+            where = next((l.strip() for l in reversed(tb) if l.strip().startswith("File") and "tf-1d-2d" in l), "")
+            text = f"{type(e).__name__}: {str(e)[:300]}"
+            kind = "EXPECTED" if any(text.startswith(t) and frag in text for t, frag in EXPECTED) else "RAISED"
+            print(f"[{i}] {kind} {text} || {where}", flush=True)
+            torch.cuda.synchronize()
+            continue
+        print(f"[{i}] {'FAIL' if bad else 'OK'} {msg}", flush=True)
+    print("[done]", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all n)")
+    ap.add_argument("--start", type=int, default=0)
+    ap.add_argument("--worker", action="store_true", help="(internal) run the cases in this process")
+    args = ap.parse_args()
+    if args.worker:
+        return worker(args)
+    # the parent never touches the GPU: it restarts the worker behind a case that killed the process (heap corruption, a GPU fault)
+    import subprocess
+    t0 = time.time()
+    calls, results, start = {}, {}, args.start
+    while start < args.n and not (args.seconds and time.time() - t0 > args.seconds):
+        left = max(1.0, args.seconds - (time.time() - t0)) if args.seconds else 0.0
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--n", str(args.n), "--seed", str(args.seed), "--dtype", args.dtype,
+               "--start", str(start), "--seconds", str(left)] + (["--only", args.only] if args.only else [])
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1)
+        cur, done, tail = None, False, []
+        for line in proc.stdout:
+            line = line.rstrip("\n")
+            tail = (tail + [line])[-6:]
+            if line == "[done]":
+                done = True
+            elif line.startswith("[") and "] " in line:
+                idx, rest = line[1:].split("] ", 1)
+                if idx.isdigit():
+                    status, _, text = rest.partition(" ")
+                    if status == "BEGIN":
+                        cur, calls[int(idx)] = int(idx), text
+                    else:
+                        results[int(idx)] = (status, text)
+                        print(f"[{idx}] {status:8s} {calls.get(int(idx), '')}\n      {text}", flush=True)
+                        cur = None
+        rc = proc.wait()
+        if done:
+            break
+        if cur is None:           # died between cases (or before the first): nothing to blame, stop rather than loop
+            print(f"worker exited with code {rc} outside a case; last output:\n  " + "\n  ".join(tail), flush=True)
+            break
+        results[cur] = ("CRASHED", f"worker exit code {rc}; last output: " + " | ".join(tail[-3:]))
+        print(f"[{cur}] CRASHED  {calls[cur]}\n      worker exit code {rc}; " + " | ".join(tail[-3:]), flush=True)
+        start = cur + 1
+    count = lambda st: sum(1 for s_, _t in results.values() if s_ == st)
+    print(f"\n==== {count('OK')} ok, {count('FAIL')} failed, {count('RAISED')} raised, {count('CRASHED')} crashed, {count('EXPECTED')} refused as the "
+          f"reference refuses them, in {time.time() - t0:.0f} s (seed {args.seed}, dtype {args.dtype})")
+    seen = set()
+    for i in sorted(results):
+        st, text = results[i]
+        if st in ("OK", "EXPECTED"):
+            continue
+        key = (st, text[:90]) if st == "RAISED" else (st, i)
+        if key in seen:
+            continue
+        seen.add(key)
+        print(f"{st} [{i}] {calls.get(i, '')}\n     {text}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
