@@ -210,7 +210,6 @@ def evaluate(model, batches: Iterable, loss: Optional[str] = None, return_dict: 
     return logs
 
 
-GRAD_TARGET = 1024.0                 # model.GRAD_TARGET: the loss scale maps max |dLoss/dOut| into [GRAD_TARGET / 2, GRAD_TARGET)
 LOSS_SCALE_GROWTH_INTERVAL = 200     # clean steps after which a backed-off scale doubles again (dynamic loss scaling)
 
 
@@ -223,7 +222,8 @@ def fit(model, train_batches, epochs: int, val_batches=None,
     hist: Dict[str, List[float]] = {}
     state = FitState(model)
     ms = _metric_set(model)
-    clean = 0                   # optimiser steps since the last non-finite gradient (loss-scale growth)
+    if hasattr(model, "loss_scale_growth_interval"):
+        model.loss_scale_growth_interval = LOSS_SCALE_GROWTH_INTERVAL
     for epoch in range(int(epochs)):
         tot, n, skipped = 0.0, 0, 0
         if ms is not None:
@@ -234,29 +234,16 @@ def fit(model, train_batches, epochs: int, val_batches=None,
             if ms is not None:                  # Keras updates the metrics from the training-mode predictions of the step
                 ms.update(targets)
             n += 1
-            if hasattr(model, "nonfinite_updates_async"):
-                # fp16 backward overflow: the optimiser skipped (and counted) the affected elements; back the loss scale off and
-                # let it grow back after a run of clean steps, like dynamic loss scaling does, and report it - Keras would have
-                # put NaNs into the weights instead.  The counter is read one step late from pinned memory: no stall of the
-                # side stream on which the optimiser runs under the next forward pass.
-                bad = model.nonfinite_updates_async()
-                if bad:
-                    skipped += bad
-                    clean = 0
-                    model.grad_target = max(model.grad_target / 2.0, 1.0)
-                else:
-                    clean += 1
-                    if clean >= LOSS_SCALE_GROWTH_INTERVAL and model.grad_target < GRAD_TARGET:
-                        model.grad_target = min(model.grad_target * 2.0, GRAD_TARGET)
-                        clean = 0
+            # (fp16-range backward overflow: the optimiser skipped and counted the affected elements and train_step backed the
+            # loss scale off - SegModel.loss_scale_feedback, one step late from pinned memory, no stall of the side stream on which
+            # the optimiser runs under the next forward pass; Keras would have put NaNs into the weights instead)
         if hasattr(model, "nonfinite_drain"):
             # what the one-step-late counter has not reported yet (the epoch's last step, or all of it when the loader had one
             # batch): this epoch's log and the loss-scale back-off see every step
             bad = model.nonfinite_drain()
             if bad:
-                skipped += bad
-                clean = 0
-                model.grad_target = max(model.grad_target / 2.0, 1.0)
+                model.loss_scale_feedback(bad)
+            skipped += model.take_skipped()
         if hasattr(model, "check_input_range"):
             model.check_input_range()            # raises on input elements the fp16 / split-pair storage cannot hold
         if hasattr(train_batches, "on_epoch_end"):

@@ -118,7 +118,14 @@ class SegModel:
         self.world_size = 1
         self.comm_timing, self._comm_events = False, []     # bench.py --gpus N: event-timed waits for the gradient slices
         self.grad_dtype = "f32"        # what the data-parallel exchange moves: "f32" (the flat buffer itself) or "bf16" (store.G16)
-        self.grad_target = F.GRAD_TARGET  # max |dLoss/dOut| is scaled into [target/2, target) before the fp16 backward pass
+        # the loss scale: max |dLoss/dOut| is scaled into [target / 2, target) before the backward pass (a power of two chosen on the
+        # device every step).  Dynamic: an optimiser step that had to skip non-finite gradient elements halves the target, a run of
+        # clean steps doubles it back up to the mode's default (loss_scale_feedback; train_step does it, one step late, without a sync)
+        self.grad_target_max = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
+        self.grad_target = self.grad_target_max
+        self.auto_loss_scale = True
+        self.loss_scale_growth_interval = F.LOSS_SCALE_GROWTH_INTERVAL
+        self._ls_clean, self._ls_skipped = 0, 0
         self.allreduce = None          # set by dp.DataParallel: whole-buffer exchange after backward
         self.bucket_hook = None        # set by dp.DataParallel(overlap=True): fn(lo, hi) called as soon as G[lo:hi] is final
         self.bucket_waits = None       # ... and fn() -> [(lo, hi, work)] handing the pending all-reduces to the optimiser
@@ -261,6 +268,9 @@ class SegModel:
         if dtype is not None:
             if dtype not in ("f16", "f32"):
                 raise ValueError("dtype must be 'f16' or 'f32'")
+            if dtype != self.dtype and self.grad_target == self.grad_target_max:
+                self.grad_target = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
+            self.grad_target_max = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.dtype = dtype
         self._enter()
         DevTensor.dtype = torch.float16 if self.dtype == "f16" else torch.float32
@@ -359,7 +369,7 @@ class SegModel:
                 if an is not None and an.attrs["fn"] != "softmax":
                     act, alpha, last = an.attrs["fn"], an.attrs["alpha"], an
                     chain.append(an)
-                F = n.attrs["filters"] if k == "convlstm" else 0
+                lstm_f = n.attrs["filters"] if k == "convlstm" else 0
                 out = DevTensor(last.name, N, last.shape[0], last.shape[1], last.shape[2])
                 pooled, psize, pool_node = None, (1, 1), None
                 for c in cons[last.idx]:
@@ -368,7 +378,7 @@ class SegModel:
                         pool_node, psize = cn, cn.attrs["size"]
                         pooled = DevTensor(cn.name, N, cn.shape[0], cn.shape[1], cn.shape[2])
                         break
-                op = ConvOp(self, n, k, segs_of(n.inputs[0]), bn, act, alpha, out, pooled, psize, F)
+                op = ConvOp(self, n, k, segs_of(n.inputs[0]), bn, act, alpha, out, pooled, psize, lstm_f)
                 self.ops.append(op)
                 for nd in chain:
                     val[nd.idx] = out
@@ -676,6 +686,27 @@ class SegModel:
             n += int(pend[1][0])
             self._nf_pending = None
         return n + self.nonfinite_updates(reset=True)
+
+    def loss_scale_feedback(self, skipped: int):
+        """Dynamic loss scaling: `skipped` = parameter elements whose update an optimiser step skipped because their gradient was
+        NaN / Inf (an overflow of the fp16-range gradient storage).  Non-zero: the target halves (never below 1); after
+        `loss_scale_growth_interval` clean steps it doubles again, up to the mode's default.  train_step() feeds it from the
+        asynchronous counter (one step late, no synchronisation); harness.fit adds what the end of an epoch drains and logs the
+        total (`take_skipped`)."""
+        if skipped:
+            self._ls_skipped += int(skipped)
+            self._ls_clean = 0
+            self.grad_target = max(self.grad_target / 2.0, 1.0)
+        else:
+            self._ls_clean += 1
+            if self._ls_clean >= self.loss_scale_growth_interval and self.grad_target < self.grad_target_max:
+                self.grad_target = min(self.grad_target * 2.0, self.grad_target_max)
+                self._ls_clean = 0
+
+    def take_skipped(self) -> int:
+        """Skipped parameter-element updates reported to loss_scale_feedback since the last call (for the epoch log)."""
+        n, self._ls_skipped = self._ls_skipped, 0
+        return n
 
     def check_input_range(self):
         """Raises when an input element handed to forward() since the last check was NaN, +-Inf or |x| >= 65504: the reference's fp32
@@ -1092,4 +1123,6 @@ class SegModel:
         lv = self.compute_loss(targets, loss)
         self.backward(None)
         self.optimizer_step()
+        if self.auto_loss_scale and not self._graph_mode:
+            self.loss_scale_feedback(self.nonfinite_updates_async())
         return lv

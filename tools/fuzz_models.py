@@ -47,8 +47,8 @@ def sample_2d(rng):
     unit = 2 ** depth
     H = unit * rng.choice([1, 2, 3, 4, 5, 8])
     W = unit * rng.choice([1, 2, 3, 4, 6, 8])
-    while H * W > 96 * 96:
-        H, W = max(unit, H // 2), max(unit, W // 2)
+    while H * W > 96 * 96:                 # (shrink in whole units: the reference needs sizes divisible by 2^depth)
+        H, W = max(unit, H // (2 * unit) * unit), max(unit, W // (2 * unit) * unit)
     width = rng.choice([4, 6, 8, 12, 16, 20, 32, 40])
     kw = dict(num_channels=rng.choice([1, 3, 3, 4, 5]), output_nums=rng.choice([1, 1, 1, 2, 4, 9]), ds=rng.choice([0, 0, 1]),
               ae=rng.choice([0, 0, 0, 1]), ag=rng.choice([0, 0, 1]), lstm=rng.choice([0, 0, 1]), dense_loop=rng.choice([1, 1, 2, 3]),
@@ -95,7 +95,15 @@ def run_case(call, make, xf, loss, dtype, rng):
     x = xf()
     model.build(x.shape[0], dtype=dtype)
     tg = targets_for(model, x, loss, rng)
-    r = U.compare_model(model, x, tg, loss, emulate_fp16=False, impose_decisions=True)
+    # an overflow of the fp16-range gradient storage is LOUD (non-finite gradient elements, skipped and counted by the optimiser) and
+    # the training step answers it by backing the loss scale off (SegModel.loss_scale_feedback): do the same here, count the retries
+    retries = 0
+    while True:
+        r = U.compare_model(model, x, tg, loss, emulate_fp16=False, impose_decisions=True)
+        if all(e == e for e, _n in r["gl2"].values()) or retries >= 8:
+            break
+        model.grad_target = max(model.grad_target / 2.0, 1.0)
+        retries += 1
     out = max(e / max(1.0, m) for e, m in zip(r["outs"], r["out_mag"]))
     lossrel = abs(r["loss"][0] - r["loss"][1]) / max(1.0, abs(r["loss"][1]))
     gn = max((n for _e, n in r["gl2"].values()), default=0.0)
@@ -108,8 +116,15 @@ def run_case(call, make, xf, loss, dtype, rng):
     nonfinite = model.nonfinite_updates() if hasattr(model, "nonfinite_updates") else 0
     tol_out, tol_g = (1e-3, 5e-4) if dtype == "f32" else (5e-2, 1.0)
     bad = out > tol_out or lossrel > (1e-5 if dtype == "f32" else 1e-2) or garith > tol_g or not all(map(lambda v: v == v, (out, lossrel, garith)))
-    return bad, f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips}"
+    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips}" + (f" loss-scale back-offs {retries}" if retries else "")
+    if VERBOSE:
+        top = sorted(arith, key=arith.get, reverse=True)[:8]
+        msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
+        msg += "\n        worst forward nodes: " + ", ".join(f"{n} {e:.1e}/{m_:.1e}" for n, e, m_ in sorted(r["nodes"], key=lambda t: -t[1] / max(1.0, t[2]))[:4])
+    return bad, msg
 
+
+VERBOSE = False
 
 EXPECTED = (("NameError", "reference MultiResUNet has no working lstm branch"),       # the reference raises the same NameError
             ("ValueError", "Invalid value for argument `filters`"))                     # Keras refuses 0 filters at construction
@@ -152,7 +167,25 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all n)")
     ap.add_argument("--start", type=int, default=0)
     ap.add_argument("--worker", action="store_true", help="(internal) run the cases in this process")
+    ap.add_argument("--cases", default="", help="comma list of case indices: run only these, in this process, with the worst tensors listed")
     args = ap.parse_args()
+    if args.cases:
+        global VERBOSE
+        VERBOSE = True
+        want = sorted(int(v) for v in args.cases.split(","))
+        rng = random.Random(args.seed)
+        torch.set_num_threads(16)
+        for i in range(want[-1] + 1):
+            two_d = rng.random() < 0.65 if not args.only else args.only == "2d"
+            call, make, xf, loss = (sample_2d if two_d else sample_1d)(rng)
+            if i in want:
+                torch.manual_seed(args.seed * 100003 + i)
+                try:
+                    bad, msg = run_case(call, make, xf, loss, args.dtype, rng)
+                    print(f"[{i}] {'FAIL' if bad else 'OK'} {call}\n      {msg}", flush=True)
+                except Exception:          # noqa: BLE001
+                    print(f"[{i}] RAISED {call}\n" + traceback.format_exc(), flush=True)
+        return 0
     if args.worker:
         return worker(args)
     # the parent never touches the GPU: it restarts the worker behind a case that killed the process (heap corruption, a GPU fault)
