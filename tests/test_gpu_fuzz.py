@@ -1,0 +1,55 @@
+"""A fixed sample of the differential fuzzer (tools/fuzz_models.py) as a regression net: random constructor arguments of the reference's
+builder API - decoder, depth, width, image size, channel / class counts, ds / ae / ag / lstm / is_transconv / alpha / dense_loop /
+feature_number, 1D and 2D, odd batches - through the engine in the parity mode against the oracle: outputs within 1e-3, loss, every
+parameter gradient (decisions imposed) within 5e-4 or 30 x its own conditioning.  Round 5's first campaigns (2 100 configurations) found:
+ConvLSTM filter counts and autoencoder extents that are not multiples of 8 (NotImplementedError - lifted), a division by zero where Keras
+raises on 0 filters, first-step gradient overflow at a loss-scale target of 1024 in the parity mode (now 32), and - in the ORACLE - heap
+corruption in oneDNN's channels-last backward of few-channel convolutions.  What the reference itself refuses (MultiResUNet with
+lstm=1: NameError; 0 filters: ValueError) must be refused the same way."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import fuzz_models as FZ
+
+
+def _cases(seed, n):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        two_d = rng.random() < 0.65
+        out.append((i,) + (FZ.sample_2d if two_d else FZ.sample_1d)(rng))
+    return out, rng
+
+
+@pytest.mark.parametrize("seed,n", [(11, 60)])
+def test_random_builder_configurations_match_the_oracle(seed, n):
+    cases, rng = _cases(seed, n)
+    ok, refused, failed = 0, 0, []
+    for i, call, make, xf, loss in cases:
+        torch.manual_seed(seed * 100003 + i)
+        try:
+            bad, msg = FZ.run_case(call, make, xf, loss, "f32", rng)
+        except Exception as e:          # noqa: BLE001
+            text = f"{type(e).__name__}: {e}"
+            if any(text.startswith(t) and frag in text for t, frag in FZ.EXPECTED):
+                refused += 1
+                continue
+            failed.append((i, call, text))
+            continue
+        if bad:
+            failed.append((i, call, msg))
+        else:
+            ok += 1
+    print(f"fuzz sample seed {seed}: {ok} ok, {refused} refused as the reference refuses them, {len(failed)} failed")
+    assert not failed, "\n".join(f"[{i}] {c}\n    {m}" for i, c, m in failed)
+    assert ok >= n * 0.8
