@@ -265,8 +265,10 @@ int seg_upsample_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, in
 int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh,
                      int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream);
 
-/* ---- add([..]) / Add() (+ optional activation) (unet_variants.py:55,73,97,112): y = act(sum_i x_i), n <= 4   */
-int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha,
+/* ---- add([..]) / Add() (+ optional activation) (unet_variants.py:55,73,97,112): y = act(sum_i x_i), n <= 4.  Dense tensors of
+ * nelem elements in rows of cs channels; channels >= c_valid are PADDING and are written as zero whatever the activation makes of 0
+ * (sigmoid(0) = 0.5 would otherwise reach the padding columns of the next conv's weight gradient)                */
+int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t cs, int32_t c_valid, int32_t act, float alpha,
                     seg_stream_t stream);
 /* dx_i (+)= dy * act'(y) for every i with dxs[i] != NULL; accumulate is a bit mask over i                      */
 int seg_add_act_bwd(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
@@ -532,7 +534,7 @@ int seg_upsample_fwd_f32(const void* x, void* y, int32_t N, int32_t H, int32_t W
                          int32_t bilinear, seg_stream_t stream);
 int seg_upsample_bwd_f32(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh,
                          int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream);
-int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha,
+int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t cs, int32_t c_valid, int32_t act, float alpha,
                         seg_stream_t stream);
 int seg_add_act_bwd_f32(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act,
                         float alpha, int32_t accumulate_mask, seg_stream_t stream);

@@ -693,6 +693,26 @@ def test_upsample_bilinear_known_answer():
     assert yd[0, 0, :, 0].float().cpu().tolist() == [0.0, 1.0, 3.0, 4.0]
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_activation_layers_keep_the_padding_channels_zero(f32):
+    """A tensor of C channels occupies rows of cs = C rounded up to 8; every kernel keeps the padding exactly zero (the next conv
+    multiplies it with padding weights and its weight gradient has columns for it).  sigmoid(0) = 0.5: an Activation('sigmoid') on a
+    6- / 12- / 20-channel tensor (UNet 3+'s upsampled branches at model_width 6 / 12 / 20) used to write 0.5 there - harmless in the
+    forward pass while the padding weights are zero, but their gradient is then sum dz * 0.5, the optimiser moves them, and from the
+    second step on the conv adds 0.5 * w_pad to every output (found by tools/fuzz_models.py: 1e-3 .. 5e-2 on predict() of every
+    UNet3P whose width is not a multiple of 8)."""
+    sfx, dt = ("_f32", torch.float32) if f32 else ("", torch.float16)
+    for C_ in (6, 12, 20):
+        x = torch.randn(2, 3, 5, C_)
+        xd = to_dev_nhwc(x, dt)
+        yd = torch.full_like(xd, 7.0) if not f32 else U.SF.split_pack(torch.full(xd.shape, 7.0, device="cuda"))
+        ptrs = (C.c_void_p * 4)(xd.data_ptr(), None, None, None)
+        ffi.call("seg_add_act_fwd" + sfx, ptrs, 1, P(yd), yd.numel(), yd.shape[-1], C_, ACT["sigmoid"], 0.0, stream())
+        got = U.dev_values(yd)
+        assert float(got[..., C_:].abs().max()) == 0.0
+        assert float((got[..., :C_] - torch.sigmoid(x if f32 else h16(x))).abs().max()) < (1e-6 if f32 else 1e-3)
+
+
 @pytest.mark.parametrize("n,act", [(2, "relu"), (3, None), (1, "sigmoid"), (4, "relu")])
 def test_add_act_fwd_bwd(n, act):
     shape = (2, 5, 6, 16)
@@ -703,7 +723,7 @@ def test_add_act_fwd_bwd(n, act):
     xds = [to_dev_nhwc(x.detach()) for x in xs]
     yd = torch.zeros_like(xds[0])
     ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in xds])
-    ffi.call("seg_add_act_fwd", ptrs, n, P(yd), yd.numel(), ACT[act], 0.0, stream())
+    ffi.call("seg_add_act_fwd", ptrs, n, P(yd), yd.numel(), yd.shape[-1], yd.shape[-1], ACT[act], 0.0, stream())
     accs = [h16(torch.randn(shape)) for _ in range(n)]
     dxs = [to_dev_nhwc(a) for a in accs]
     mask = 0b0101 & ((1 << n) - 1)

@@ -112,7 +112,7 @@ def test_engine_reproduces_the_documented_examples():
             x = U.to_dev_nhwc(torch.from_numpy(xs).reshape(1, 1, n, 1).expand(1, 1, n, 8).contiguous(), dt)
             y = torch.zeros_like(x)
             ptrs = (C.c_void_p * 4)(x.data_ptr(), None, None, None)
-            ffi.call("seg_add_act_fwd" + sfx, ptrs, 1, U.P(y), n * 8, ffi.ACT[act], alpha, U.stream())
+            ffi.call("seg_add_act_fwd" + sfx, ptrs, 1, U.P(y), n * 8, 8, 8, ffi.ACT[act], alpha, U.stream())
             got = U.dev_values(y)[0, 0, :, 0].tolist()
             assert got == pytest.approx(want, rel=(tol if not f32 else 1e-6), abs=1e-6 if f32 else 1e-3), (act, f32, got)
 

@@ -124,7 +124,7 @@ _PROTOS = {
     "seg_maxpool_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_upsample_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
     "seg_upsample_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], C.c_int),
-    "seg_add_act_fwd": ([C.POINTER(vp), i32, vp, i64, i32, f32, vp], C.c_int),
+    "seg_add_act_fwd": ([C.POINTER(vp), i32, vp, i64, i32, i32, i32, f32, vp], C.c_int),
     "seg_add_act_stats_fwd": ([C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(CatDesc), vp, vp, vp, i64, i32, i32, i32, f32, vp, i32, i32, i32, vp], C.c_int),
     "seg_bn_bwd_apply_fanout": ([vp, vp, C.POINTER(vp), i32, i32, i64, i32, vp, vp, vp, vp, vp, i32, C.POINTER(CatDesc), vp, vp, vp, C.POINTER(LazyBN), i32, i32, vp], C.c_int),
     "seg_cat_bn_bwd_scatter": ([vp, C.POINTER(CatDesc), i64, i32, vp, vp, vp, vp, vp, vp], C.c_int),

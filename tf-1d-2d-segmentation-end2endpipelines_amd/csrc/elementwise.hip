@@ -764,7 +764,9 @@ template <typename T> struct Ptr4 { const T* p[4]; };
 template <typename T> struct MPtr4 { T* p[4]; };
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void add_act_fwd_kernel(Ptr4<T> xs, int n, T* y, int64_t nchunks, int act, float alpha) {
+__global__ __launch_bounds__(TPB) void add_act_fwd_kernel(Ptr4<T> xs, int n, T* y, int64_t nchunks, int CH, int c_valid, int act, float alpha) {
+  // padding channels (>= c_valid) must stay exactly zero: act(0) is not 0 for a sigmoid.  Masked only when the row has padding at all
+  const bool mask = c_valid < CH * 8 && act == SEG_ACT_SIGMOID;
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < nchunks; it += (int64_t)gridDim.x * TPB) {
     float o[8];
     load8(xs.p[0] + it * 8, o);
@@ -776,6 +778,12 @@ __global__ __launch_bounds__(TPB) void add_act_fwd_kernel(Ptr4<T> xs, int n, T* 
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) o[t] = seg_act(o[t], act, alpha);
+    if (mask) {
+      const int c0 = (int)(it % CH) * 8;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (c0 + t >= c_valid) o[t] = 0.f;
+    }
     store8(y + it * 8, o);
   }
 }
@@ -2234,16 +2242,18 @@ extern "C" int seg_upsample_bwd(const void* dy, void* dx, int32_t N, int32_t H, 
 extern "C" int seg_upsample_bwd_f32(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t cs, int32_t fh, int32_t fw, int32_t bilinear, int32_t accumulate, seg_stream_t stream) { return seg_upsample_bwd_impl<split_t>(dy, dx, N, H, W, cs, fh, fw, bilinear, accumulate, stream); }
 
 template <typename T>
-static int seg_add_act_fwd_impl(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) {
-  SEG_CHECK_ARG(xs && y && n >= 1 && n <= 4 && nelem > 0 && (nelem & 7) == 0, "seg_add_act_fwd: bad arguments (n=%d)", n);
+static int seg_add_act_fwd_impl(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t cs, int32_t c_valid, int32_t act, float alpha,
+                                seg_stream_t stream) {
+  SEG_CHECK_ARG(xs && y && n >= 1 && n <= 4 && nelem > 0 && cs > 0 && (cs & 7) == 0 && nelem % cs == 0 && c_valid > 0 && c_valid <= cs,
+                "seg_add_act_fwd: bad arguments (n=%d cs=%d c_valid=%d)", n, cs, c_valid);
   Ptr4<T> p;
   for (int k = 0; k < 4; ++k) p.p[k] = k < n ? (const T*)xs[k] : nullptr;
-  hipLaunchKernelGGL((add_act_fwd_kernel<T>), dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), p, n, (T*)y, nelem / 8, act, alpha);
+  hipLaunchKernelGGL((add_act_fwd_kernel<T>), dim3(grid_for(nelem / 8)), dim3(TPB), 0, ST(stream), p, n, (T*)y, nelem / 8, cs / 8, c_valid, act, alpha);
   SEG_CHECK_LAUNCH("seg_add_act_fwd");
   return SEG_OK;
 }
-extern "C" int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<half_t>(xs, n, y, nelem, act, alpha, stream); }
-extern "C" int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<split_t>(xs, n, y, nelem, act, alpha, stream); }
+extern "C" int seg_add_act_fwd(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t cs, int32_t c_valid, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<half_t>(xs, n, y, nelem, cs, c_valid, act, alpha, stream); }
+extern "C" int seg_add_act_fwd_f32(const void* const* xs, int32_t n, void* y, int64_t nelem, int32_t cs, int32_t c_valid, int32_t act, float alpha, seg_stream_t stream) { return seg_add_act_fwd_impl<split_t>(xs, n, y, nelem, cs, c_valid, act, alpha, stream); }
 
 template <typename T>
 static int seg_add_act_bwd_impl(const void* dy, const void* y, void* const* dxs, int32_t n, int64_t nelem, int32_t act, float alpha,

@@ -1091,7 +1091,7 @@ class AddOp(Op):
                  _p(vb.scale) if vb is not None else None, _p(vb.shift) if vb is not None else None, _p(self.out.buf), self.out.npix,
                  self.out.cs, self.out.C, ACT[self.act], float(self.alpha), _p(b.stats), b.nparts, 0, 0, _stream())
             return
-        call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), ACT[self.act],
+        call("seg_add_act_fwd", self.ptrs, len(self.xs), _p(self.out.buf), self.out.buf.numel(), self.out.cs, self.out.C, ACT[self.act],
              float(self.alpha), _stream())
 
     def plan_backward(self):

@@ -133,8 +133,28 @@ def run_case(call, make, xf, loss, dtype, rng):
     tol_out, tol_g = (1e-3, 5e-4) if dtype == "f32" else (5e-2, 1.0)
     over = {k: v for k, v in arith.items() if v > max(tol_g, 30.0 * sens.get(k, 0.0))}
     tol_loss = max(1e-5 if dtype == "f32" else 1e-2, 30.0 * loss_sens)
-    bad = out > tol_out or lossrel > tol_loss or bool(over) or not all(map(lambda v: v == v, (out, lossrel, garith)))
-    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e}" + (f" loss-scale back-offs {retries}" if retries else "")
+    # two optimiser steps, then inference (moving statistics, the one-launch Conv_Block form) against the oracle on the trained weights
+    from ir_interp import run_graph
+    for _ in range(2):
+        model.train_step(x, tg, loss)
+    wt = {k: torch.from_numpy(v) for k, v in model.get_weights().items()}
+    ref = run_graph(model.graph, x, wt, training=False)
+    pred = model.predict(x)
+    pred = pred if isinstance(pred, (list, tuple)) else [pred]
+    perr, pmask = 0.0, 0
+    for p_, r_ in zip(pred, ref):
+        got, rd = torch.from_numpy(p_).reshape(r_.shape), r_.detach()
+        perr = max(perr, float((got - rd).abs().max()) / max(1.0, float(rd.abs().max())))
+        if rd.shape[-1] == 1:
+            m_got, m_ref, margin = got >= 0.5, rd >= 0.5, (rd - 0.5).abs()
+        else:
+            m_got, m_ref = got.argmax(-1, keepdim=True), rd.argmax(-1, keepdim=True)
+            top = rd.topk(2, -1).values
+            margin = top[..., :1] - top[..., 1:]
+        pmask += int(((m_got != m_ref) & (margin > 1e-4)).sum())
+    bad = (out > tol_out or lossrel > tol_loss or bool(over) or not all(map(lambda v: v == v, (out, lossrel, garith, perr)))
+           or perr > tol_out or (dtype == "f32" and pmask > 0))
+    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e} predict {perr:.1e} masks off {pmask}" + (f" loss-scale back-offs {retries}" if retries else "")
     if VERBOSE:
         top = sorted(arith, key=arith.get, reverse=True)[:8]
         msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
