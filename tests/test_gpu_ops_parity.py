@@ -450,7 +450,7 @@ def test_add_act(n, act):
     ds = [dev(x.detach()) for x in xs]
     ptrs = (C.c_void_p * 4)(*([d.data_ptr() for d in ds] + [None] * (4 - n)))
     yd = torch.zeros_like(ds[0])
-    ffi.call("seg_add_act_fwd_f32", ptrs, n, P(yd), yd.numel(), ACT[act], 0.3, stream())
+    ffi.call("seg_add_act_fwd_f32", ptrs, n, P(yd), yd.numel(), yd.shape[-1], yd.shape[-1], ACT[act], 0.3, stream())
     gs = [torch.zeros_like(d) for d in ds]
     gp = (C.c_void_p * 4)(*([g.data_ptr() for g in gs] + [None] * (4 - n)))
     dyd = dev(dy)
