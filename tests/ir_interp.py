@@ -29,7 +29,8 @@ def _pool_take(x, size, idx):
     return out.permute(0, 2, 3, 1)
 
 
-def run_graph(g, x: torch.Tensor, weights: Dict[str, torch.Tensor], training=True, return_all=False, emulate_fp16=False, impose=None):
+def run_graph(g, x: torch.Tensor, weights: Dict[str, torch.Tensor], training=True, return_all=False, emulate_fp16=False, impose=None,
+              update_moving=False):
     """emulate_fp16: round every materialised tensor (and the MFMA weight operands) to fp16 exactly where the HIP
     engine does - model input, conv / convT / ConvLSTM weights, every layer output except the fp32 heads - so that
     activation masks (ReLU, max-pool arg-max, hard-sigmoid knees) agree with the GPU run and kernel logic can be
@@ -66,9 +67,13 @@ def run_graph(g, x: torch.Tensor, weights: Dict[str, torch.Tensor], training=Tru
         elif n.kind == "convT":
             v = R(K.conv2d_transpose_same(ins[0], R(weights[f"{n.name}/kernel"]), weights[f"{n.name}/bias"], a["strides"]))
         elif n.kind == "bn":
-            v, _, _ = K.batchnorm(ins[0], weights[f"{n.name}/gamma"], weights[f"{n.name}/beta"],
-                                  weights[f"{n.name}/moving_mean"], weights[f"{n.name}/moving_variance"], training,
-                                  fused_4d=(g.ndim == 2), eps=a["eps"], momentum=a["momentum"])
+            v, nm, nv = K.batchnorm(ins[0], weights[f"{n.name}/gamma"], weights[f"{n.name}/beta"],
+                                    weights[f"{n.name}/moving_mean"], weights[f"{n.name}/moving_variance"], training,
+                                    fused_4d=(g.ndim == 2), eps=a["eps"], momentum=a["momentum"])
+            if update_moving and training:          # (a training loop: the layer's moving statistics follow, as Keras updates them)
+                with torch.no_grad():
+                    weights[f"{n.name}/moving_mean"].copy_(nm)
+                    weights[f"{n.name}/moving_variance"].copy_(nv)
             v = R(v)
         elif n.kind == "act":
             if n.name in impose and a["fn"] in ("relu", "leaky_relu"):
