@@ -114,3 +114,116 @@ def test_two_ranks_equal_hand_averaged_replicas(overlap, grad_dtype):
     assert np.abs(res[0][1] - want).max() < (1e-6 if grad_dtype != "bf16" else 2e-3), np.abs(res[0][1] - want).max()
     rel = 1e-5 if grad_dtype != "bf16" else 1e-3
     assert res[0][2] == pytest.approx(ref_losses[0::2], rel=rel) and res[1][2] == pytest.approx(ref_losses[1::2], rel=rel)
+
+
+# ---- random builder configurations under the data-parallel exchange (round 5): odd parameter counts against bucket and optimiser-slice
+# boundaries, Dense bottlenecks, ConvLSTM gate padding, one- and many-channel heads.  The configurations come from the differential
+# fuzzer's sampler (tools/fuzz_models.py) with a fixed seed; every rank rebuilds the same sequence.
+DP_FUZZ_SEED, DP_FUZZ_N = 21, 14
+
+
+def _fuzz_cases():
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_models as FZ
+    rng = random.Random(DP_FUZZ_SEED)
+    out = []
+    for i in range(DP_FUZZ_N):
+        two_d = rng.random() < 0.65
+        call, make, xf, loss = (FZ.sample_2d if two_d else FZ.sample_1d)(rng)
+        out.append((i, call, make, xf, loss, rng.choice([3000, 8000, 20000, 100000])))
+    return out, FZ
+
+
+def _fuzz_batches(i, xf, model, loss, FZ):
+    import random
+    torch.manual_seed(1000 + i)
+    xs = [xf() for _ in range(2)]
+    ts = [FZ.targets_for(model, xs[0], loss, random.Random(i)) for _ in range(2)]
+    return xs, ts
+
+
+def _fuzz_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import torch.distributed as dist
+        dp = importlib.import_module(PKG + ".dp")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cases, FZ = _fuzz_cases()
+        out = {}
+        for i, call, make, xf, loss, bucket in cases:
+            try:
+                m = make()
+                x0 = xf()
+                m.build(x0.shape[0], dtype="f32")
+            except (ValueError, NameError):          # refused as the reference refuses it (same on every rank)
+                continue
+            m.compile(loss=loss, lr=1e-3)
+            d = dp.DataParallel(m, bucket_elems=bucket, overlap=True)
+            xs, ts = _fuzz_batches(i, xf, m, loss, FZ)
+            losses = [float(d.train_step(xs[rank].cuda(), [t.cuda() for t in ts[rank]]).cpu()) for _ in range(STEPS)]
+            m._join_side()
+            torch.cuda.synchronize()
+            out[i] = (m.store.P.cpu().numpy(), losses, int(m.nonfinite_updates()))
+        q.put((rank, out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:      # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_random_configurations_under_data_parallel():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fuzz_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for _rank, _out, err in res:
+        assert err is None, err
+    r0, r1 = res[0][1], res[1][1]
+    assert sorted(r0) == sorted(r1) and len(r0) >= DP_FUZZ_N // 2
+    cases, FZ = _fuzz_cases()
+    checked = 0
+    for i, call, make, xf, loss, bucket in cases:
+        if i not in r0:
+            continue
+        assert np.array_equal(r0[i][0], r1[i][0]), call                  # the replicas stay bit-identical
+        a, b = make(), make()
+        x0 = xf()
+        for m in (a, b):
+            m.build(x0.shape[0], dtype="f32")
+            m.compile(loss=loss, lr=1e-3)
+        b.set_weights(a.get_weights())
+        xs, ts = _fuzz_batches(i, xf, a, loss, FZ)
+        ref_losses, skipped = [], 0
+        for _ in range(STEPS):
+            gs = []
+            for m, x, t in ((a, xs[0], ts[0]), (b, xs[1], ts[1])):
+                m.forward(x.cuda(), training=True)
+                ref_losses.append(float(m.compute_loss([v.cuda() for v in t]).cpu()))
+                m.backward(None)
+                torch.cuda.synchronize()
+                gs.append(m.store.G.clone())
+            for m in (a, b):
+                m.store.G.copy_((gs[0] + gs[1]) * 0.5)
+                m.optimizer_step()
+                m._join_side()
+            skipped += int(a.nonfinite_updates(reset=True))
+        if skipped or r0[i][2]:
+            continue                  # a first-step overflow is skipped element by element: not comparable, and rare at a target of 32
+        torch.cuda.synchronize()
+        want = a.store.P.cpu().numpy()
+        assert np.abs(r0[i][0] - want).max() < 2e-6 * max(1.0, np.abs(want).max()), (call, bucket, np.abs(r0[i][0] - want).max())
+        assert r0[i][1] == pytest.approx(ref_losses[0::2], rel=1e-5) and r1[i][1] == pytest.approx(ref_losses[1::2], rel=1e-5), call
+        checked += 1
+    assert checked >= DP_FUZZ_N // 2
