@@ -342,3 +342,27 @@ def grad_rel_err(res, floor=1e-4):
     """worst |err| / (max|ref| + floor * global max |grad|): parameters whose true gradient is numerically zero
     (conv bias in front of BatchNormalization) are judged against the global gradient scale."""
     return max((e / (d + floor * res["gmax"]) for e, d in res["grads"].values()), default=0.0)
+
+
+def padding_residue(model) -> float:
+    """What the engine's flat parameter buffer holds OUTSIDE the logical parameters: tensors are padded to 8 channels, GEMM operands to
+    32 K columns per segment, ConvLSTM gate blocks to 8 - and every one of those padding entries has to stay exactly zero through
+    training (a padding weight only ever meets a padding activation, which is zero - unless a kernel leaks something into the padding
+    channels: then the padding weights get a gradient, the optimiser moves them, and the layer drifts from the reference from the second
+    step on; the sigmoid of round 5).  Returns max |P - to_engine(from_engine(P))| over all parameters: 0.0 for a healthy model."""
+    return max(padding_residues(model).values(), default=0.0)
+
+
+def padding_residues(model) -> dict:
+    """{parameter name: max |P - to_engine(from_engine(P))|} for the parameters where it is not zero."""
+    model._join_side()
+    host_p, host_s = model.store.P.cpu().numpy(), model.store.S.cpu().numpy()       # trainable parameters / moving statistics
+    out = {}
+    for name, sl in model.store.slots.items():
+        cur = (host_p if sl.trainable else host_s)[sl.off:sl.off + sl.numel]
+        back = np.asarray(sl.to_engine(np.asarray(sl.from_engine(cur), np.float32)), np.float32).reshape(-1)
+        d = float(np.abs(cur - back).max())
+        if d != 0.0:
+            out[name] = d
+    return out
+

@@ -277,3 +277,31 @@ def test_multi_op_nodes_train_like_the_oracle(kw):
     wg, wr = model.get_weights(), L.get_weights()
     worst = max(float(np.abs(wg[k] - wr[k]).max()) for k in wr if L.trainable.get(k, False))
     assert worst < 2e-3, worst
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("make,xshape", [
+    (lambda: B("UNet3P", 16, 16, 12, 2, num_channels=3), (2, 16, 16, 3)),                       # sigmoid on 12-channel upsampled branches
+    (lambda: B("MultiResUNet", 16, 16, 12, 2, num_channels=3, ag=1, alpha=1.67), (2, 16, 16, 3)),  # attention gates: sigmoid(psi), 1 channel
+    (lambda: B("UNet", 16, 16, 12, 2, num_channels=5, lstm=1, ae=1, feature_number=10), (2, 16, 16, 5)),   # ConvLSTM F = 12, Dense bottleneck
+    (lambda: segamd.BCDUNet(40, 2, 1, 12, 3, lstm=1, ag=1, dense_loop=2).BCDUNet(), (3, 40, 1)),
+], ids=["unet3p_w12", "multires_ag_w12", "unet_lstm_ae_w12", "bcdunet1d_w12"])
+def test_padding_weights_stay_zero_through_training(make, xshape, dtype):
+    """Tensors are padded to 8 channels and GEMM operands to 32 K columns; the padding weights only ever meet padding activations,
+    which every kernel keeps at zero - so their gradient is zero and they never move.  Round 5's fuzzer found the exception:
+    Activation('sigmoid') wrote sigmoid(0) = 0.5 into the padding channels, the next conv's padding weights moved, and every model with
+    a sigmoid on a tensor whose width is not a multiple of 8 (UNet 3+; the attention gate's 1-channel map in front of a transposed
+    conv) drifted from the reference from the second optimiser step on.  Three steps with a large learning rate, then every parameter
+    must round-trip through its Keras layout unchanged."""
+    torch.manual_seed(4)
+    m = make()
+    x = torch.rand(*xshape)
+    m.build(x.shape[0], dtype=dtype)
+    m.compile(loss="mse", optimizer="SGD", lr=5e-2)
+    _m, _x, tg, _l = _with_targets(m, x, "mse")
+    assert U.padding_residues(m) == {}
+    for _ in range(3):
+        m.train_step(x, tg)
+    assert m.nonfinite_updates() == 0
+    assert U.padding_residues(m) == {}
+

@@ -105,7 +105,9 @@ def run_case(call, make, xf, loss, dtype, rng):
     # the training step answers it by backing the loss scale off (SegModel.loss_scale_feedback): do the same here, count the retries
     retries = 0
     while True:
-        r = U.compare_model(model, x, tg, loss, emulate_fp16=False, impose_decisions=True)
+        # (f16 = the throughput mode: held against the ROUNDING-EMULATING oracle - same rounding points on the CPU - so that what is
+        # compared is the kernels' logic, not fp16 against fp32)
+        r = U.compare_model(model, x, tg, loss, emulate_fp16=(dtype == "f16"), impose_decisions=True)
         if all(e == e for e, _n in r["gl2"].values()) or retries >= 8:
             break
         model.grad_target = max(model.grad_target / 2.0, 1.0)
@@ -126,8 +128,8 @@ def run_case(call, make, xf, loss, dtype, rng):
     dec = U.gpu_decisions(model)
     w_np = model.get_weights()
     xp = x * (1.0 + 1e-6 * torch.randn_like(x))
-    o1 = U.oracle_run(model.graph, w_np, x, tg, loss, impose=dec)
-    o2 = U.oracle_run(model.graph, w_np, xp, tg, loss, impose=dec)
+    o1 = U.oracle_run(model.graph, w_np, x, tg, loss, emulate_fp16=(dtype == "f16"), impose=dec)
+    o2 = U.oracle_run(model.graph, w_np, xp, tg, loss, emulate_fp16=(dtype == "f16"), impose=dec)
     sens = {}
     for k, t in o1["W"].items():
         if t.grad is not None and o2["W"][k].grad is not None:
@@ -135,7 +137,7 @@ def run_case(call, make, xf, loss, dtype, rng):
     cond = max(sens.values(), default=0.0)
     loss_sens = abs(float(o2["loss"].detach()) - float(o1["loss"].detach())) / max(1.0, abs(float(o1["loss"].detach())))
     nonfinite = model.nonfinite_updates() if hasattr(model, "nonfinite_updates") else 0
-    tol_out, tol_g = (1e-3, 5e-4) if dtype == "f32" else (5e-2, 1.0)
+    tol_out, tol_g = (1e-3, 5e-4) if dtype == "f32" else (2e-2, 6e-2)
     over = {k: v for k, v in arith.items() if v > max(tol_g, 30.0 * sens.get(k, 0.0))}
     # BatchNormalization over fewer than four samples (batch x bottom extent: a 4x4 image at depth 2 with batch 1 normalises ONE value
     # per channel: x - mean is rounding noise times 1 / sqrt(eps)) has no gradient worth the name in the reference either: the
@@ -191,6 +193,7 @@ def run_case(call, make, xf, loss, dtype, rng):
         for k in W:
             if k.endswith("moving_mean") or k.endswith("moving_variance"):
                 stats_err = max(stats_err, float(np.abs(w_end[k] - W_one[k]).max() / (1.0 + np.abs(W_one[k]).max())))
+    residue = U.padding_residue(model)          # the padding entries of every parameter are still exactly zero after two steps
     wt = {k: torch.from_numpy(v) for k, v in model.get_weights().items()}
     ref = run_graph(model.graph, x, wt, training=False)
     pred = model.predict(x)
@@ -207,8 +210,8 @@ def run_case(call, make, xf, loss, dtype, rng):
             margin = top[..., :1] - top[..., 1:]
         pmask += int(((m_got != m_ref) & (margin > 1e-4)).sum())
     bad = (out > tol_out or lossrel > tol_loss or bool(over) or not all(map(lambda v: v == v, (out, lossrel, garith, perr)))
-           or perr > tol_out or (dtype == "f32" and (pmask > 0 or moved_wrong > 1e-2 * max(moved_total, 1) or stats_err > 1e-3)))
-    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e} predict {perr:.1e} masks off {pmask} | {oname}: {moved_wrong} of {moved_total} sure elements moved differently in the first step [{worst_k}], moving statistics {stats_err:.1e}" + (f" [BN over {bottom} sample(s): gradients not held]" if bottom < 4 else "") + (f" loss-scale back-offs {retries}" if retries else "")
+           or perr > (tol_out if dtype == "f32" else 1e-1) or residue != 0.0 or (dtype == "f32" and (pmask > 0 or moved_wrong > 1e-2 * max(moved_total, 1) or stats_err > 1e-3)))
+    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e} predict {perr:.1e} masks off {pmask} | {oname}: {moved_wrong} of {moved_total} sure elements moved differently in the first step [{worst_k}], moving statistics {stats_err:.1e}" + (f" PADDING WEIGHTS NON-ZERO ({residue:.1e})" if residue else "") + (f" [BN over {bottom} sample(s): gradients not held]" if bottom < 4 else "") + (f" loss-scale back-offs {retries}" if retries else "")
     if VERBOSE:
         top = sorted(arith, key=arith.get, reverse=True)[:8]
         msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
