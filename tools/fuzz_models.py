@@ -43,15 +43,26 @@ def targets_for(model, x, loss, rng):
     return tg
 
 
+BIG = False      # --big: images of 64 .. 256 pixels a side and widths up to 64 - the geometries the halo-tile kernels, the split
+                 # reductions and the gathered data gradients take (the default sizes stay on the per-tap kernels)
+
+
 def sample_2d(rng):
     dec = rng.choice(["UNet", "UNet", "UNetE", "UNetP", "UNetPP", "UNetPP", "UNet3P", "MultiResUNet", "MultiResUNet"])
     depth = rng.choice([1, 2, 2, 3, 3, 4])
     unit = 2 ** depth
-    H = unit * rng.choice([1, 2, 3, 4, 5, 8])
-    W = unit * rng.choice([1, 2, 3, 4, 6, 8])
-    while H * W > 96 * 96:                 # (shrink in whole units: the reference needs sizes divisible by 2^depth)
-        H, W = max(unit, H // (2 * unit) * unit), max(unit, W // (2 * unit) * unit)
-    width = rng.choice([4, 6, 8, 12, 16, 20, 32, 40])
+    if BIG:
+        depth = rng.choice([2, 3, 3, 4])
+        unit = 2 ** depth
+        H = 16 * rng.choice([4, 6, 8, 10, 12, 16])
+        W = 16 * rng.choice([4, 5, 6, 8, 12, 16])
+        width = rng.choice([12, 16, 24, 32, 40, 48, 64])
+    else:
+        H = unit * rng.choice([1, 2, 3, 4, 5, 8])
+        W = unit * rng.choice([1, 2, 3, 4, 6, 8])
+        while H * W > 96 * 96:                 # (shrink in whole units: the reference needs sizes divisible by 2^depth)
+            H, W = max(unit, H // (2 * unit) * unit), max(unit, W // (2 * unit) * unit)
+        width = rng.choice([4, 6, 8, 12, 16, 20, 32, 40])
     kw = dict(num_channels=rng.choice([1, 3, 3, 4, 5]), output_nums=rng.choice([1, 1, 1, 2, 4, 9]), ds=rng.choice([0, 0, 1]),
               ae=rng.choice([0, 0, 0, 1]), ag=rng.choice([0, 0, 1]), lstm=rng.choice([0, 0, 1]), dense_loop=rng.choice([1, 1, 2, 3]),
               feature_number=rng.choice([8, 24, 50]), is_transconv=rng.choice([True, True, False]),
@@ -61,7 +72,7 @@ def sample_2d(rng):
     loss = "cce" if fa == "softmax" else rng.choice(["bce", "mse"]) if fa == "sigmoid" else "mse"
     if kw["ds"] == 1 and loss == "cce":
         loss = "mse"                      # the deep-supervision levels are one-channel maps
-    N = rng.choice([1, 2, 2, 3])
+    N = rng.choice([1, 2, 2, 3]) if not BIG else rng.choice([2, 4, 8])
     call = f'unet_model_builder({dec!r}, {H}, {W}, {width}, {depth}, ' + ", ".join(f"{k}={v!r}" for k, v in kw.items()) + f', train_mode="from_scratch").ResNet50()  batch {N} loss {loss}'
     make = lambda: segamd.unet_model_builder(dec, H, W, width, depth, train_mode="from_scratch", **kw).ResNet50()
     x = lambda: torch.rand(N, H, W, kw["num_channels"])
@@ -264,8 +275,12 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all n)")
     ap.add_argument("--start", type=int, default=0)
     ap.add_argument("--worker", action="store_true", help="(internal) run the cases in this process")
+    ap.add_argument("--big", action="store_true", help="2-D models at 64 .. 256 pixels a side, widths up to 64, batch 2 - 8 (halo-tile kernels, split reductions)")
     ap.add_argument("--cases", default="", help="comma list of case indices: run only these, in this process, with the worst tensors listed")
     args = ap.parse_args()
+    global BIG
+    if args.big:
+        BIG, args.only = True, "2d"
     if args.cases:
         global VERBOSE
         VERBOSE = True
@@ -292,7 +307,7 @@ def main():
     while start < args.n and not (args.seconds and time.time() - t0 > args.seconds):
         left = max(1.0, args.seconds - (time.time() - t0)) if args.seconds else 0.0
         cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--n", str(args.n), "--seed", str(args.seed), "--dtype", args.dtype,
-               "--start", str(start), "--seconds", str(left)] + (["--only", args.only] if args.only else [])
+               "--start", str(start), "--seconds", str(left)] + (["--only", args.only] if args.only else []) + (["--big"] if args.big else [])
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1)
         cur, done, tail = None, False, []
         for line in proc.stdout:
