@@ -27,19 +27,38 @@ import segamd
 import gpu_util as U
 
 
+# the 16 losses of the reference's registry (utils/tf_losses.py:9-39) by the kind of target they are meant for; MAPE is left out
+# (targets near zero divide by epsilon: nothing to compare)
+ONE_HOT = ("cce", "categorical_hinge")
+BINARY = ("bce", "binary_focal", "hinge", "squared_hinge")
+SMOOTH = ("mse", "mse", "mae", "msle", "huber", "logcosh", "poisson", "kld", "cosine")
+
+
+def pick_loss(rng, final_activation, n_out, ds):
+    if final_activation == "softmax" and not ds:
+        return rng.choice(["cce", "cce", "categorical_hinge", "sparse_cce", "kld", "cosine"])
+    if final_activation == "sigmoid":
+        # (cosine similarity over a one-channel axis is the constant -1; Poisson takes the log of the deep-supervision levels' linear maps)
+        pool = ["bce", "bce", "mse", "binary_focal", "hinge", "squared_hinge"] + [l for l in SMOOTH[2:] if not (l == "cosine" and n_out == 1) and not (l == "poisson" and ds)]
+        return rng.choice(pool)
+    return rng.choice(["mse", "mse", "mae", "huber", "logcosh"])
+
+
 def targets_for(model, x, loss, rng):
     g = model.graph
     tg = []
     for o in g.outputs:
         H, W, C = g.nodes[o].shape
         shape = (x.shape[0], W, C) if g.ndim == 1 else (x.shape[0], H, W, C)
-        if loss == "cce":
+        if loss in ONE_HOT:
             idx = torch.randint(0, C, shape[:-1])
             tg.append(torch.nn.functional.one_hot(idx, C).float())
-        elif loss == "bce":
+        elif loss == "sparse_cce":
+            tg.append(torch.randint(0, C, shape[:-1]).float())
+        elif loss in BINARY:
             tg.append((torch.rand(shape) > 0.5).float())
         else:
-            tg.append(torch.rand(shape))
+            tg.append(torch.rand(shape) * 0.98 + 0.01)
     return tg
 
 
@@ -69,9 +88,7 @@ def sample_2d(rng):
               alpha=rng.choice([1.0, 1.0, 1.67, 0.5]))
     fa = "softmax" if kw["output_nums"] > 1 and rng.random() < 0.6 else rng.choice(["sigmoid", "sigmoid", "linear"]) if kw["output_nums"] == 1 else "sigmoid"
     kw["final_activation"] = fa
-    loss = "cce" if fa == "softmax" else rng.choice(["bce", "mse"]) if fa == "sigmoid" else "mse"
-    if kw["ds"] == 1 and loss == "cce":
-        loss = "mse"                      # the deep-supervision levels are one-channel maps
+    loss = pick_loss(rng, fa, kw["output_nums"], kw["ds"] == 1)      # (the deep-supervision levels are one-channel maps: no softmax losses)
     N = rng.choice([1, 2, 2, 3]) if not BIG else rng.choice([2, 4, 8])
     call = f'unet_model_builder({dec!r}, {H}, {W}, {width}, {depth}, ' + ", ".join(f"{k}={v!r}" for k, v in kw.items()) + f', train_mode="from_scratch").ResNet50()  batch {N} loss {loss}'
     make = lambda: segamd.unet_model_builder(dec, H, W, width, depth, train_mode="from_scratch", **kw).ResNet50()
@@ -98,7 +115,8 @@ def sample_1d(rng):
         kw["alpha"] = rng.choice([1, 1, 1.67])
         make = lambda: getattr(segamd.UNet1D(L, depth, cin, width, ksz, ptype, **kw), kind)()
         call = f"UNet1D({L}, {depth}, {cin}, {width}, {ksz}, {ptype!r}, " + ", ".join(f"{k}={v!r}" for k, v in kw.items()) + f").{kind}()  batch {N}"
-    loss = "cce" if (ptype == "Classification" and kw["output_nums"] > 1 and kw["ds"] == 0) else "mse"
+    loss = (rng.choice(["cce", "categorical_hinge", "sparse_cce", "kld"]) if (ptype == "Classification" and kw["output_nums"] > 1 and kw["ds"] == 0)
+            else rng.choice(["mse", "mse", "mae", "huber", "logcosh"]))
     x = lambda: torch.rand(N, L, cin)
     return call + f" loss {loss}", make, x, loss
 
@@ -165,7 +183,7 @@ def run_case(call, make, xf, loss, dtype, rng):
     # did (a slice the optimiser kernels missed, a stale operand copy, a late moving-statistics update show up here)
     orng = random.Random(call)
     oname = orng.choice(["Adam", "Adam", "Adam", "SGD", "RMSprop", "Adagrad", "Adamax", "Nadam"])
-    lr = {"SGD": 1e-2}.get(oname, 1e-3)
+    lr = {"SGD": 1e-2 / max(1.0, gn)}.get(oname, 1e-3)       # (SGD moves by lr x gradient: keep the step small whatever the loss's scale)
     model.compile(loss=loss, optimizer=oname, lr=lr)
     w_start = model.get_weights()
     W = {k: torch.from_numpy(np.array(v, np.float32)) for k, v in w_start.items()}
@@ -212,7 +230,10 @@ def run_case(call, make, xf, loss, dtype, rng):
     perr, pmask = 0.0, 0
     for p_, r_ in zip(pred, ref):
         got, rd = torch.from_numpy(p_).reshape(r_.shape), r_.detach()
-        perr = max(perr, float((got - rd).abs().max()) / max(1.0, float(rd.abs().max())))
+        d_ = float((got - rd).abs().max())
+        perr = float("inf") if not (d_ == d_) else max(perr, d_ / max(1.0, float(rd.abs().max())))          # (NaN on either side: inf)
+        if VERBOSE and not (d_ == d_):
+            print(f"        predict: engine NaN count {int(torch.isnan(got).sum())}, oracle NaN count {int(torch.isnan(rd).sum())} of {got.numel()}")
         if rd.shape[-1] == 1:
             m_got, m_ref, margin = got >= 0.5, rd >= 0.5, (rd - 0.5).abs()
         else:
