@@ -143,6 +143,17 @@ def test_engine_reproduces_the_reference(path):
         moved = [k for k in after if not (k.endswith("moving_mean") or k.endswith("moving_variance"))]
         close = np.mean([float(np.mean(np.abs(now[k] - after[k]) < 1e-4)) for k in moved])
         assert close > 0.99, (meta["case"], close)
+        # the trajectory: the capture's extra steps on the same batch, then inference ('predict_after_steps/*' - fixtures written
+        # before round 5 do not have it)
+        z = np.load(path)
+        extra = [k for k in z.files if k.startswith("predict_after_steps/")]
+        if extra:
+            for _ in range(int(meta.get("train_step", {}).get("extra_steps", 2))):
+                m.train_step(torch.from_numpy(x), tg)
+            got = m.predict(x)
+            got = got if isinstance(got, list) else [got]
+            for i, g_ in enumerate(got):
+                assert float(np.abs(g_ - z[f"predict_after_steps/{i}"]).max()) < 5e-3, (meta["case"], i)
 
 
 def test_the_skip_is_visible_and_the_capture_spec_is_self_contained():
@@ -152,7 +163,7 @@ def test_the_skip_is_visible_and_the_capture_spec_is_self_contained():
     assert "keras_map.keras_weights_by_structural_name" in src and "/root/reference" not in src
     # the cases cover the semantics SURVEY 8c marks: ConvLSTM (hard-sigmoid) in 2D and 1D, attention gates, MultiRes, 1D builders,
     # BCDUNet, and the training-side quantities (moving statistics after a training-mode call, one Adam step)
-    for needle in ("lstm=1", "ag=1", "MultiResUNet", "Models.unet_variants", "Models.BCDUNet", "moving_after/", "w_after/", "train_on_batch"):
+    for needle in ("lstm=1", "ag=1", "MultiResUNet", "Models.unet_variants", "Models.BCDUNet", "moving_after/", "w_after/", "train_on_batch", "predict_after_steps/", "unet3p_w12"):
         assert needle in src, needle
     if not FIXTURES:
         pytest.skip("parity unpinned: no TensorFlow-produced fixture present (expected in this container)")
@@ -170,8 +181,8 @@ def test_fixture_consumers_run_on_an_oracle_made_stand_in(case, tmp_path):
     cap = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cap)
     if case in cap.CASES:
-        dec, kw = cap.CASES[case]
-        meta = dict(case=case, ndim=2, decoder=dec, kwargs=kw, H=32, W=32, width=cap.WIDTH, depth=cap.DEPTH)
+        dec, kw = cap.CASES[case][:2]
+        meta = dict(case=case, ndim=2, decoder=dec, kwargs=kw, H=32, W=32, width=(cap.CASES[case][2] if len(cap.CASES[case]) > 2 else cap.WIDTH), depth=cap.DEPTH)
         x = np.random.default_rng(0).random((2, 32, 32, kw.get("num_channels", 3)), dtype=np.float32)
     else:
         _mod, cls, method, pos, kw = cap.CASES_1D[case]

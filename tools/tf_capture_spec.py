@@ -20,6 +20,7 @@ For every case below it
   6. takes ONE optimiser step - `compile(Adam(1e-3), 'mse')`, `train_on_batch(x, t)` with t = 0.5 everywhere - and keeps the loss it
      reports and every weight afterwards ('loss', 'w_after/<name>': Keras' Adam with epsilon outside the root, the MSE reduction,
      the gradient of every layer type on the path),
+  6b. takes EXTRA_STEPS more steps on the same batch and keeps `predict(x)` afterwards ('predict_after_steps/<i>'),
   7. writes tests/golden/tf_<case>.npz: 'meta' (json: constructor arguments, TF / Keras versions), 'x', 'w/<structural name>'
      for every weight, 'predict/<i>' and 'train_fwd/<i>' for every output, and the arrays of 5. and 6.
 The cases cover every semantic SURVEY.md 8c marks as a risk in ONE run: Conv2DTranspose 'same' cropping and LeakyReLU 0.3
@@ -51,7 +52,14 @@ CASES = {
     "unet_upsampling": ("UNet", dict(num_channels=3, is_transconv=False)),
     "unet3p": ("UNet3P", dict(num_channels=3)),
     "multiresunet_ag": ("MultiResUNet", dict(num_channels=3, ag=1, alpha=1.0)),
+    # widths that are NOT multiples of 8 (third element: model_width instead of WIDTH).  Round 5's fuzzer found every defect of the
+    # round behind them: padding channels (sigmoid(0) = 0.5 leaking into them: UNet 3+, the attention gate's 1-channel map), ConvLSTM
+    # gate blocks, Dense-bottleneck extents - and none of them shows in the first step: hence 'predict_after_steps/*' below
+    "unet3p_w12": ("UNet3P", dict(num_channels=3), 12),
+    "multiresunet_ag_w12": ("MultiResUNet", dict(num_channels=3, ag=1, alpha=1.67), 12),
+    "unet_lstm_ae_w12": ("UNet", dict(num_channels=5, lstm=1, ae=1, feature_number=10), 12),
 }
+EXTRA_STEPS = 2       # optimiser steps after the first one before 'predict_after_steps/*' is taken
 # 1D: (module of the reference, class, method, positional (length, model_depth, num_channel, model_width, kernel_size), kwargs)
 CASES_1D = {
     "unet1d": ("Models.unet_variants", "UNet", "UNet", (256, 2, 1, 8, 3), dict(problem_type="Regression", output_nums=1, ds=1)),
@@ -88,14 +96,21 @@ def capture(tf, kmodel, g, x, meta, keras_map, path):
     loss = kmodel.train_on_batch(x, targets if len(targets) > 1 else targets[0])
     loss = float(loss[0] if isinstance(loss, (list, tuple)) else loss)
     w_after = keras_map.keras_weights_by_structural_name(kmodel, g)
+    # ... and the trajectory: EXTRA_STEPS more steps on the same batch, then inference (a defect that leaves the first step exact -
+    # weights that should never move, a stale operand copy - shows here)
+    for _ in range(EXTRA_STEPS):
+        kmodel.train_on_batch(x, targets if len(targets) > 1 else targets[0])
+    pred_after = kmodel.predict(x, verbose=0)
+    pred_after = pred_after if isinstance(pred_after, list) else [pred_after]
     meta = dict(meta, tensorflow=tf.__version__, keras=getattr(tf.keras, "__version__", "?"), output_names=list(kmodel.output_names),
-                train_step=dict(optimizer="Adam", lr=1e-3, loss="mse", target=0.5))
+                train_step=dict(optimizer="Adam", lr=1e-3, loss="mse", target=0.5, extra_steps=EXTRA_STEPS))
     arrays = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), "x": x, "loss": np.float32(loss)}
     arrays.update({"w/" + k.replace("/", "|"): v for k, v in weights.items()})
     arrays.update({"moving_after/" + k.replace("/", "|"): v for k, v in moving.items()})
     arrays.update({"w_after/" + k.replace("/", "|"): v for k, v in w_after.items()})
     arrays.update({f"predict/{i}": np.asarray(p, np.float32) for i, p in enumerate(pred)})
     arrays.update({f"train_fwd/{i}": np.asarray(p, np.float32) for i, p in enumerate(trn)})
+    arrays.update({f"predict_after_steps/{i}": np.asarray(p, np.float32) for i, p in enumerate(pred_after)})
     np.savez_compressed(path, **arrays)
     print(f"{meta['case']}: {len(weights)} weights, {len(pred)} outputs, loss {loss:.6f} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
 
@@ -116,11 +131,12 @@ def main():
         path = os.path.join(args.out, f"tf_{case}.npz")
         if case in CASES:
             ref = importlib.import_module("models.unet_variants")     # the reference's 2D module, from PYTHONPATH
-            dec, kw = CASES[case]
-            kmodel = ref.unet_model_builder(dec, H, W, WIDTH, DEPTH, train_mode="from_scratch", **kw).ResNet50()
-            g = segamd.unet_model_builder(dec, H, W, WIDTH, DEPTH, train_mode="from_scratch", **kw).graph()
+            dec, kw = CASES[case][:2]
+            width = CASES[case][2] if len(CASES[case]) > 2 else WIDTH
+            kmodel = ref.unet_model_builder(dec, H, W, width, DEPTH, train_mode="from_scratch", **kw).ResNet50()
+            g = segamd.unet_model_builder(dec, H, W, width, DEPTH, train_mode="from_scratch", **kw).graph()
             x = np.random.default_rng(0).random((2, H, W, kw.get("num_channels", 3)), dtype=np.float32)
-            meta = dict(case=case, ndim=2, decoder=dec, kwargs=kw, H=H, W=W, width=WIDTH, depth=DEPTH)
+            meta = dict(case=case, ndim=2, decoder=dec, kwargs=kw, H=H, W=W, width=width, depth=DEPTH)
         else:
             mod, cls, method, pos, kw = CASES_1D[case]
             ref = importlib.import_module(mod)                         # the reference's 1D module (TensorFlow/1DCNN on PYTHONPATH)
