@@ -169,7 +169,7 @@ def test_the_skip_is_visible_and_the_capture_spec_is_self_contained():
         pytest.skip("parity unpinned: no TensorFlow-produced fixture present (expected in this container)")
 
 
-@pytest.mark.parametrize("case", ["unet_lstm", "unet1d_lstm_ag", "bcdunet1d"])
+@pytest.mark.parametrize("case", ["unet_lstm", "unet1d_lstm_ag", "bcdunet1d", "unet_lstm_ae_w12", "unet3p_w12"])
 def test_fixture_consumers_run_on_an_oracle_made_stand_in(case, tmp_path):
     """Plumbing only - NOT a pin: a file in the fixture format is written from the ORACLE's own outputs (same keys, same meta as
     tools/tf_capture_spec.py writes for the case) and the CPU consumer above is run on it, so that the first TensorFlow-made
