@@ -366,3 +366,23 @@ def padding_residues(model) -> dict:
             out[name] = d
     return out
 
+
+def padding_leaks(model) -> dict:
+    """{tensor name: max |value| in its padding channels} over the materialised activation and gradient tensors of the pass just run,
+    for the tensors where it is not zero (every kernel keeps channels >= C of a row of cs exactly zero)."""
+    out = {}
+    for name, t in model.tensors.items():
+        if not getattr(t, "materialised", True) or t.cs == t.C or getattr(t, "gate_pad", None) is not None:
+            continue
+        for what, buf in (("", t.buf), (":grad", t.grad)):
+            if buf is None or not buf.numel():
+                continue
+            v = float(DevTensorDecode(buf)[..., t.C:].abs().max())
+            if v != 0.0:
+                out[name + what] = v
+    return out
+
+
+def DevTensorDecode(buf):
+    return (SF.split_unpack(buf) if buf.dtype == torch.float32 else buf.float()).cpu()
+

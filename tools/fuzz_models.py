@@ -141,6 +141,7 @@ def run_case(call, make, xf, loss, dtype, rng):
             break
         model.grad_target = max(model.grad_target / 2.0, 1.0)
         retries += 1
+    leaks = U.padding_leaks(model)          # padding channels of every activation / gradient tensor of the pass just run: exactly zero
     out = max(e / max(1.0, m) for e, m in zip(r["outs"], r["out_mag"]))
     lossrel = abs(r["loss"][0] - r["loss"][1]) / max(1.0, abs(r["loss"][1]))
     gn = max((n for _e, n in r["gl2"].values()), default=0.0)
@@ -247,8 +248,8 @@ def run_case(call, make, xf, loss, dtype, rng):
     if chaotic:
         moved_wrong, pmask, perr = 0, 0, min(perr, 0.0)
     bad = (out > tol_out or lossrel > tol_loss or bool(over) or not all(map(lambda v: v == v, (out, lossrel, garith, perr)))
-           or perr > (tol_out if dtype == "f32" else 1e-1) or residue != 0.0 or (dtype == "f32" and (pmask > 0 or moved_wrong > 1e-2 * max(moved_total, 1) or stats_err > 1e-3)))
-    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e} predict {perr:.1e} masks off {pmask} | {oname}: {moved_wrong} of {moved_total} sure elements moved differently in the first step [{worst_k}], moving statistics {stats_err:.1e}" + (f" PADDING WEIGHTS NON-ZERO ({residue:.1e})" if residue else "") + (f" [BN over {bottom} sample(s): gradients not held]" if bottom < 4 else "") + (f" loss-scale back-offs {retries}" if retries else "")
+           or perr > (tol_out if dtype == "f32" else 1e-1) or residue != 0.0 or bool(leaks) or (dtype == "f32" and (pmask > 0 or moved_wrong > 1e-2 * max(moved_total, 1) or stats_err > 1e-3)))
+    msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e} predict {perr:.1e} masks off {pmask} | {oname}: {moved_wrong} of {moved_total} sure elements moved differently in the first step [{worst_k}], moving statistics {stats_err:.1e}" + (f" PADDING WEIGHTS NON-ZERO ({residue:.1e})" if residue else "") + (f" PADDING CHANNELS NON-ZERO {dict(list(leaks.items())[:4])}" if leaks else "") + (f" [BN over {bottom} sample(s): gradients not held]" if bottom < 4 else "") + (f" loss-scale back-offs {retries}" if retries else "")
     if VERBOSE:
         top = sorted(arith, key=arith.get, reverse=True)[:8]
         msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
