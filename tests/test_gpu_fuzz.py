@@ -53,3 +53,19 @@ def test_random_builder_configurations_match_the_oracle(seed, n):
     print(f"fuzz sample seed {seed}: {ok} ok, {refused} refused as the reference refuses them, {len(failed)} failed")
     assert not failed, "\n".join(f"[{i}] {c}\n    {m}" for i, c, m in failed)
     assert ok >= n * 0.8
+
+
+@pytest.mark.parametrize("dec", ["UNetPP", "UNet3P"])
+def test_depth_eight_concatenates_more_segments_than_the_kernels_walk(dec):
+    """UNet++ / UNet 3+ of depth 8 concatenate NINE tensors in front of X08 / dec0; the GEMM kernels walk at most eight K segments.
+    The leading pieces are materialised into one tensor (model.py, 'concat'), the rest stays virtual - until round 5 this was a
+    NotImplementedError although the reference takes any depth (unet_variants.py:1036-1043).  Same checks as a fuzz case."""
+    import segamd
+    make = lambda: segamd.unet_model_builder(dec, 256, 256, 4, 8, num_channels=3, ds=1, train_mode="from_scratch").ResNet50()
+    torch.manual_seed(8)
+    bad, msg = FZ.run_case(dec + " depth 8", make, lambda: torch.rand(4, 256, 256, 3), "mse", "f32", random.Random(8))
+    print(msg)
+    assert not bad, msg
+    m = make()
+    m.build(1, dtype="f32")
+    assert any(type(o).__name__ == "ConcatOp" and o.out.name.endswith(":part") for o in m.ops)

@@ -342,7 +342,14 @@ class SegModel:
                 for j in n.inputs:
                     segs.extend(segs_of(j))
                 if len(segs) > _ffi.MAX_SEG:
-                    raise NotImplementedError(f"{n.name}: more than {_ffi.MAX_SEG} concat segments")
+                    # the GEMM kernels walk at most MAX_SEG (8) K segments (UNet++ / UNet 3+ of depth 8 concatenate 9): the leading
+                    # pieces are materialised into ONE tensor (element-granular channel copies each way, as for a BatchNormalization
+                    # over a concatenation), the rest stays virtual - the reference takes any depth (unet_variants.py:1036-1043)
+                    k = len(segs) - _ffi.MAX_SEG + 1
+                    head = segs[:k]
+                    part = DevTensor(n.name + ":part", N, head[0][0].H, head[0][0].W, sum(c for _t, c in head))
+                    self.ops.append(ConcatOp(self, head, part))
+                    segs = [(part, part.C)] + segs[k:]
                 val[i] = segs
             elif k in ("conv", "convT", "convlstm"):
                 if k == "conv" and i in outset and n.attrs["kernel"] == (1, 1):
