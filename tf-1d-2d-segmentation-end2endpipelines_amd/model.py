@@ -696,14 +696,16 @@ class SegModel:
 
     def loss_scale_feedback(self, skipped: int):
         """Dynamic loss scaling: `skipped` = parameter elements whose update an optimiser step skipped because their gradient was
-        NaN / Inf (an overflow of the fp16-range gradient storage).  Non-zero: the target halves (never below 1); after
+        NaN / Inf (an overflow of the fp16-range gradient storage).  Non-zero: the target halves (down to 2^-20: a network whose
+        backward pass amplifies by more than 65 504 - BatchNormalization after BatchNormalization on a near-constant signal - still
+        finds a scale at which nothing overflows, at the price of its smallest gradients); after
         `loss_scale_growth_interval` clean steps it doubles again, up to the mode's default.  train_step() feeds it from the
         asynchronous counter (one step late, no synchronisation); harness.fit adds what the end of an epoch drains and logs the
         total (`take_skipped`)."""
         if skipped:
             self._ls_skipped += int(skipped)
             self._ls_clean = 0
-            self.grad_target = max(self.grad_target / 2.0, 1.0)
+            self.grad_target = max(self.grad_target / 2.0, 2.0 ** -20)      # (a power of two: the device picks scale = target / max |dLoss/dOut| as one)
         else:
             self._ls_clean += 1
             if self._ls_clean >= self.loss_scale_growth_interval and self.grad_target < self.grad_target_max:

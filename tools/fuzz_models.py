@@ -101,7 +101,7 @@ def sample_1d(rng):
     depth = rng.choice([1, 2, 3, 3, 4])
     L = 2 ** depth * rng.choice([2, 4, 5, 8, 16, 25, 32])
     width = rng.choice([4, 8, 12, 16, 24])
-    ksz = rng.choice([3, 3, 3, 5, 7])
+    ksz = rng.choice([3, 3, 3, 5, 7, 2, 4, 6, 9, 11, 1])
     kw = dict(output_nums=rng.choice([1, 1, 2, 3]), ds=rng.choice([0, 1]), ae=rng.choice([0, 0, 1]), ag=rng.choice([0, 0, 1]),
               lstm=rng.choice([0, 0, 1]), feature_number=rng.choice([8, 40]), is_transconv=rng.choice([True, True, False]))
     ptype = rng.choice(["Regression", "Regression", "Classification"])
@@ -137,9 +137,9 @@ def run_case(call, make, xf, loss, dtype, rng):
         # (f16 = the throughput mode: held against the ROUNDING-EMULATING oracle - same rounding points on the CPU - so that what is
         # compared is the kernels' logic, not fp16 against fp32)
         r = U.compare_model(model, x, tg, loss, emulate_fp16=(dtype == "f16"), impose_decisions=True)
-        if all(e == e for e, _n in r["gl2"].values()) or retries >= 8:
+        if all(e == e for e, _n in r["gl2"].values()) or retries >= 24:
             break
-        model.grad_target = max(model.grad_target / 2.0, 1.0)
+        model.grad_target = max(model.grad_target / 2.0, 2.0 ** -20)
         retries += 1
     leaks = U.padding_leaks(model)          # padding channels of every activation / gradient tensor of the pass just run: exactly zero
     out = max(e / max(1.0, m) for e, m in zip(r["outs"], r["out_mag"]))
