@@ -645,8 +645,8 @@ class SegModel:
     def nonfinite_updates(self, reset: bool = False) -> int:
         """Parameter elements whose update the optimiser skipped since the last reset because their gradient was NaN or
         +-Inf (an overflow of the fp16 backward pass; Keras would have propagated the NaN into the weights).  Reading it
-        synchronises with the device - harness.fit reads it once per step next to the loss and halves `grad_target` (the
-        fp16 loss scale) when it is non-zero, the way dynamic loss scaling backs off."""
+        synchronises with the device; train_step() uses the asynchronous form (nonfinite_updates_async, one step late) and feeds it to
+        loss_scale_feedback(), which halves `grad_target` (the loss scale) when it is non-zero, the way dynamic loss scaling backs off."""
         self._join_side()
         n = int(self.store.nonfinite.cpu())
         if reset and n:
