@@ -337,7 +337,7 @@ def launch_plan(gpus, env, argv):
                            loopback address because the container's hostname may not resolve) - relay its output and exit with its
                            code (a child process, never an exec: no HIP call has been made yet here, and none will be);
       ("error", text, N)   --gpus was given AND disagrees with WORLD_SIZE: the line would report a job that was not run."""
-    ws = env.get("WORLD_SIZE")
+    ws = env.get("WORLD_SIZE") or None          # (an empty value is "not set")
     if ws is not None:
         if gpus is not None and int(ws) != gpus:
             return "error", f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus} (or drop --gpus / WORLD_SIZE)", gpus
@@ -398,7 +398,7 @@ def main():
     if what == "spawn":
         sys.exit(spawn_ranks(payload))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE") or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

@@ -19,6 +19,7 @@ def test_launch_plan():
     b = _bench()
     assert b.launch_plan(1, {}, ["--gpus", "1"]) == ("run", None, 1)
     assert b.launch_plan(None, {}, []) == ("run", None, 1)
+    assert b.launch_plan(None, {"WORLD_SIZE": ""}, []) == ("run", None, 1)          # an empty value is "not set"
     assert b.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, ["--gpus", "8"]) == ("run", None, 8)
     what, msg, _n = b.launch_plan(8, {"WORLD_SIZE": "1"}, ["--gpus", "8"])
     assert what == "error" and "WORLD_SIZE=1" in msg
