@@ -36,7 +36,7 @@ enum { SEG_LOSS_MSE = 0, SEG_LOSS_BCE = 1, SEG_LOSS_CCE = 2, SEG_LOSS_MAE = 3, S
        SEG_LOSS_FOCAL = 11, SEG_LOSS_KLD = 12, SEG_LOSS_CATHINGE = 13, SEG_LOSS_COSINE = 14, SEG_LOSS_SPARSE_CCE = 15 };
 
 #define SEG_MAX_SEG 8
-#define SEG_MAX_TAPS 16
+#define SEG_MAX_TAPS 32        /* taps of all sub-pixel classes together: a 1-D kernel_size of up to 32 (the reference takes any) */
 #define SEG_MAX_CLS 4
 
 const char* seg_last_error(void);

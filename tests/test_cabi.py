@@ -63,7 +63,7 @@ def test_abi_version_ignores_comments_and_survives_a_missing_header(built, tmp_p
 def test_struct_layout_matches_header():
     """ctypes mirrors of seg_geom / seg_igemm_*_args: field order and sizes as declared in the header."""
     ffi = importlib.import_module(PKG + "._ffi")
-    assert ctypes.sizeof(ffi.Geom) == 4 * (14 + 2 * 4 + 3 * 16)
+    assert ctypes.sizeof(ffi.Geom) == 4 * (14 + 2 * 4 + 3 * 32)
     hdr = open(os.path.join(ROOT, "include", "seg_hip.h")).read()
     for struct, cls in (("seg_igemm_fwd_args", ffi.IgemmFwdArgs), ("seg_igemm_wgrad_args", ffi.IgemmWgradArgs), ("seg_geom", ffi.Geom),
                         ("seg_transpose_desc", ffi.TransposeDesc)):

@@ -37,7 +37,10 @@ def _fill_geom(g: Geom, N, Hin, Win, Hl, Wl, isy, isx, Hout, Wout, osy, osx, cla
     g.N, g.Hin, g.Win, g.Hl, g.Wl, g.isy, g.isx = N, Hin, Win, Hl, Wl, isy, isx
     g.Hout, g.Wout, g.osy, g.osx = Hout, Wout, osy, osx
     g.ncls, g.ntaps, g.T_total = len(classes), len(classes[0][2]), T_total
-    assert all(len(c[2]) == g.ntaps for c in classes) and g.ncls * g.ntaps <= _ffi.MAX_TAPS and g.ncls <= _ffi.MAX_CLS
+    assert all(len(c[2]) == g.ntaps for c in classes) and g.ncls <= _ffi.MAX_CLS
+    if g.ncls * g.ntaps > _ffi.MAX_TAPS:
+        raise NotImplementedError(f"a convolution of {g.ncls * g.ntaps} taps: the implicit-GEMM geometry (seg_geom) holds at most "
+                                  f"SEG_MAX_TAPS = {_ffi.MAX_TAPS} (1-D kernel_size <= {_ffi.MAX_TAPS}, 2-D kernels up to 5x5)")
     for ci, (oy, ox, taps) in enumerate(classes):
         g.oy[ci], g.ox[ci] = oy, ox
         for t, (dy, dx, wi) in enumerate(taps):

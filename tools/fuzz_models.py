@@ -101,7 +101,7 @@ def sample_1d(rng):
     depth = rng.choice([1, 2, 3, 3, 4])
     L = 2 ** depth * rng.choice([2, 4, 5, 8, 16, 25, 32])
     width = rng.choice([4, 8, 12, 16, 24])
-    ksz = rng.choice([3, 3, 3, 5, 7, 2, 4, 6, 9, 11, 1])
+    ksz = rng.choice([3, 3, 3, 5, 7, 2, 4, 6, 9, 11, 1, 17, 25, 32])
     kw = dict(output_nums=rng.choice([1, 1, 2, 3]), ds=rng.choice([0, 1]), ae=rng.choice([0, 0, 1]), ag=rng.choice([0, 0, 1]),
               lstm=rng.choice([0, 0, 1]), feature_number=rng.choice([8, 40]), is_transconv=rng.choice([True, True, False]))
     ptype = rng.choice(["Regression", "Regression", "Classification"])
