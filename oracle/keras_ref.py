@@ -88,19 +88,45 @@ def same_pad(n_in: int, k: int, s: int) -> Tuple[int, int]:
 
 
 _NARROW = 16
+import warnings as _warnings
+_warnings.filterwarnings("ignore", message="TF32 acceleration on top of oneDNN")      # (torch.backends.mkldnn.flags() prints it on CPUs)
+
+
+class _NativeConv(torch.autograd.Function):
+    """F.conv2d / F.conv_transpose2d with oneDNN switched off for the forward AND the backward call (torch picks the convolution
+    backend when each of them runs, so a context manager around the forward alone is not enough), on contiguous NCHW tensors."""
+
+    @staticmethod
+    def forward(ctx, xin, w, bias, stride, transposed):
+        ctx.stride, ctx.transposed = stride, transposed
+        ctx.save_for_backward(xin, w, bias)
+        with torch.backends.mkldnn.flags(enabled=False):
+            return (F.conv_transpose2d if transposed else F.conv2d)(xin, w, bias, stride=stride)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xin, w, bias = ctx.saved_tensors
+        args = [t.detach().requires_grad_(True) if t is not None else None for t in (xin, w, bias)]
+        need = [a for a, n in zip(args, ctx.needs_input_grad[:3]) if a is not None and n]
+        with torch.enable_grad(), torch.backends.mkldnn.flags(enabled=False):
+            y = (F.conv_transpose2d if ctx.transposed else F.conv2d)(args[0], args[1], args[2], stride=ctx.stride)
+            got = iter(torch.autograd.grad(y, need, gy.contiguous()) if need else ())
+        out = [next(got) if (a is not None and n) else None for a, n in zip(args, ctx.needs_input_grad[:3])]
+        return out[0], out[1], out[2], None, None
 
 
 def _conv(xin, w, bias, stride, transposed=False):
     """F.conv2d / F.conv_transpose2d on the NHWC tensor's NCHW view (channels-last strides: oneDNN's fast path, ~1.6 x the NCHW
-    kernels on wide layers).  NARROW layers get a contiguous NCHW copy instead: with torch 2.10 / oneDNN on this image the
-    channels-last BACKWARD of a convolution with a handful of channels (the attention gate's theta / phi / psi convs at model
-    widths 4 - 8, unet_variants.py:69-78) corrupts the heap when it runs on several threads - "double free or corruption",
-    "corrupted size vs. prev_size" or a segmentation fault in about one of six random attention-gate models
-    (tools/fuzz_models.py; reproducible with the oracle alone, never with one thread, with oneDNN off or with NCHW inputs).
-    Same arithmetic either way; the copy costs nothing at these widths."""
+    kernels on wide layers).  NARROW layers (at most 16 input or output channels) take torch's native kernels on contiguous NCHW
+    copies instead: with torch 2.10 / oneDNN on this image the BACKWARD of a convolution with a handful of channels corrupts the heap
+    when it runs on several threads - "double free or corruption", "corrupted size vs. prev_size", segmentation faults or bus
+    errors: in about one of six random attention-gate models on the channels-last path (theta / phi / psi convs at model widths
+    4 - 8, unet_variants.py:69-78; tools/fuzz_models.py), and on the NCHW path still for a 1x1 / stride-2 convolution of ONE input
+    channel (tools/fuzz_ops.py) - reproducible with the oracle alone, never with one thread or with oneDNN off.  Same arithmetic
+    either way; the native kernels are 3 - 6 x slower on wide layers, which therefore stay on oneDNN."""
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     if min(cin, cout) <= _NARROW:
-        xin = xin.contiguous()
+        return _NativeConv.apply(xin.contiguous(), w.contiguous(), bias, tuple(stride), transposed)
     return (F.conv_transpose2d if transposed else F.conv2d)(xin, w, bias, stride=stride)
 
 
