@@ -13,7 +13,9 @@ boundary; a 1D signal (N, L, C) is handled as (N, 1, L, C).
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import warnings
 import zlib
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -88,8 +90,14 @@ def same_pad(n_in: int, k: int, s: int) -> Tuple[int, int]:
 
 
 _NARROW = 16
-import warnings as _warnings
-_warnings.filterwarnings("ignore", message="TF32 acceleration on top of oneDNN")      # (torch.backends.mkldnn.flags() prints it on CPUs)
+
+
+@contextlib.contextmanager
+def _no_onednn():
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="TF32 acceleration on top of oneDNN")      # (what flags() says on a CPU-only torch)
+        with torch.backends.mkldnn.flags(enabled=False):
+            yield
 
 
 class _NativeConv(torch.autograd.Function):
@@ -100,7 +108,7 @@ class _NativeConv(torch.autograd.Function):
     def forward(ctx, xin, w, bias, stride, transposed):
         ctx.stride, ctx.transposed = stride, transposed
         ctx.save_for_backward(xin, w, bias)
-        with torch.backends.mkldnn.flags(enabled=False):
+        with _no_onednn():
             return (F.conv_transpose2d if transposed else F.conv2d)(xin, w, bias, stride=stride)
 
     @staticmethod
@@ -108,7 +116,7 @@ class _NativeConv(torch.autograd.Function):
         xin, w, bias = ctx.saved_tensors
         args = [t.detach().requires_grad_(True) if t is not None else None for t in (xin, w, bias)]
         need = [a for a, n in zip(args, ctx.needs_input_grad[:3]) if a is not None and n]
-        with torch.enable_grad(), torch.backends.mkldnn.flags(enabled=False):
+        with torch.enable_grad(), _no_onednn():
             y = (F.conv_transpose2d if ctx.transposed else F.conv2d)(args[0], args[1], args[2], stride=ctx.stride)
             got = iter(torch.autograd.grad(y, need, gy.contiguous()) if need else ())
         out = [next(got) if (a is not None and n) else None for a, n in zip(args, ctx.needs_input_grad[:3])]

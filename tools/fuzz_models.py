@@ -8,7 +8,8 @@ the parity mode (forward + loss + backward through the C ABI) against the oracle
 Every case prints one line (OK / FAIL / RAISED with the constructor call); the summary at the end lists what to look at.  A case
 counts as failed when an output is off by more than 1e-3 (the north-star bound; the kernels deliver ~1e-5), the loss by more than
 1e-5 relative, a parameter gradient with the GPU's branch decisions imposed by more than 5e-4 relative L2 (measured ~1e-5) AND by
-more than 30 x what the oracle's own gradient moves when the input is perturbed by 1e-6 (the conditioning of that gradient), or
+more than 10 x what the oracle's own gradient moves when the input is perturbed by 1e-6 and the parameters by 2^-22 relative - the
+rounding of the parity mode's storage format - (the conditioning of that gradient), or
 when the engine raises where the oracle's graph runs.  Build-authored test tooling; needs an MI355X."""
 import argparse
 import os
@@ -159,7 +160,10 @@ def run_case(call, make, xf, loss, dtype, rng):
     w_np = model.get_weights()
     xp = x * (1.0 + 1e-6 * torch.randn_like(x))
     o1 = U.oracle_run(model.graph, w_np, x, tg, loss, emulate_fp16=(dtype == "f16"), impose=dec)
-    o2 = U.oracle_run(model.graph, w_np, xp, tg, loss, emulate_fp16=(dtype == "f16"), impose=dec)
+    # (... and on parameters perturbed by 2^-22 relative, the rounding of the parity mode's storage format: what the engine holds IS
+    # such a perturbed copy of them)
+    w_pert = {k: (np.asarray(v) * (1.0 + 2.0 ** -22 * torch.randn(np.shape(v), dtype=torch.float64).numpy())).astype(np.asarray(v).dtype) for k, v in w_np.items()}
+    o2 = U.oracle_run(model.graph, w_pert, xp, tg, loss, emulate_fp16=(dtype == "f16"), impose=dec)
     sens = {}
     for k, t in o1["W"].items():
         if t.grad is not None and o2["W"][k].grad is not None:
@@ -168,7 +172,7 @@ def run_case(call, make, xf, loss, dtype, rng):
     loss_sens = abs(float(o2["loss"].detach()) - float(o1["loss"].detach())) / max(1.0, abs(float(o1["loss"].detach())))
     nonfinite = model.nonfinite_updates() if hasattr(model, "nonfinite_updates") else 0
     tol_out, tol_g = (1e-3, 5e-4) if dtype == "f32" else (2e-2, 6e-2)
-    over = {k: v for k, v in arith.items() if v > max(tol_g, 30.0 * sens.get(k, 0.0))}
+    over = {k: v for k, v in arith.items() if v > max(tol_g, 10.0 * sens.get(k, 0.0))}
     # BatchNormalization over fewer than four samples (batch x bottom extent: a 4x4 image at depth 2 with batch 1 normalises ONE value
     # per channel: x - mean is rounding noise times 1 / sqrt(eps)) has no gradient worth the name in the reference either: the
     # forward pass, the loss and predict() are still held, the gradients are reported only
@@ -260,7 +264,9 @@ def run_case(call, make, xf, loss, dtype, rng):
         pmask += int(((m_got != m_ref) & (margin > 1e-4)).sum())
     # (a gradient that moves by more than 1 % under a 1e-6 perturbation of the input - saturated cross-entropy - makes the trajectories
     # of the two training loops diverge whatever the kernels do: the optimiser step and predict() are then reported, not held)
-    chaotic = cond > 1e-2
+    # (the oracle's training loop decides its ReLUs / pools itself: where ONE decision on a rounding boundary moves its gradient by more
+    # than 1 % - batch 1, a handful of channels - the two first steps differ by that flip, not by the optimiser kernels)
+    chaotic = cond > 1e-2 or (flips > 0 and gown > 1e-2)
     if chaotic:
         moved_wrong, pmask, perr = 0, 0, min(perr, 0.0)
     bad = (out > tol_out or lossrel > tol_loss or bool(over) or not all(map(lambda v: v == v, (out, lossrel, garith, perr)))
@@ -270,7 +276,7 @@ def run_case(call, make, xf, loss, dtype, rng):
     msg = f"out {out:.1e} loss {lossrel:.1e} grad(arith) {garith:.1e} [{worst}] grad(own) {gown:.1e} flips {flips} sensitivity {cond:.1e} predict {perr:.1e} masks off {pmask} | {oname}: {moved_wrong} of {moved_total} sure elements moved differently in the first step [{worst_k}], moving statistics {stats_err:.1e}" + (f" NOT REPRODUCIBLE: {repro_bad} elements differ between two identical runs" if repro_bad else "") + (f" PADDING WEIGHTS NON-ZERO ({residue:.1e})" if residue else "") + (f" PADDING CHANNELS NON-ZERO {dict(list(leaks.items())[:4])}" if leaks else "") + (f" [BN over {bottom} sample(s): only the invariants are held]" if bottom < 4 else "") + (f" loss-scale back-offs {retries}" if retries else "")
     if VERBOSE:
         top = sorted(arith, key=arith.get, reverse=True)[:8]
-        msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
+        msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} (relative {arith[k]:.1e}, conditioning {sens.get(k, 0.0):.1e}) norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
         msg += "\n        activation gradients off by more than 1e-3 of their own maximum (graph order): " + "; ".join(
             f"{n} {e / (m_ + 1e-30):.1e}" for n, e, m_ in r["agrads"] if e > 1e-3 * m_)[:3000]
         msg += "\n        worst forward nodes: " + ", ".join(f"{n} {e:.1e}/{m_:.1e}" for n, e, m_ in sorted(r["nodes"], key=lambda t: -t[1] / max(1.0, t[2]))[:4])

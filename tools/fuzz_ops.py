@@ -153,33 +153,28 @@ def run_wgrad(c, rng):
     return msgs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=500)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=0.0)
-    ap.add_argument("--start", type=int, default=0)
-    args = ap.parse_args()
-    rng = random.Random(args.seed)
-    torch.set_num_threads(16)
+def run(n, seed, seconds=0.0, start=0, verbose=True):
+    """Cases [start, n) of the seed's sequence: (launches right, launches refused with an argument error, [(case, description, what)])."""
+    rng = random.Random(seed)
     t0 = time.time()
     n_ok = n_ref = 0
     fails = []
-    for i in range(args.n):
-        if args.seconds and time.time() - t0 > args.seconds:
+    say = print if verbose else (lambda *a, **k: None)
+    for i in range(n):
+        if seconds and time.time() - t0 > seconds:
             break
         c = sample(rng)
-        torch.manual_seed(args.seed * 7919 + i)
-        np.random.seed(args.seed * 7919 + i)
-        if i < args.start:
+        torch.manual_seed(seed * 7919 + i)
+        np.random.seed(seed * 7919 + i)
+        if i < start:
             continue
         desc = f"{c['kind']} {c['N']}x{c['H']}x{c['W']} cins {c['cins']} -> {c['cout']} k {c['k']} s {c['s']} {'f32' if c['f32'] else 'f16'} bias {c['bias']} act {c['act']} stats {c['stats']} acc {c['acc']}"
-        print(f"[{i}] BEGIN {desc}", flush=True)
+        say(f"[{i}] BEGIN {desc}", flush=True)
         try:
             msgs = run_fwd(c, rng) + run_wgrad(c, rng)
         except Exception as e:          # noqa: BLE001
             fails.append((i, desc, f"RAISED {type(e).__name__}: {str(e)[:200]}"))
-            print(f"[{i}] RAISED {desc}: {type(e).__name__}: {str(e)[:200]}", flush=True)
+            say(f"[{i}] RAISED {desc}: {type(e).__name__}: {str(e)[:200]}", flush=True)
             torch.cuda.synchronize()
             continue
         for st, what, info in msgs:
@@ -190,7 +185,20 @@ def main():
             else:
                 fails.append((i, desc, what + " " + info))
         bad = [m for m in msgs if m[0] == "FAIL"]
-        print(f"[{i}] {'FAIL' if bad else 'ok  '} {desc} | " + "; ".join(f"{w}: {inf}" for s_, w, inf in msgs if s_ != "ok" or bad)[:400], flush=True)
+        say(f"[{i}] {'FAIL' if bad else 'ok  '} {desc} | " + "; ".join(f"{w}: {inf}" for s_, w, inf in msgs if s_ != "ok" or bad)[:400], flush=True)
+    return n_ok, n_ref, fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=500)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=0.0)
+    ap.add_argument("--start", type=int, default=0)
+    args = ap.parse_args()
+    torch.set_num_threads(16)
+    t0 = time.time()
+    n_ok, n_ref, fails = run(args.n, args.seed, args.seconds, args.start)
     print(f"\n==== {n_ok} launches ok, {n_ref} refused with an argument error, {len(fails)} failed, in {time.time() - t0:.0f} s (seed {args.seed})")
     seen = set()
     for i, desc, info in fails:
