@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/keras_files/: Keras checkpoint files of small models of the reference's builder calls, in the layouts
+keras_file.py documents, through the REAL HDF5 library - plus planted.npz, the weights each file holds under their structural names.
+
+Two stages, because no interpreter of this image has everything: the system python (this package, no h5py) lays the models out -
+the Keras view of a builder graph is tests/test_keras_map.py's FakeKerasModel: auto-names with process-global counters, model.layers
+in an unrelated order, pairwise concatenates, Reshape around ConvLSTM, Flatten -> Dense -> Dense -> Reshape - and hands a JSON + npz
+to /opt/conda's python3.9 (h5py 3.3 / HDF5 1.10.6, no torch), which writes the files:
+
+    python tests/golden/make_keras_files.py
+
+NOT output of Keras (no TensorFlow in this image): the layouts are restated from the formats' documentation, so these fixtures pin
+h5lite / keras_file against the real HDF5 library and the documented layout, not against a Keras release.  Build-authored."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "keras_files")
+CONDA = "/opt/conda/bin/python3.9"
+
+CASES = [      # (file, decoder, constructor keywords, layout)
+    ("unet_lstm_ag_ds.keras", "UNet", dict(model_width=4, model_depth=2, num_channels=1, lstm=1, ag=1, ds=1), "keras_counted"),
+    ("unetpp_named.keras", "UNetPP", dict(model_width=4, model_depth=2, num_channels=3, ds=1), "keras_named_k3"),
+    ("unet_ae_tf212.keras", "UNet", dict(model_width=4, model_depth=2, num_channels=3, ae=1, feature_number=12), "keras_tf212"),
+    ("multires_legacy.h5", "MultiResUNet", dict(model_width=8, model_depth=1, num_channels=3, ag=1, alpha=1.0), "h5_model"),
+    ("unet3p_weights_only.h5", "UNet3P", dict(model_width=4, model_depth=2, num_channels=3), "h5_weights"),
+    ("unet1d.keras", "UNet1D", dict(length=64, model_depth=2, num_channel=2, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=1), "keras_counted"),
+]
+
+ONE_D = {"Conv2D": "Conv1D", "Conv2DTranspose": "Conv1DTranspose", "MaxPooling2D": "MaxPooling1D", "UpSampling2D": "UpSampling1D", "ConvLSTM2D": "ConvLSTM1D"}
+
+
+def stage1(tmp):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, os.path.dirname(HERE))
+    import segamd
+    from test_keras_map import FakeKerasModel
+    from segamd.keras_file import _snake
+    spec, arrays, planted = [], {}, {}
+    for ci, (fname, dec, kw, layout) in enumerate(CASES):
+        kw = dict(kw)
+        one_d = dec == "UNet1D"
+        if one_d:
+            g = segamd.UNet1D(**kw).graph_UNet()
+        else:
+            w, d = kw.pop("model_width"), kw.pop("model_depth")
+            g = segamd.unet_model_builder(dec, 32, 32, w, d, train_mode="from_scratch", **kw).graph()
+        fake = FakeKerasModel(g, np.random.default_rng(100 + ci))
+        layers = []
+        for l in fake.layers:
+            cls = l.__class__.__name__
+            cls = ONE_D.get(cls, cls) if one_d else cls
+            ws = l.get_weights()
+            if one_d:
+                ws = [w[0] if (w.ndim == 4 and w.shape[0] == 1) else w for w in ws]          # Conv1D kernels are (k, Cin, Cout)
+            inbound = l._inbound_nodes[0].inbound_layers if l._inbound_nodes else []
+            inbound = inbound if isinstance(inbound, list) else [inbound]
+            wkeys = []
+            for wi, w in enumerate(ws):
+                key = f"{ci}:{l.name}:{wi}"
+                arrays[key] = w
+                wkeys.append(key)
+            layers.append(dict(name=l.name, cls=cls, inbound=[x.name for x in inbound], weights=wkeys))
+        outputs = [t._keras_history.layer.name for t in fake.outputs]
+        for k, v in fake.planted.items():
+            planted[f"{fname}|{k.replace('/', '|')}"] = v
+        spec.append(dict(file=fname, layout=layout, layers=layers, outputs=outputs,
+                         snake={l["cls"]: _snake(l["cls"]) for l in layers}))
+    with open(os.path.join(tmp, "spec.json"), "w") as fh:
+        json.dump(spec, fh)
+    np.savez(os.path.join(tmp, "arrays.npz"), **arrays)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez(os.path.join(OUT, "planted.npz"), **planted)
+
+
+WEIGHT_NAMES = {"Conv": ("kernel", "bias"), "BatchNormalization": ("gamma", "beta", "moving_mean", "moving_variance"),
+                "ConvLSTM": ("kernel", "recurrent_kernel", "bias"), "Dense": ("kernel", "bias")}
+
+
+def stage2(tmp):
+    import io
+    import zipfile
+
+    import h5py
+    spec = json.load(open(os.path.join(tmp, "spec.json")))
+    arrays = np.load(os.path.join(tmp, "arrays.npz"))
+    for case in spec:
+        layers, layout = case["layers"], case["layout"]
+
+        def node(l):
+            if not l["inbound"]:
+                return []
+            if layout == "keras_named_k3":              # Keras 3 spelling
+                kts = [{"class_name": "__keras_tensor__", "config": {"shape": [None], "dtype": "float32", "keras_history": [n, 0, 0]}} for n in l["inbound"]]
+                return [{"args": [kts if len(kts) > 1 else kts[0]], "kwargs": {}}]
+            return [[[n, 0, 0, {}] for n in l["inbound"]]]
+
+        cfg_layers = [{"module": "keras.layers", "class_name": l["cls"], "config": {"name": l["name"], "trainable": True, "dtype": "float32"},
+                       "registered_name": None, "name": l["name"], "inbound_nodes": node(l)} for l in layers]
+        outs = [[n, 0, 0] for n in case["outputs"]]
+        config = {"module": "keras.src.engine.functional", "class_name": "Functional",
+                  "config": {"name": "model", "trainable": True, "layers": cfg_layers,
+                             "input_layers": [[l["name"], 0, 0] for l in layers if l["cls"] == "InputLayer"],
+                             "output_layers": outs[0] if (layout == "keras_named_k3" and len(outs) == 1) else outs},
+                  "registered_name": "Functional", "build_config": {"input_shape": None}}
+        path = os.path.join(OUT, case["file"])
+        if layout.startswith("keras"):
+            bio = io.BytesIO()
+            with h5py.File(bio, "w") as f:
+                top = "_layer_checkpoint_dependencies" if layout == "keras_tf212" else "layers"
+                f.create_group("vars")
+                used = {}
+                for l in layers:
+                    base = case["snake"][l["cls"]]
+                    if base in used:
+                        used[base] += 1
+                        counted = f"{base}_{used[base]}"
+                    else:
+                        used[base] = 0
+                        counted = base
+                    key = l["name"] if layout == "keras_named_k3" else counted
+                    g = f.create_group(f"{top}/{key}")
+                    holder = g
+                    g.create_group("vars")
+                    if l["cls"].startswith("ConvLSTM"):          # the recurrent layer keeps its variables in its cell
+                        holder = g.create_group("cell")
+                        holder.create_group("vars")
+                    for i, k in enumerate(l["weights"]):
+                        holder["vars"].create_dataset(str(i), data=arrays[k])
+                f.create_dataset("optimizer/vars/0", data=np.int64(1234))
+            with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+                z.writestr("metadata.json", json.dumps({"keras_version": "2.13.1", "date_saved": "2026-10-03@00:00:00"}))
+                z.writestr("config.json", json.dumps(config))
+                z.writestr("model.weights.h5", bio.getvalue())
+        else:
+            with h5py.File(path, "w") as f:
+                root = f
+                if layout == "h5_model":
+                    f.attrs["model_config"] = json.dumps(config)
+                    f.attrs["keras_version"] = "2.11.0"
+                    f.attrs["backend"] = "tensorflow"
+                    root = f.create_group("model_weights")
+                else:
+                    with open(os.path.join(OUT, case["file"].replace(".h5", ".config.json")), "w") as fh:
+                        json.dump(config, fh)
+                root.attrs["layer_names"] = np.array([l["name"].encode() for l in layers])
+                root.attrs["backend"] = b"tensorflow"
+                root.attrs["keras_version"] = b"2.11.0"
+                for l in layers:
+                    g = root.create_group(l["name"])
+                    fam = next((v for k, v in WEIGHT_NAMES.items() if l["cls"].startswith(k)), ())
+                    names = [f"{l['name']}/{fam[i]}:0" for i in range(len(l["weights"]))]
+                    g.attrs["weight_names"] = np.array([n.encode() for n in names]) if names else np.zeros((0,), "S1")
+                    for n, k in zip(names, l["weights"]):
+                        g.create_dataset(n, data=arrays[k])
+        print(case["file"], os.path.getsize(path), "bytes,", len(layers), "layers")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--write":
+        stage2(sys.argv[2])
+    else:
+        with tempfile.TemporaryDirectory() as tmp:
+            stage1(tmp)
+            env = {k: v for k, v in os.environ.items() if k not in ("PYTHONHOME", "PYTHONPATH")}
+            subprocess.run([CONDA, os.path.abspath(__file__), "--write", tmp], check=True, env=env)

@@ -1,0 +1,63 @@
+"""MI355X: a Keras checkpoint FILE of the reference's builder call goes into the engine without TensorFlow (SegModel.load_weights on a
+`.keras` / `.h5` path: keras_file.py + h5lite.py), runs, trains, and goes back out as a checkpoint of the same shape."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import segamd
+from ir_interp import run_graph
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, HERE)
+from make_keras_files import CASES  # noqa: E402
+
+FILES = os.path.join(HERE, "keras_files")
+PLANTED = np.load(os.path.join(FILES, "planted.npz"))
+
+
+def _model(dec, kw):
+    kw = dict(kw)
+    if dec == "UNet1D":
+        return segamd.UNet1D(**kw).UNet(), (3, kw["length"], kw["num_channel"])
+    w, d = kw.pop("model_width"), kw.pop("model_depth")
+    return segamd.unet_model_builder(dec, 32, 32, w, d, train_mode="from_scratch", **kw).ResNet50(), (3, 32, 32, kw["num_channels"])
+
+
+@pytest.mark.parametrize("fname,dec,kw,layout", CASES, ids=[c[0] for c in CASES])
+def test_checkpoint_file_runs_on_the_engine_and_goes_back_out(fname, dec, kw, layout, tmp_path):
+    model, xshape = _model(dec, kw)
+    model.build(xshape[0], dtype="f32")
+    path = os.path.join(FILES, fname)
+    cfg = open(path.replace(".h5", ".config.json")).read() if layout == "h5_weights" else None
+    model.load_weights(path, config=cfg)
+    want = {k.split("|", 1)[1].replace("|", "/"): v for k, v in PLANTED.items() if k.startswith(fname + "|")}
+    got = model.get_weights()
+    assert set(want) <= set(got)
+    for k, v in want.items():
+        assert np.array_equal(got[k].reshape(v.shape), v), k          # the fp32 master copy holds the file's numbers exactly
+    # moving variances of a random fixture are negative half of the time: make them usable before running the model
+    fixed = {k: (np.abs(v) + 0.5 if k.endswith("moving_variance") else v) for k, v in got.items()}
+    model.set_weights(fixed)
+    torch.manual_seed(3)
+    x = torch.randn(*xshape)
+    ref = run_graph(model.graph, x, {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in fixed.items()}, training=False)
+    pred = model.predict(x.numpy())
+    pred = pred if isinstance(pred, (list, tuple)) else [pred]
+    for p_, r_ in zip(pred, ref):
+        r_ = r_.detach().numpy()
+        assert np.abs(np.asarray(p_).reshape(r_.shape) - r_).max() <= 1e-3 * max(1.0, np.abs(r_).max())
+    out = str(tmp_path / ("trained_" + fname))
+    model.save_keras_file(out, like=path, config=cfg)
+    again, _ = _model(dec, kw)
+    again.build(xshape[0], dtype="f32")
+    again.load_weights(out, config=cfg)
+    back = again.get_weights()
+    assert all(np.array_equal(back[k], fixed[k].reshape(back[k].shape)) for k in fixed)

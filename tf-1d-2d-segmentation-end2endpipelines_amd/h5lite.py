@@ -15,7 +15,8 @@ links written with `libver='latest'` or `track_order=True`), the extensible / fi
 reference / array datatypes, shared (committed) datatype messages, external files, virtual datasets.
 
 Writer (`H5Writer`): superblock version 0, version-1 object headers, symbol-table groups, contiguous little-endian datasets,
-fixed-length string and numeric attributes - enough for a weights file that libhdf5 (h5py, Keras) opens.
+numeric / fixed-length string attributes, long text attributes as variable-length strings in a global heap collection - enough for a
+weights file that libhdf5 (h5py, Keras) opens.
 
 Verified against files written by the real library (h5py 3.3 / HDF5 1.10.6, `tests/golden/make_h5_files.py`) and, the other way,
 by letting that library read what `H5Writer` wrote (`tests/test_h5lite.py`).  Format facts follow the published "HDF5 File Format
@@ -684,6 +685,8 @@ class H5Writer:
             a = a.astype(np.uint8)
         parts = [p for p in path.split("/") if p]
         parent = self._find("/".join(parts[:-1]), True)
+        if parent["kind"] != "group":
+            raise H5Error(f"{path!r}: a dataset is in the way")
         if parts[-1] in parent["children"]:
             raise H5Error(f"{path!r} exists")
         parent["children"][parts[-1]] = {"kind": "dataset", "data": a.astype(a.dtype.newbyteorder("<")), "attrs": {}}
@@ -710,9 +713,20 @@ class H5Writer:
         return struct.pack("<BBBB4x", 1, len(shape), 0, 0) + b"".join(struct.pack("<Q", s) for s in shape)
 
     @classmethod
-    def _attr_msg(cls, name: str, value) -> bytes:
+    def _attr_msg(cls, name: str, value, alloc=None) -> bytes:
+        pad = lambda b: b + b"\0" * (-len(b) % 8)
+        nm = name.encode("utf-8") + b"\0"
         if isinstance(value, str):
             value = value.encode("utf-8")
+        if isinstance(value, bytes) and len(value) > 60000 and alloc is not None:
+            # more than an object-header message holds (a legacy file's model_config): a variable-length string - the text in a
+            # global heap collection of its own (exactly filled: header, object 1, no free-space object), the attribute a reference
+            n = (len(value) + 7) & ~7
+            gaddr = alloc(b"GCOL" + struct.pack("<B3xQ", 1, 32 + n) + struct.pack("<HHIQ", 1, 0, 0, len(value)) + value + b"\0" * (n - len(value)))
+            t = struct.pack("<BBBBI", 0x19, 0x01, 0x01, 0, 16) + struct.pack("<BBBBI", 0x10, 0, 0, 0, 1) + struct.pack("<HH", 0, 8)
+            sp = struct.pack("<BBBB4x", 1, 0, 0, 0)
+            return (struct.pack("<BBHHH", 1, 0, len(nm), len(t), len(sp)) + pad(nm) + pad(t) + pad(sp)
+                    + struct.pack("<IQI", len(value), gaddr, 1))
         if isinstance(value, bytes):
             a = np.array(value + b"\0", dtype=f"S{len(value) + 1}")
         elif isinstance(value, (list, tuple)) and value and isinstance(value[0], (bytes, str)):
@@ -724,12 +738,10 @@ class H5Writer:
                 raise H5Error(f"attribute {name!r}: dtype {a.dtype}")
             if a.dtype.kind != "S":
                 a = a.astype(a.dtype.newbyteorder("<"))
-        pad = lambda b: b + b"\0" * (-len(b) % 8)
-        nm = name.encode("utf-8") + b"\0"
         t, s = cls._type_msg(a.dtype), cls._space_msg(a.shape)
         body = struct.pack("<BBHHH", 1, 0, len(nm), len(t), len(s)) + pad(nm) + pad(t) + pad(s) + a.tobytes()
         if len(body) > 65000:
-            raise H5Error(f"attribute {name!r}: {len(body)} bytes (an object-header message holds 64 KB; split it as Keras does)")
+            raise H5Error(f"attribute {name!r}: {len(body)} bytes (an object-header message holds 64 KB; split the list as Keras does)")
         return body
 
     @staticmethod
@@ -750,7 +762,7 @@ class H5Writer:
             return a
 
         def emit(node) -> Tuple[int, Optional[Tuple[int, int]]]:
-            attrs = [(0x0C, self._attr_msg(k, v)) for k, v in node["attrs"].items()]
+            attrs = [(0x0C, self._attr_msg(k, v, alloc)) for k, v in node["attrs"].items()]
             if node["kind"] == "dataset":
                 a = node["data"]
                 daddr = alloc(a.tobytes()) if a.size else 0xFFFFFFFFFFFFFFFF

@@ -7,7 +7,7 @@ f1  training harness of `2DCNN/Train.py:372-415`: Keras `fit` loop semantics wit
 f2  inference / mask path of `2DCNN/Test.py:153-182`: predict, deep-supervision output 0, threshold rule
     `np.where(pred < threshold, 0, 1)` for one class, channel arg-max for several (the reference's multi-class
     branch references an undefined variable and cannot run), grey levels `mask * round(norm / classes)`.
-f3  weight files keyed by structural parameter names (.npz).
+f3  weight files keyed by structural parameter names (.npz, .safetensors); Keras checkpoint files: keras_file.py.
 """
 from __future__ import annotations
 
@@ -360,6 +360,22 @@ def predict_directory(model, image_dir: str, mask_dir: str, save_dir: Optional[s
 # ------------------------------------------------------------------------------------------------ f3: weight files
 def save_weights_npz(weights: Dict[str, np.ndarray], path: str):
     np.savez(path if path.endswith(".npz") else path + ".npz", **{k.replace("/", "|"): v for k, v in weights.items()})
+
+
+def save_weights_file(weights: Dict[str, np.ndarray], path: str):
+    """By extension: `.safetensors` (structural names as they are), anything else the .npz form."""
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import save_file
+        save_file({k: np.ascontiguousarray(v, np.float32) for k, v in weights.items()}, path, metadata={"format": "segamd structural names, Keras layouts"})
+    else:
+        save_weights_npz(weights, path)
+
+
+def load_weights_file(path: str) -> Dict[str, np.ndarray]:
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+        return dict(load_file(path))
+    return load_weights_npz(path)
 
 
 def load_weights_npz(path: str) -> Dict[str, np.ndarray]:

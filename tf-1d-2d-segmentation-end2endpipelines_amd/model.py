@@ -614,14 +614,31 @@ class SegModel:
         return out
 
     def save_weights(self, path: str):
-        """.npz keyed by structural parameter names, Keras layouts (the reference saves .keras files, Train.py:375)."""
-        from .harness import save_weights_npz
-        save_weights_npz(self.get_weights(), path)
+        """.npz (or .safetensors, by extension) keyed by structural parameter names, Keras layouts (the reference saves .keras
+        files, Train.py:375: `save_keras_file`)."""
+        from .harness import save_weights_file
+        save_weights_file(self.get_weights(), path)
 
-    def load_weights(self, path: str):
-        """model.load_weights (Train.py:363,367)."""
-        from .harness import load_weights_npz
-        self.set_weights(load_weights_npz(path))
+    def load_weights(self, path: str, config: Optional[str] = None):
+        """model.load_weights (Train.py:363,367): a weight file of this package (.npz / .safetensors) or a Keras checkpoint of the
+        reference (.keras / .h5 / .hdf5: `load_keras_file`)."""
+        if path.endswith((".keras", ".h5", ".hdf5")):
+            return self.load_keras_file(path, config)
+        from .harness import load_weights_file
+        self.set_weights(load_weights_file(path))
+
+    def load_keras_file(self, path: str, config: Optional[str] = None):
+        """Take over the weights of a Keras checkpoint FILE written by the reference for the same constructor call (`.keras` archive,
+        legacy whole-model `.h5`; a weights-only `.h5` with `config=` the text of `model.to_json()`): read without TensorFlow or
+        h5py (h5lite.py), matched layer by layer through the file's own `inbound_nodes` (keras_file.py, keras_map.py)."""
+        from .keras_file import load_keras_file
+        self.set_weights(load_keras_file(path, self.graph, config))
+
+    def save_keras_file(self, path: str, like: str, config: Optional[str] = None):
+        """This model's weights as a Keras checkpoint shaped like `like` (the checkpoint it was loaded from, or any checkpoint of
+        the same constructor call): configuration, metadata and optimiser variables are `like`'s, the layer weights this model's."""
+        from .keras_file import save_keras_file
+        save_keras_file(self.get_weights(), path, like, self.graph, config)
 
     def load_keras_model(self, keras_model):
         """Take over the weights of a tf.keras model built by the reference for the same constructor call: every Keras layer
