@@ -69,6 +69,24 @@ def _masks(p):
 
 @needs_fixture
 @pytest.mark.parametrize("path", FIXTURES or ["<none>"])
+def test_checkpoint_files_of_the_reference_read_without_tensorflow(path):
+    """tf_<case>.keras / tf_<case>.h5 beside a fixture are Keras' own files of the same weights ('w/*'): keras_file.py + h5lite.py
+    must get every array onto its structural name, bit for bit."""
+    from segamd import keras_file as KF
+    meta, _x, w, _pred, _trn = _load(path)
+    files = [path[:-4] + ext for ext in (".keras", ".h5") if os.path.exists(path[:-4] + ext)]
+    if not files:
+        pytest.skip("this fixture was captured without checkpoint files")
+    g = _engine(meta).graph
+    for f in files:
+        got = KF.load_keras_file(f, g)
+        assert set(got) == set(w), f
+        for k, v in w.items():
+            assert np.array_equal(got[k].reshape(v.shape), v), (f, k)
+
+
+@needs_fixture
+@pytest.mark.parametrize("path", FIXTURES or ["<none>"])
 def test_oracle_reproduces_the_reference(path):
     from oracle.keras_ref import Layers
     from oracle.train_ref import KerasAdam, loss_and_grads

@@ -13,7 +13,8 @@ configuration plus its HDF5 weight groups, read by `h5lite.py`), so that
 
 File layouts understood (restated from the Keras documentation / the files' own structure; NO Keras installation was available to
 produce a fixture - the test files are written by the real HDF5 library in the layout described here, `tests/golden/make_keras_files.py`,
-and a file from a real Keras run is the first thing to try on a TensorFlow machine, `tools/tf_capture_spec.py --keras-file`):
+and `tools/tf_capture_spec.py` saves `tf_<case>.keras` / `.h5` beside every fixture on a TensorFlow machine - the first real Keras
+files this reader will see, held against the captured weights by `tests/test_tf_fixture.py`):
 
   * `.keras` archive (Keras "v3" saving format, TF >= 2.12): a zip of `config.json` (the functional model: `config.layers[*]` with
     `class_name`, `name`, `inbound_nodes`; `config.output_layers`), `metadata.json` and `model.weights.h5` whose groups are

@@ -83,6 +83,13 @@ def capture(tf, kmodel, g, x, meta, keras_map, path):
     weights = keras_map.keras_weights_by_structural_name(kmodel, g)
     missing = {p.name for p in g.param_specs()} - set(weights)
     assert not missing, f"{meta['case']}: parameters without a Keras counterpart: {sorted(missing)}"
+    # the same weights as checkpoint FILES, the way the reference's ModelCheckpoint / model.save leave them (Train.py:375-379): what
+    # keras_file.py reads without TensorFlow is held against 'w/*' by tests/test_tf_fixture.py - the first REAL Keras files it sees
+    for ext in (".keras", ".h5"):
+        try:
+            kmodel.save(path[:-4] + ext)
+        except Exception as e:          # noqa: BLE001  (a Keras release without one of the formats: say so, keep going)
+            print(f"{meta['case']}: model.save('{ext}') failed: {type(e).__name__}: {e}")
     pred = kmodel.predict(x, verbose=0)
     pred = pred if isinstance(pred, list) else [pred]
     trn = kmodel(x, training=True)
