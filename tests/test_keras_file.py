@@ -148,3 +148,21 @@ def test_safetensors_weight_files_round_trip(tmp_path):
         save_weights_file(w, p)
         back = load_weights_file(p)
         assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) for k in w)
+
+
+def test_one_loader_takes_every_weight_file_by_what_it_is(tmp_path):
+    """The reference hands ONE path (`..._Fold_1.keras`) to ModelCheckpoint and to load_weights (Train.py:363-379): a Keras archive
+    at that path is read as one; what this package's save_weights wrote for that path (path + '.npz') is found under it too."""
+    from segamd import harness
+    fname, dec, kw, _layout = CASES[1]
+    g = _graph(dec, kw)
+    want = _planted(fname)
+    got = harness.load_weights_file(os.path.join(FILES, fname), g)
+    assert all(np.array_equal(got[k].reshape(v.shape), v) for k, v in want.items())
+    ckpt = str(tmp_path / "UNetPP_32_Fold_1.keras")
+    harness.save_weights_file(want, ckpt)                 # (ModelCheckpoint -> SegModel.save_weights)
+    assert not os.path.exists(ckpt) and os.path.exists(ckpt + ".npz")
+    back = harness.load_weights_file(ckpt, g)             # (the resume branch of Train.py: load_weights of the same path)
+    assert set(back) == set(want) and all(np.array_equal(back[k], want[k]) for k in want)
+    with pytest.raises(ValueError, match="needs the builder graph"):
+        harness.load_weights_file(os.path.join(FILES, fname))

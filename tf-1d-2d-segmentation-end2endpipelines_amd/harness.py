@@ -371,10 +371,21 @@ def save_weights_file(weights: Dict[str, np.ndarray], path: str):
         save_weights_npz(weights, path)
 
 
-def load_weights_file(path: str) -> Dict[str, np.ndarray]:
+def load_weights_file(path: str, graph=None, config: Optional[str] = None) -> Dict[str, np.ndarray]:
+    """{structural name: array} of a weight file, by what the file IS: `.safetensors` / `.npz` of this package, or - given the
+    builder graph - a Keras checkpoint of the reference (`.keras` archive, `.h5` / `.hdf5`: keras_file.py).  The reference's
+    training script hands ONE path to ModelCheckpoint and to `load_weights` (Train.py:363-379, `..._Fold_1.keras`): what
+    `save_weights(path)` of this package wrote for such a path is `path + '.npz'`, and is found under the path it was asked for."""
     if path.endswith(".safetensors"):
         from safetensors.numpy import load_file
         return dict(load_file(path))
+    if path.endswith((".keras", ".h5", ".hdf5")):
+        if not os.path.exists(path) and os.path.exists(path + ".npz"):
+            return load_weights_npz(path + ".npz")
+        if graph is None:
+            raise ValueError(f"{path}: a Keras checkpoint needs the builder graph to be mapped onto (SegModel.load_weights)")
+        from .keras_file import load_keras_file
+        return load_keras_file(path, graph, config)
     return load_weights_npz(path)
 
 

@@ -622,10 +622,8 @@ class SegModel:
     def load_weights(self, path: str, config: Optional[str] = None):
         """model.load_weights (Train.py:363,367): a weight file of this package (.npz / .safetensors) or a Keras checkpoint of the
         reference (.keras / .h5 / .hdf5: `load_keras_file`)."""
-        if path.endswith((".keras", ".h5", ".hdf5")):
-            return self.load_keras_file(path, config)
         from .harness import load_weights_file
-        self.set_weights(load_weights_file(path))
+        self.set_weights(load_weights_file(path, self.graph, config))
 
     def load_keras_file(self, path: str, config: Optional[str] = None):
         """Take over the weights of a Keras checkpoint FILE written by the reference for the same constructor call (`.keras` archive,
