@@ -3,8 +3,8 @@
 keras_file.py documents, through the REAL HDF5 library - plus planted.npz, the weights each file holds under their structural names.
 
 Two stages, because no interpreter of this image has everything: the system python (this package, no h5py) lays the models out -
-the Keras view of a builder graph is tests/test_keras_map.py's FakeKerasModel: auto-names with process-global counters, model.layers
-in an unrelated order, pairwise concatenates, Reshape around ConvLSTM, Flatten -> Dense -> Dense -> Reshape - and hands a JSON + npz
+the Keras view of a builder graph (`keras_view`: get_config()-style layer configurations, auto-names with process-global counters,
+model.layers in an unrelated order, pairwise concatenates, Reshape in front of ConvLSTM, Flatten -> Dense -> Dense -> Reshape) - and hands a JSON + npz
 to /opt/conda's python3.9 (h5py 3.3 / HDF5 1.10.6, no torch), which writes the files:
 
     python tests/golden/make_keras_files.py
@@ -33,14 +33,104 @@ CASES = [      # (file, decoder, constructor keywords, layout)
 ]
 
 ONE_D = {"Conv2D": "Conv1D", "Conv2DTranspose": "Conv1DTranspose", "MaxPooling2D": "MaxPooling1D", "UpSampling2D": "UpSampling1D", "ConvLSTM2D": "ConvLSTM1D"}
+AUTO = {"Conv2D": "conv2d", "Conv2DTranspose": "conv2d_transpose", "BatchNormalization": "batch_normalization", "Activation": "activation",
+        "LeakyReLU": "leaky_re_lu", "MaxPooling2D": "max_pooling2d", "UpSampling2D": "up_sampling2d", "Concatenate": "concatenate", "Add": "add",
+        "Multiply": "multiply", "ConvLSTM2D": "conv_lstm2d", "InputLayer": "input", "Reshape": "reshape", "Flatten": "flatten", "Dense": "dense"}
+
+
+def keras_view(g, rng, one_d, name_offset=17):
+    """The layers a tf.keras model of the reference has for builder graph `g`, as (name, class, get_config()-style dict, inbound
+    layer names, [(structural parameter name, array)]): process-global auto-names, pairwise-folded concatenates (Concat_Block,
+    unet_variants.py:27-32), Reshape((1, ...)) in front of every ConvLSTM (:147), Flatten -> Dense('features') -> Dense -> Reshape for
+    the autoencoder bottleneck (:41-47), separate Activation / LeakyReLU layers, heads with their explicit names."""
+    counters, layers, layer_of = {}, [], {}
+    outset = set(g.outputs)
+    sp = (lambda hw: [int(hw[1])] if one_d else [int(hw[0]), int(hw[1])])
+
+    def auto(cls):
+        i = counters.get(cls, name_offset)
+        counters[cls] = i + 1
+        base = AUTO[cls]
+        return f"{base.replace('2d', '1d') if one_d else base}_{i}"
+
+    def emit(cls, name, cfg, inbound, weights=()):
+        layers.append(dict(name=name, cls=ONE_D.get(cls, cls) if one_d else cls, config=dict(cfg, name=name), inbound=list(inbound), weights=list(weights)))
+        return name
+
+    def planted(n, params):
+        out = []
+        for p in params:
+            w = rng.standard_normal(p.shape).astype(np.float32)
+            if p.name.endswith("moving_variance"):
+                w = np.abs(w) + 0.5
+            elif len(p.shape) >= 2:
+                w = (w / np.sqrt(np.prod(p.shape[:-1]))).astype(np.float32)          # (values a trained model could have: the file runs)
+            out.append((p.name, w))
+        return out
+
+    for i in g.live_nodes():
+        n = g.nodes[i]
+        ins = [layer_of[j] for j in n.inputs]
+        a = n.attrs
+        H, W, C = n.shape
+        if n.kind == "input":
+            layer_of[i] = emit("InputLayer", "input_1", dict(batch_input_shape=[None] + sp((H, W)) + [C], dtype="float32", sparse=False), [])
+        elif n.kind in ("conv", "convT"):
+            cls = "Conv2D" if n.kind == "conv" else "Conv2DTranspose"
+            cfg = dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp(a["strides"]), padding="same", data_format="channels_last",
+                       dilation_rate=sp((1, 1)), groups=1, activation=a.get("activation") or "linear", use_bias=a.get("use_bias", True))
+            if n.kind == "convT":
+                cfg["output_padding"] = None
+            layer_of[i] = emit(cls, n.name if i in outset else auto(cls), cfg, ins, planted(n, n.params))
+        elif n.kind == "bn":
+            layer_of[i] = emit("BatchNormalization", auto("BatchNormalization"),
+                               dict(axis=[2 if one_d else 3], momentum=a["momentum"], epsilon=a["eps"], center=True, scale=True), ins, planted(n, n.params))
+        elif n.kind == "act":
+            if a["fn"] == "leaky_relu":
+                layer_of[i] = emit("LeakyReLU", auto("LeakyReLU"), dict(alpha=a["alpha"]), ins)
+            else:
+                layer_of[i] = emit("Activation", n.name if i in outset else auto("Activation"), dict(activation=a["fn"]), ins)
+        elif n.kind == "maxpool":
+            layer_of[i] = emit("MaxPooling2D", auto("MaxPooling2D"), dict(pool_size=sp(a["size"]), strides=sp(a["size"]), padding="valid"), ins)
+        elif n.kind == "upsample":
+            cfg = dict(size=sp(a["size"])[0] if one_d else sp(a["size"]))
+            if not one_d:
+                cfg["interpolation"] = a["interpolation"]
+            layer_of[i] = emit("UpSampling2D", auto("UpSampling2D"), cfg, ins)
+        elif n.kind == "concat":
+            cur = ins[0]
+            for nxt in ins[1:]:
+                cur = emit("Concatenate", auto("Concatenate"), dict(axis=-1), [cur, nxt])
+            layer_of[i] = cur
+        elif n.kind == "add":
+            layer_of[i] = emit("Add", auto("Add"), {}, ins)
+        elif n.kind == "mul":
+            layer_of[i] = emit("Multiply", auto("Multiply"), {}, ins)
+        elif n.kind == "convlstm":
+            Hi, Wi, Ci = g.nodes[n.inputs[0]].shape
+            r = emit("Reshape", auto("Reshape"), dict(target_shape=[1] + sp((Hi, Wi)) + [Ci]), ins)
+            layer_of[i] = emit("ConvLSTM2D", auto("ConvLSTM2D"),
+                               dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp((1, 1)), padding="same", dilation_rate=sp((1, 1)), activation="tanh",
+                                    recurrent_activation="hard_sigmoid", use_bias=True, return_sequences=False, go_backwards=True, stateful=False),
+                               [r], planted(n, n.params))
+        elif n.kind == "dense_ae":
+            ws = planted(n, n.params)
+            fl = emit("Flatten", auto("Flatten"), dict(data_format="channels_last"), ins)
+            d1 = emit("Dense", "features", dict(units=a["features"], activation="linear", use_bias=True), [fl], ws[0:2])
+            d2 = emit("Dense", auto("Dense"), dict(units=H * W * C, activation="linear", use_bias=True), [d1], ws[2:4])
+            layer_of[i] = emit("Reshape", auto("Reshape"), dict(target_shape=sp((H, W)) + [C]), [d2])
+        else:
+            raise ValueError(n.kind)
+    outputs = [layer_of[o] for o in g.outputs]
+    import random
+    random.Random(3).shuffle(layers)                    # model.layers is in graph-depth order, not creation order
+    return layers, outputs
 
 
 def stage1(tmp):
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    sys.path.insert(0, os.path.dirname(HERE))
     import segamd
-    from test_keras_map import FakeKerasModel
-    from segamd.keras_file import _snake
+    from segamd import keras_file
     spec, arrays, planted = [], {}, {}
     for ci, (fname, dec, kw, layout) in enumerate(CASES):
         kw = dict(kw)
@@ -50,27 +140,19 @@ def stage1(tmp):
         else:
             w, d = kw.pop("model_width"), kw.pop("model_depth")
             g = segamd.unet_model_builder(dec, 32, 32, w, d, train_mode="from_scratch", **kw).graph()
-        fake = FakeKerasModel(g, np.random.default_rng(100 + ci))
-        layers = []
-        for l in fake.layers:
-            cls = l.__class__.__name__
-            cls = ONE_D.get(cls, cls) if one_d else cls
-            ws = l.get_weights()
-            if one_d:
-                ws = [w[0] if (w.ndim == 4 and w.shape[0] == 1) else w for w in ws]          # Conv1D kernels are (k, Cin, Cout)
-            inbound = l._inbound_nodes[0].inbound_layers if l._inbound_nodes else []
-            inbound = inbound if isinstance(inbound, list) else [inbound]
-            wkeys = []
-            for wi, w in enumerate(ws):
-                key = f"{ci}:{l.name}:{wi}"
+        layers, outputs = keras_view(g, np.random.default_rng(100 + ci), one_d)
+        for l in layers:
+            keys = []
+            for wi, (pname, w) in enumerate(l["weights"]):
+                planted[f"{fname}|{pname.replace('/', '|')}"] = w
+                if one_d and w.ndim == 4 and w.shape[0] == 1:
+                    w = w[0]                            # Conv1D kernels are (k, Cin, Cout)
+                key = f"{ci}:{l['name']}:{wi}"
                 arrays[key] = w
-                wkeys.append(key)
-            layers.append(dict(name=l.name, cls=cls, inbound=[x.name for x in inbound], weights=wkeys))
-        outputs = [t._keras_history.layer.name for t in fake.outputs]
-        for k, v in fake.planted.items():
-            planted[f"{fname}|{k.replace('/', '|')}"] = v
+                keys.append(key)
+            l["weights"] = keys
         spec.append(dict(file=fname, layout=layout, layers=layers, outputs=outputs,
-                         snake={l["cls"]: _snake(l["cls"]) for l in layers}))
+                         snake={l["cls"]: keras_file._snake(l["cls"]) for l in layers}))
     with open(os.path.join(tmp, "spec.json"), "w") as fh:
         json.dump(spec, fh)
     np.savez(os.path.join(tmp, "arrays.npz"), **arrays)
@@ -100,7 +182,7 @@ def stage2(tmp):
                 return [{"args": [kts if len(kts) > 1 else kts[0]], "kwargs": {}}]
             return [[[n, 0, 0, {}] for n in l["inbound"]]]
 
-        cfg_layers = [{"module": "keras.layers", "class_name": l["cls"], "config": {"name": l["name"], "trainable": True, "dtype": "float32"},
+        cfg_layers = [{"module": "keras.layers", "class_name": l["cls"], "config": dict(l["config"], trainable=True, dtype="float32"),
                        "registered_name": None, "name": l["name"], "inbound_nodes": node(l)} for l in layers]
         outs = [[n, 0, 0] for n in case["outputs"]]
         config = {"module": "keras.src.engine.functional", "class_name": "Functional",

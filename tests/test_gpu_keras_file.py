@@ -63,3 +63,31 @@ def test_checkpoint_file_runs_on_the_engine_and_goes_back_out(fname, dec, kw, la
     again.load_weights(out, config=cfg)
     back = again.get_weights()
     assert all(np.array_equal(back[k], fixed[k].reshape(back[k].shape)) for k in fixed)
+
+
+@pytest.mark.parametrize("fname,dec,kw,layout", CASES, ids=[c[0] for c in CASES])
+def test_load_model_runs_a_checkpoint_without_the_constructor_call(fname, dec, kw, layout):
+    """tf.keras.saving.load_model + predict (2D/Test.py:114, 153): the graph comes out of the file (keras_import.py), the engine lowers
+    it like a builder's, and predict() matches the oracle run on the BUILDER's graph with the weights planted in the file."""
+    path = os.path.join(FILES, fname)
+    cfg = open(path.replace(".h5", ".config.json")).read() if layout == "h5_weights" else None
+    model = segamd.load_model(path, config=cfg)
+    assert not model.built
+    builder, xshape = _model(dec, kw)
+    want = {k.split("|", 1)[1].replace("|", "/"): torch.from_numpy(np.asarray(v, np.float32)) for k, v in PLANTED.items() if k.startswith(fname + "|")}
+    torch.manual_seed(5)
+    x = torch.randn(*xshape)
+    ref = run_graph(builder.graph, x, want, training=False)
+    pred = model.predict(x.numpy())                      # builds for this batch, takes the weights over
+    assert model.built and model._weights_at_build is None
+    pred = pred if isinstance(pred, (list, tuple)) else [pred]
+    assert len(pred) == len(ref)
+    for p_, r_ in zip(pred, ref):
+        r_ = r_.detach().numpy()
+        assert np.abs(np.asarray(p_).reshape(r_.shape) - r_).max() <= 1e-3 * max(1.0, np.abs(r_).max())
+    # ... and it trains: one step moves the loss the way the oracle's graph says (same loss value within the parity bound)
+    tg = [torch.full(tuple(r.shape), 0.5) for r in ref]
+    loss0 = float(model.train_step(x, tg if len(tg) > 1 else tg[0], "mse"))
+    o = run_graph(builder.graph, x, want, training=True)
+    want_loss = sum(float(((a - 0.5) ** 2).mean()) for a in o)
+    assert abs(loss0 - want_loss) <= 1e-3 * max(1.0, abs(want_loss))

@@ -1,0 +1,119 @@
+"""CPU: `segamd.load_model(path)` - the reference's `tf.keras.saving.load_model` (2D/Test.py:114) - rebuilds the layer graph from the
+checkpoint file alone (keras_import.py).  Held against the builder: the imported graph, run through the oracle's interpreter with the
+file's weights, gives the outputs of the builder's graph with the same weights, bit for bit - for every fixture layout."""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import segamd
+from segamd import keras_file as KF
+from segamd import keras_import as KI
+from ir_interp import run_graph
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, HERE)
+from make_keras_files import CASES  # noqa: E402
+
+FILES = os.path.join(HERE, "keras_files")
+PLANTED = np.load(os.path.join(FILES, "planted.npz"))
+
+
+def _builder_graph(dec, kw):
+    kw = dict(kw)
+    if dec == "UNet1D":
+        return segamd.UNet1D(**kw).graph_UNet()
+    w, d = kw.pop("model_width"), kw.pop("model_depth")
+    return segamd.unet_model_builder(dec, 32, 32, w, d, train_mode="from_scratch", **kw).graph()
+
+
+def _cfg(fname, layout):
+    return open(os.path.join(FILES, fname.replace(".h5", ".config.json"))).read() if layout == "h5_weights" else None
+
+
+@pytest.mark.parametrize("fname,dec,kw,layout", CASES, ids=[c[0] for c in CASES])
+def test_imported_graph_computes_what_the_builders_graph_computes(fname, dec, kw, layout):
+    kfile = KF.KerasFileModel(os.path.join(FILES, fname), _cfg(fname, layout))
+    gi = KI.graph_from_keras_config(kfile.config)
+    wi = KI.weights_of_imported_graph(kfile, gi)
+    gb = _builder_graph(dec, kw)
+    wb = {k.split("|", 1)[1].replace("|", "/"): v for k, v in PLANTED.items() if k.startswith(fname + "|")}
+    assert gi.ndim == gb.ndim and gi.nodes[gi.inputs[0]].shape == gb.nodes[gb.inputs[0]].shape
+    assert gi.count_params() == gb.count_params() and len(gi.outputs) == len(gb.outputs)
+    assert sorted(gi.nodes[i].kind for i in gi.live_nodes()) == sorted(gb.nodes[i].kind for i in gb.live_nodes())
+    assert [gi.nodes[o].shape for o in gi.outputs] == [gb.nodes[o].shape for o in gb.outputs]
+    torch.manual_seed(0)
+    H, W, C = gb.nodes[gb.inputs[0]].shape
+    x = torch.randn(2, W, C) if gb.ndim == 1 else torch.randn(2, H, W, C)
+    t = lambda w: {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in w.items()}
+    for training in (False, True):
+        a = run_graph(gi, x, t(wi), training=training)
+        b = run_graph(gb, x, t(wb), training=training)
+        for p, q in zip(a, b):
+            assert torch.equal(p, q)
+
+
+def _config_of(fname):
+    return copy.deepcopy(KF.KerasFileModel(os.path.join(FILES, fname)).config)
+
+
+def _layer(cfg, cls):
+    return next(l for l in cfg["config"]["layers"] if l["class_name"] == cls)
+
+
+@pytest.mark.parametrize("cls,key,value,says", [
+    ("Conv2D", "padding", "valid", "padding='valid'"),
+    ("Conv2D", "dilation_rate", [2, 2], "dilation_rate"),
+    ("Conv2D", "activation", "tanh", "activation 'tanh'"),
+    ("Conv2DTranspose", "output_padding", [1, 1], "output_padding"),
+    ("BatchNormalization", "axis", [1], "axis"),
+    ("MaxPooling2D", "strides", [1, 1], "strides"),
+    ("ConvLSTM2D", "recurrent_activation", "sigmoid", "hard_sigmoid"),
+    ("ConvLSTM2D", "return_sequences", True, "return_sequences"),
+    ("Reshape", "target_shape", [2, 16, 16, 2], "target_shape"),
+])
+def test_what_the_engine_would_compute_differently_is_refused_by_name(cls, key, value, says):
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    l = _layer(cfg, cls)
+    l["config"][key] = value
+    with pytest.raises(KI.KerasImportError, match=says) as e:
+        KI.graph_from_keras_config(cfg)
+    assert l["name"] in str(e.value)
+
+
+def test_layers_outside_the_hot_path_shared_layers_and_loose_dense_layers_are_refused():
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    _layer(cfg, "MaxPooling2D")["class_name"] = "AveragePooling2D"
+    with pytest.raises(KI.KerasImportError, match="AveragePooling2D is not part of the UNet-family hot path"):
+        KI.graph_from_keras_config(cfg)
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    l = _layer(cfg, "Conv2D")
+    l["inbound_nodes"] = l["inbound_nodes"] * 2
+    with pytest.raises(KI.KerasImportError, match="called 2 times"):
+        KI.graph_from_keras_config(cfg)
+    cfg = _config_of("unet_ae_tf212.keras")
+    _layer(cfg, "Flatten")["class_name"] = "Dropout"          # a Dense on an unflattened tensor
+    with pytest.raises(KI.KerasImportError, match="outside the Flatten -> Dense -> Dense -> Reshape bottleneck"):
+        KI.graph_from_keras_config(cfg)
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    cfg["class_name"] = "Sequential"
+    with pytest.raises(KI.KerasImportError, match="Sequential"):
+        KI.graph_from_keras_config(cfg)
+
+
+def test_both_spellings_of_the_input_shape_and_of_leaky_relu():
+    cfg = _config_of("unetpp_named.keras")
+    ic = _layer(cfg, "InputLayer")["config"]
+    ic["batch_shape"] = ic.pop("batch_input_shape")          # Keras 3
+    lr = _layer(cfg, "LeakyReLU")["config"]
+    lr["negative_slope"] = lr.pop("alpha")
+    g = KI.graph_from_keras_config(cfg)
+    assert g.nodes[g.inputs[0]].shape == (32, 32, 3)
+    assert any(n.kind == "act" and n.attrs["fn"] == "leaky_relu" and abs(n.attrs["alpha"] - 0.3) < 1e-7 for n in g.nodes)
+    ic["batch_shape"] = [None, None, None, 3]
+    with pytest.raises(KI.KerasImportError, match="fixed"):
+        KI.graph_from_keras_config(cfg)

@@ -13,6 +13,8 @@ from .builders1d import UNet as UNet1D
 from . import harness
 from . import data
 from . import keras_map
+from . import h5lite, keras_file, keras_import
+from .keras_import import load_model
 from .data import CustomDataGenerator, prepare_train_dict, create_patches, patchify, unpatchify
 from .harness import (EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, fit, masks_from_predictions, mask_grey_levels,
                       predict_directory)
@@ -20,5 +22,5 @@ from .harness import (EarlyStopping, ModelCheckpoint, ReduceLROnPlateau, fit, ma
 __all__ = ["Graph", "Node", "ParamSpec", "Sym", "unet_model_builder", "model_selector", "ENCODER_METHODS",
            "SUPPORTED_DECODERS", "builders1d", "BCDUNet", "UNet1D", "harness", "EarlyStopping", "ModelCheckpoint",
            "ReduceLROnPlateau", "fit", "masks_from_predictions", "mask_grey_levels", "predict_directory", "data",
-           "CustomDataGenerator", "prepare_train_dict", "create_patches", "patchify", "unpatchify", "keras_map"]
+           "CustomDataGenerator", "prepare_train_dict", "create_patches", "patchify", "unpatchify", "keras_map", "keras_file", "keras_import", "h5lite", "load_model"]
 __version__ = "0.1.0"

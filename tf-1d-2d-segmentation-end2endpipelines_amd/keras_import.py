@@ -1,0 +1,271 @@
+"""`load_model(path)`: a Keras checkpoint of the reference -> a SegModel, from the FILE alone.
+
+The reference's test script does not call the builder again: it rebuilds the network from the checkpoint,
+`tf.keras.saving.load_model('..._Fold_1.keras')` (`2D/Test.py:114`), and predicts.  The equivalent here reads the functional
+model's JSON configuration (the `.keras` archive's `config.json`, a legacy `.h5` file's `model_config`), turns every layer into the
+node the builders of this package would have emitted for it, and takes the weights over - no constructor arguments, no TensorFlow:
+
+    model = segamd.load_model("Results/UNet/Fold_1/UNet_256_Fold_1.keras")     # == tf.keras.saving.load_model(...)
+    pred = model.predict(images)                                                # builds itself for the batch on first use
+
+Layers understood - the ones the UNet-family builders of the reference emit (`2D/models/unet_variants.py`, `1D/Models/
+unet_variants.py`, `BCDUNet.py`): InputLayer; Conv1D/2D and Conv1D/2DTranspose with padding='same', no dilation; BatchNormalization
+over the channel axis; Activation / ReLU / LeakyReLU / Softmax; MaxPooling (stride = pool size); UpSampling (nearest / bilinear);
+Concatenate over channels (nested concatenates are flattened - `Concat_Block` folds pairwise); Add; Multiply; ConvLSTM1D/2D on a
+length-1 sequence (the Reshape in front of it is absorbed); Flatten -> Dense -> Dense -> Reshape as the autoencoder bottleneck;
+Dropout-family layers and shape-preserving Reshapes as identity (inference semantics: the engine has no dropout, and says so).
+Anything else - 'valid' padding, dilation, a Dense that is not part of that bottleneck, Lambda, shared layers, nested models - raises
+KerasImportError naming the layer: a model the engine would compute differently is refused, not approximated.
+
+Node names are the Keras layer names (`conv2d_17/kernel`), so `get_weights()` of an imported model is keyed the way the file is.
+The configuration keys are restated from the Keras layer documentation (`get_config()`); like keras_file.py this has met no file
+written by Keras itself yet (`tools/tf_capture_spec.py` saves them on a TensorFlow machine)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .graph import Graph, Sym
+from .keras_file import KerasFileError, KerasFileModel, _refs
+
+
+class KerasImportError(ValueError):
+    pass
+
+
+_ACTS = {"relu": "relu", "sigmoid": "sigmoid", "softmax": "softmax", "linear": None, None: None, "leaky_relu": "leaky_relu"}
+
+
+def _act_name(v, layer):
+    if isinstance(v, dict):                              # a serialised activation object ({"class_name": ..., "config": ...})
+        v = (v.get("config") or {}).get("name") or v.get("class_name")
+        v = v.lower() if isinstance(v, str) else v
+    if v not in _ACTS:
+        raise KerasImportError(f"layer {layer!r}: activation {v!r} is not one the hot path has (relu, leaky_relu, sigmoid, softmax, linear)")
+    return _ACTS[v]
+
+
+def _ints(v, n) -> Tuple[int, ...]:
+    if isinstance(v, (list, tuple)):
+        if len(v) != n:
+            raise KerasImportError(f"expected {n} values, got {v}")
+        return tuple(int(x) for x in v)
+    return (int(v),) * n
+
+
+def graph_from_keras_config(cfg: dict) -> Graph:
+    """The builder graph of a serialised functional Keras model (module docstring)."""
+    if cfg.get("class_name") not in ("Functional", "Model"):
+        raise KerasImportError(f"a {cfg.get('class_name')} model (the reference builds functional models)")
+    body = cfg["config"]
+    layers = {(lc.get("name") or lc["config"]["name"]): lc for lc in body["layers"]}
+    ins_of: Dict[str, List[str]] = {}
+    for name, lc in layers.items():
+        nodes = lc.get("inbound_nodes", [])
+        if len(nodes) > 1:
+            raise KerasImportError(f"layer {name!r} is called {len(nodes)} times (shared layers are not part of the hot path)")
+        ins_of[name] = _refs(nodes[0]) if nodes else []
+    inputs = [n for n, lc in layers.items() if lc["class_name"] == "InputLayer"]
+    if len(inputs) != 1:
+        raise KerasImportError(f"{len(inputs)} input layers (the reference's models have one)")
+    icfg = layers[inputs[0]]["config"]
+    ishape = icfg.get("batch_input_shape") or icfg.get("batch_shape") or ([None] + list(icfg.get("shape") or []))
+    spatial = [d for d in ishape[1:]]
+    if any(d is None for d in spatial) or len(spatial) not in (2, 3):
+        raise KerasImportError(f"input shape {ishape}: a fixed (H, W, C) or (L, C) is needed")
+    ndim = len(spatial) - 1
+    g = Graph(ndim=ndim, name=body.get("name", "model"))
+    sym: Dict[str, Sym] = {}
+    flat_shape: Dict[str, Tuple[int, ...]] = {}           # Keras-side shapes of layers that have no node of their own (Flatten, Dense)
+
+    def need(cond, layer, what):
+        if not cond:
+            raise KerasImportError(f"layer {layer!r} ({layers[layer]['class_name']}): {what}")
+
+    def same_padding(c, name):
+        need(str(c.get("padding", "valid")).lower() == "same", name, f"padding={c.get('padding')!r} (the hot path is padding='same')")
+        need(all(d == 1 for d in _ints(c.get("dilation_rate", 1), ndim)), name, f"dilation_rate={c.get('dilation_rate')}")
+        need(c.get("data_format") in (None, "channels_last"), name, f"data_format={c.get('data_format')!r}")
+        need(int(c.get("groups", 1) or 1) == 1, name, f"groups={c.get('groups')}")
+
+    def build(name: str) -> Sym:
+        """The node for layer `name`; its inputs are there already (topological order below)."""
+        lc = layers[name]
+        cls, c = lc["class_name"], lc["config"]
+        srcs = ins_of[name]
+        xs = [sym[s] for s in srcs]
+        k1 = (lambda v: _ints(v, ndim) if ndim == 2 else _ints(v, 1)[0])
+        out: Optional[Sym]
+        if cls == "InputLayer":
+            out = g.input(*(spatial if ndim == 2 else [1] + spatial), name=name)
+        elif cls in ("Conv1D", "Conv2D"):
+            need(cls == f"Conv{ndim}D", name, f"in a {ndim}-D model")
+            same_padding(c, name)
+            out = g.conv(xs[0], int(c["filters"]), k1(c["kernel_size"]), name, strides=k1(c.get("strides", 1)),
+                         use_bias=bool(c.get("use_bias", True)), activation=_act_name(c.get("activation"), name))
+        elif cls in ("Conv1DTranspose", "Conv2DTranspose"):
+            same_padding(c, name)
+            need(c.get("output_padding") is None, name, f"output_padding={c.get('output_padding')}")
+            need(bool(c.get("use_bias", True)), name, "use_bias=False")
+            need(_act_name(c.get("activation"), name) is None, name, f"activation={c.get('activation')!r} (the reference's transposed convs are linear)")
+            out = g.conv_transpose(xs[0], int(c["filters"]), k1(c["kernel_size"]), k1(c.get("strides", 1)), name)
+        elif cls == "BatchNormalization":
+            axis = c.get("axis", -1)
+            axis = axis[0] if isinstance(axis, (list, tuple)) else axis
+            need(axis in (-1, ndim + 1), name, f"axis={c.get('axis')} (channels last)")
+            need(bool(c.get("center", True)) and bool(c.get("scale", True)), name, "center / scale switched off")
+            out = g.bn(xs[0], name, eps=float(c.get("epsilon", 1e-3)), momentum=float(c.get("momentum", 0.99)))
+        elif cls == "Activation":
+            a = _act_name(c.get("activation"), name)
+            out = xs[0] if a is None else g.act(xs[0], a, name)
+        elif cls == "ReLU":
+            need(c.get("max_value") is None and float(c.get("threshold", 0.0) or 0.0) == 0.0, name, "max_value / threshold")
+            slope = float(c.get("negative_slope", 0.0) or 0.0)
+            out = g.act(xs[0], "relu", name) if slope == 0.0 else g.act(xs[0], "leaky_relu", name, alpha=slope)
+        elif cls == "LeakyReLU":
+            slope = c.get("negative_slope", c.get("alpha", 0.3))
+            out = g.act(xs[0], "leaky_relu", name, alpha=float(slope))
+        elif cls == "Softmax":
+            need(c.get("axis", -1) in (-1, ndim + 1), name, f"axis={c.get('axis')}")
+            out = g.act(xs[0], "softmax", name)
+        elif cls in ("MaxPooling1D", "MaxPooling2D", "MaxPool1D", "MaxPool2D"):
+            size = k1(c.get("pool_size", 2))
+            need(c.get("strides") is None or k1(c["strides"]) == size, name, f"strides={c.get('strides')} != pool_size={c.get('pool_size')}")
+            H, W, _C = xs[0].shape
+            ph, pw = (size if ndim == 2 else (1, size))
+            need(str(c.get("padding", "valid")).lower() == "valid" or (H % ph == 0 and W % pw == 0), name, "padding='same' on an extent the pool does not divide")
+            out = g.maxpool(xs[0], size, name)
+        elif cls in ("UpSampling1D", "UpSampling2D"):
+            interp = str(c.get("interpolation", "nearest")).lower()
+            need(interp in ("nearest", "bilinear"), name, f"interpolation={interp!r}")
+            out = g.upsample(xs[0], k1(c.get("size", 2)), name, interpolation=interp)
+        elif cls == "Concatenate":
+            need(c.get("axis", -1) in (-1, ndim + 1), name, f"axis={c.get('axis')} (channels)")
+            parts: List[Sym] = []
+            for s, x in zip(srcs, xs):                   # concatenate([concatenate([a, b]), c]) == concatenate([a, b, c])
+                parts += [Sym(g, j) for j in x.node.inputs] if x.node.kind == "concat" else [x]
+            out = g.concat(parts, name)
+        elif cls == "Add":
+            out = g.add(xs, name)
+        elif cls == "Multiply":
+            need(len(xs) == 2, name, f"{len(xs)} factors")
+            a, b = xs
+            if a.shape[2] == 1 and b.shape[2] != 1:      # (the one-channel gate is the second operand of Graph.mul)
+                a, b = b, a
+            out = g.mul(a, b, name)
+        elif cls in ("ConvLSTM1D", "ConvLSTM2D"):
+            same_padding(c, name)
+            need(not c.get("return_sequences", False) and not c.get("stateful", False), name, "return_sequences / stateful")
+            need(all(s == 1 for s in _ints(c.get("strides", 1), ndim)), name, f"strides={c.get('strides')}")
+            # (go_backwards=True, as the reference passes it, is the identity on a length-1 sequence; the gates are Keras 2's
+            # defaults - tanh and HARD sigmoid, what the kernels compute: a file that says 'sigmoid' (Keras 3's default) is refused)
+            need(str(c.get("activation", "tanh")) == "tanh" and str(c.get("recurrent_activation", "hard_sigmoid")) == "hard_sigmoid",
+                 name, f"activation={c.get('activation')!r} / recurrent_activation={c.get('recurrent_activation')!r} (the engine's gates are tanh / hard_sigmoid)")
+            need((flat_shape.get(srcs[0]) or (0,))[0] == 1, name, "its input is not a length-1 sequence (Reshape((1, ...)) in front of it)")
+            out = g.convlstm(xs[0], int(c["filters"]), k1(c["kernel_size"]), name)
+        elif cls in ("Dropout", "SpatialDropout1D", "SpatialDropout2D", "Identity"):
+            out = xs[0]
+        elif cls == "Flatten":
+            H, W, C = xs[0].shape
+            flat_shape[name] = (H * W * C,)
+            out = xs[0]
+        elif cls == "Dense":
+            need(srcs[0] in flat_shape and len(flat_shape[srcs[0]]) == 1, name, "a Dense layer outside the Flatten -> Dense -> Dense -> Reshape bottleneck")
+            need(_act_name(c.get("activation"), name) is None and bool(c.get("use_bias", True)), name, "activation / use_bias (the bottleneck's Dense layers are linear with bias)")
+            flat_shape[name] = (int(c["units"]),)
+            out = xs[0]
+        elif cls == "Reshape":
+            target = tuple(int(d) for d in c["target_shape"])
+            src_cls = layers[srcs[0]]["class_name"]
+            if src_cls == "Dense":                       # ... -> Reshape closes the bottleneck
+                d2, d1 = srcs[0], ins_of[srcs[0]][0]
+                need(layers[d1]["class_name"] == "Dense" and layers[ins_of[d1][0]]["class_name"] == "Flatten", name,
+                     "Reshape of a Dense output that is not Flatten -> Dense -> Dense -> Reshape")
+                H, W, _C = xs[0].shape
+                full = target if ndim == 2 else (1,) + target
+                need(len(full) == 3 and full[:2] == (H, W) and flat_shape[d2][0] == full[0] * full[1] * full[2], name,
+                     f"target_shape={target} against the flattened tensor {xs[0].shape}")
+                out = g.dense_ae(xs[0], flat_shape[d1][0], full[2], name)
+                out.node.attrs["keras_dense"] = (d1, d2)
+            else:
+                shp = xs[0].shape if ndim == 2 else xs[0].shape[1:]
+                need(target in (tuple(shp), (1,) + tuple(shp)), name, f"target_shape={target} of a tensor {tuple(shp)} (only the length-1 sequence axis in front of a ConvLSTM)")
+                flat_shape[name] = target if len(target) == len(shp) + 1 else ()
+                out = xs[0]
+        else:
+            raise KerasImportError(f"layer {name!r}: class {cls} is not part of the UNet-family hot path")
+        if cls not in ("Reshape",) and name not in flat_shape:
+            flat_shape[name] = ()
+        sym[name] = out
+        return out
+
+    try:
+        out_names = _refs(body["output_layers"])
+        order, state, stack = [], {}, [(n, 0) for n in reversed(out_names)]          # iterative depth-first post-order from the outputs
+        while stack:
+            n, i = stack.pop()
+            if state.get(n) == 2:
+                continue
+            if i < len(ins_of[n]):
+                stack.append((n, i + 1))
+                m = ins_of[n][i]
+                if state.get(m) == 1:
+                    raise KerasImportError(f"the layer graph has a cycle through {m!r}")
+                if state.get(m) is None:
+                    state[m] = 1
+                    stack.append((m, 0))
+                state[n] = 1
+            else:
+                state[n] = 2
+                order.append(n)
+        for n in order:
+            build(n)
+    except KeyError as e:
+        raise KerasImportError(f"the configuration names a layer or key that is not there: {e}") from None
+    g.set_outputs([sym[n] for n in out_names], out_names)
+    return g
+
+
+_SLOTS = {"conv": 2, "convT": 2, "bn": 4, "convlstm": 3}
+
+
+def weights_of_imported_graph(kfile: KerasFileModel, g: Graph) -> Dict[str, np.ndarray]:
+    """{parameter name: array}: node names ARE the Keras layer names here, so every weight-bearing node takes its layer's
+    `get_weights()` in Keras' order (kernel, bias / gamma, beta, moving_mean, moving_variance / kernel, recurrent_kernel, bias);
+    the bottleneck node takes its two Dense layers'."""
+    by_name = {l.name: l for l in kfile.layers}
+    out = {}
+    for i in g.live_nodes():
+        n = g.nodes[i]
+        if not n.params:
+            continue
+        if n.kind == "dense_ae":
+            d1, d2 = n.attrs["keras_dense"]
+            ws = by_name[d1].get_weights() + by_name[d2].get_weights()
+        else:
+            ws = by_name[n.name].get_weights()
+        if len(ws) != len(n.params):
+            raise KerasImportError(f"layer {n.name!r}: {len(ws)} arrays in the file for {[p.name for p in n.params]}")
+        for p, w in zip(n.params, ws):
+            w = np.asarray(w, np.float32)
+            want = tuple(p.shape)
+            if w.shape != want and g.ndim == 1 and (1,) + tuple(w.shape) == want:
+                w = w[None]                               # Conv1D kernel (k, Cin, Cout) -> the H = 1 convention
+            if tuple(w.shape) != want:
+                raise KerasImportError(f"{p.name}: the file holds {w.shape}, the layer's configuration implies {want}")
+            out[p.name] = w
+    return out
+
+
+def load_model(path: str, config: Optional[str] = None, batch_size: Optional[int] = None, dtype: str = "f32"):
+    """tf.keras.saving.load_model (2D/Test.py:114): the SegModel of a Keras checkpoint file, weights taken over when it is built
+    (`batch_size=` builds it right away; otherwise `predict` / `build` do)."""
+    from .model import SegModel
+    kfile = KerasFileModel(path, config)
+    g = graph_from_keras_config(kfile.config)
+    model = SegModel(g, dtype=dtype)
+    model._weights_at_build = weights_of_imported_graph(kfile, g)
+    if batch_size is not None:
+        model.build(batch_size, dtype=dtype)
+    return model

@@ -489,6 +489,10 @@ class SegModel:
             self.side_stream = torch.cuda.Stream()
         self.built = True
         self._init_optimizer_state()
+        w0 = getattr(self, "_weights_at_build", None)          # keras_import.load_model: the checkpoint's weights, taken over once
+        if w0 is not None and not _DryRun.on:
+            self.set_weights(w0)
+            self._weights_at_build = None
         return self
 
     def _fuse_bn_tail(self, bop: "BNOp", n: Node, cons):
