@@ -91,3 +91,27 @@ def test_load_model_runs_a_checkpoint_without_the_constructor_call(fname, dec, k
     o = run_graph(builder.graph, x, want, training=True)
     want_loss = sum(float(((a - 0.5) ** 2).mean()) for a in o)
     assert abs(loss0 - want_loss) <= 1e-3 * max(1.0, abs(want_loss))
+
+
+def test_checkpoint_written_here_reloads_without_the_constructor_call(tmp_path):
+    """ModelCheckpoint('x.keras') on this side, then Test.py's load_model + predict: the same predictions."""
+    fname, dec, kw, _layout = CASES[0]
+    model, xshape = _model(dec, kw)
+    model.build(xshape[0], dtype="f32")
+    torch.manual_seed(7)
+    x = torch.randn(*xshape)
+    tg = [torch.full((xshape[0],) + tuple(model.graph.nodes[o].shape), 0.5) for o in model.graph.outputs]
+    for _ in range(3):
+        model.train_step(x, tg, "mse")
+    path = str(tmp_path / "UNet_32_Fold_1.keras")
+    model.save_weights(path)
+    want = model.predict(x.numpy())
+    again = segamd.load_model(path)
+    got = again.predict(x.numpy())
+    for a, b in zip(want, got):
+        assert np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-6
+    fresh, _ = _model(dec, kw)
+    fresh.build(xshape[0], dtype="f32")
+    fresh.load_weights(path)
+    w0, w1 = model.get_weights(), fresh.get_weights()
+    assert all(np.array_equal(w0[k], w1[k]) for k in w0)

@@ -117,3 +117,48 @@ def test_both_spellings_of_the_input_shape_and_of_leaky_relu():
     ic["batch_shape"] = [None, None, None, 3]
     with pytest.raises(KI.KerasImportError, match="fixed"):
         KI.graph_from_keras_config(cfg)
+
+
+BUILDS = [
+    ("UNet", dict(model_width=4, model_depth=2, num_channels=1, lstm=1, ag=1, ds=1)),
+    ("UNetPP", dict(model_width=4, model_depth=3, num_channels=3, ds=1)),
+    ("UNet", dict(model_width=4, model_depth=2, num_channels=3, ae=1, feature_number=12, is_transconv=False)),
+    ("MultiResUNet", dict(model_width=8, model_depth=2, num_channels=3, ag=1, alpha=1.0)),
+    ("UNet3P", dict(model_width=4, model_depth=2, num_channels=3, output_nums=3, final_activation="softmax")),
+    ("UNetE", dict(model_width=4, model_depth=2, num_channels=2)),
+    ("UNet1D", dict(length=64, model_depth=2, num_channel=2, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=1, lstm=1, ag=1)),
+    ("UNet1D", dict(length=64, model_depth=2, num_channel=1, model_width=4, kernel_size=5, problem_type="Classification", output_nums=3, ae=1, feature_number=6)),
+]
+
+
+@pytest.mark.parametrize("dec,kw", BUILDS, ids=[f"{d}-{i}" for i, (d, _k) in enumerate(BUILDS)])
+def test_a_model_saved_as_keras_archive_comes_back_from_the_file_alone(dec, kw, tmp_path):
+    """ModelCheckpoint('x.keras') on this side (SegModel.save_weights -> keras_import.save_model), then the Test.py flow:
+    load_model(path) without the constructor call - same outputs - and load_weights(path) into a freshly built constructor call."""
+    from segamd import harness
+    g = _builder_graph(dec, kw)
+    rng = np.random.default_rng(2)
+    w = {}
+    for p in g.param_specs():
+        v = rng.standard_normal(p.shape).astype(np.float32)
+        w[p.name] = (np.abs(v) + 0.5 if p.name.endswith("moving_variance") else v / np.sqrt(np.prod(p.shape[:-1])) if len(p.shape) >= 2 else v).astype(np.float32)
+    path = str(tmp_path / "UNet_32_Fold_1.keras")
+    harness.save_weights_file(w, path, g)
+    # 1. the archive alone -> graph + weights -> same numbers as the builder's graph
+    kfile = KF.KerasFileModel(path)
+    gi = KI.graph_from_keras_config(kfile.config)
+    wi = KI.weights_of_imported_graph(kfile, gi)
+    assert gi.count_params() == g.count_params()
+    torch.manual_seed(1)
+    H, W, C = g.nodes[g.inputs[0]].shape
+    x = torch.randn(2, W, C) if g.ndim == 1 else torch.randn(2, H, W, C)
+    t = lambda d: {k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in d.items()}
+    for p_, q_ in zip(run_graph(gi, x, t(wi), training=True), run_graph(g, x, t(w), training=True)):
+        assert torch.equal(p_, q_)
+    # 2. the same file through the constructor-call route (resume branch of Train.py): structural names, bit for bit
+    back = harness.load_weights_file(path, g)
+    assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) for k in w)
+    # 3. the configuration is plain JSON in Keras 2's spelling: no '/' in layer names, every layer has the keys load_model needs
+    cfg = kfile.config
+    assert all("/" not in l["name"] and l["config"]["name"] == l["name"] for l in cfg["config"]["layers"])
+    assert json.loads(json.dumps(cfg)) == cfg

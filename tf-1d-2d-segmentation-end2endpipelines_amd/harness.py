@@ -362,9 +362,14 @@ def save_weights_npz(weights: Dict[str, np.ndarray], path: str):
     np.savez(path if path.endswith(".npz") else path + ".npz", **{k.replace("/", "|"): v for k, v in weights.items()})
 
 
-def save_weights_file(weights: Dict[str, np.ndarray], path: str):
-    """By extension: `.safetensors` (structural names as they are), anything else the .npz form."""
-    if path.endswith(".safetensors"):
+def save_weights_file(weights: Dict[str, np.ndarray], path: str, graph=None):
+    """By extension: `.safetensors` (structural names as they are); `.keras` - what the reference's ModelCheckpoint is given
+    (Train.py:375) - a Keras-layout archive of the builder graph and the weights (keras_import.save_model; needs `graph`); anything
+    else the .npz form."""
+    if path.endswith(".keras") and graph is not None:
+        from .keras_import import save_model
+        save_model(graph, weights, path)
+    elif path.endswith(".safetensors"):
         from safetensors.numpy import save_file
         save_file({k: np.ascontiguousarray(v, np.float32) for k, v in weights.items()}, path, metadata={"format": "segamd structural names, Keras layouts"})
     else:

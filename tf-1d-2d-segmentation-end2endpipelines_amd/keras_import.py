@@ -269,3 +269,103 @@ def load_model(path: str, config: Optional[str] = None, batch_size: Optional[int
     if batch_size is not None:
         model.build(batch_size, dtype=dtype)
     return model
+
+
+# ------------------------------------------------------------------------------------------------------------------ the way out
+def _lname(s: str) -> str:
+    return s.replace("/", ".")                            # (Keras 3 refuses '/' in layer names)
+
+
+def config_from_graph(g: Graph) -> Tuple[dict, List[Tuple[str, str, List[str]]]]:
+    """(functional-model configuration, [(Keras layer name, sub-object holding its variables or "", [parameter names in Keras' order])])
+    for a layer graph of this package: the inverse of `graph_from_keras_config`, in Keras 2's spelling (`batch_input_shape`, nested-list
+    `inbound_nodes`, `alpha`).  A ConvLSTM gets its Reshape((1, ...)) in front, the bottleneck its Flatten -> Dense -> Dense -> Reshape."""
+    one_d = g.ndim == 1
+    D = "1D" if one_d else "2D"
+    sp = (lambda hw: [int(hw[1])] if one_d else [int(hw[0]), int(hw[1])])
+    layers, holders, lname = [], [], {}
+
+    def emit(cls, name, cfg, inbound, params=(), sub=""):
+        layers.append({"module": "keras.layers", "class_name": cls, "config": dict(cfg, name=name, trainable=True, dtype="float32"),
+                       "registered_name": None, "name": name, "inbound_nodes": [[[n, 0, 0, {}] for n in inbound]] if inbound else []})
+        if params:
+            holders.append((name, sub, [p.name for p in params]))
+        return name
+
+    for i in g.live_nodes():
+        n = g.nodes[i]
+        a, nm = n.attrs, _lname(n.name)
+        ins = [lname[j] for j in n.inputs]
+        H, W, C = n.shape
+        if n.kind == "input":
+            lname[i] = emit("InputLayer", nm, dict(batch_input_shape=[None] + sp((H, W)) + [C], sparse=False, ragged=False), [])
+        elif n.kind in ("conv", "convT"):
+            cfg = dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp(a["strides"]), padding="same", data_format="channels_last",
+                       dilation_rate=sp((1, 1)), groups=1, activation=a.get("activation") or "linear", use_bias=bool(a.get("use_bias", True)))
+            if n.kind == "convT":
+                cfg["output_padding"] = None
+            lname[i] = emit(f"Conv{D}" + ("Transpose" if n.kind == "convT" else ""), nm, cfg, ins, n.params)
+        elif n.kind == "bn":
+            lname[i] = emit("BatchNormalization", nm, dict(axis=[2 if one_d else 3], momentum=float(a["momentum"]), epsilon=float(a["eps"]), center=True, scale=True),
+                            ins, n.params)
+        elif n.kind == "act":
+            lname[i] = (emit("LeakyReLU", nm, dict(alpha=float(a["alpha"])), ins) if a["fn"] == "leaky_relu"
+                        else emit("Activation", nm, dict(activation=a["fn"]), ins))
+        elif n.kind == "maxpool":
+            lname[i] = emit(f"MaxPooling{D}", nm, dict(pool_size=sp(a["size"]), strides=sp(a["size"]), padding="valid", data_format="channels_last"), ins)
+        elif n.kind == "upsample":
+            cfg = dict(size=sp(a["size"])[0]) if one_d else dict(size=sp(a["size"]), data_format="channels_last", interpolation=a["interpolation"])
+            lname[i] = emit(f"UpSampling{D}", nm, cfg, ins)
+        elif n.kind == "concat":
+            lname[i] = emit("Concatenate", nm, dict(axis=-1), ins)
+        elif n.kind == "add":
+            lname[i] = emit("Add", nm, {}, ins)
+        elif n.kind == "mul":
+            lname[i] = emit("Multiply", nm, {}, ins)
+        elif n.kind == "convlstm":
+            Hi, Wi, Ci = g.nodes[n.inputs[0]].shape
+            r = emit("Reshape", nm + ".sequence", dict(target_shape=[1] + sp((Hi, Wi)) + [Ci]), ins)
+            lname[i] = emit(f"ConvLSTM{D}", nm, dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp((1, 1)), padding="same", data_format="channels_last",
+                                                      dilation_rate=sp((1, 1)), activation="tanh", recurrent_activation="hard_sigmoid", use_bias=True,
+                                                      unit_forget_bias=True, return_sequences=False, go_backwards=True, stateful=False), [r], n.params, "cell")
+        elif n.kind == "dense_ae":
+            fl = emit("Flatten", nm + ".flatten", dict(data_format="channels_last"), ins)
+            d1 = emit("Dense", nm + ".features", dict(units=int(a["features"]), activation="linear", use_bias=True), [fl], n.params[0:2])
+            d2 = emit("Dense", nm + ".expand", dict(units=H * W * C, activation="linear", use_bias=True), [d1], n.params[2:4])
+            lname[i] = emit("Reshape", nm, dict(target_shape=sp((H, W)) + [C]), [d2])
+        else:
+            raise KerasImportError(f"node {n.name!r}: kind {n.kind} has no Keras layer")
+    cfg = {"module": "keras.src.engine.functional", "class_name": "Functional",
+           "config": {"name": g.name, "trainable": True, "layers": layers,
+                      "input_layers": [[lname[i], 0, 0] for i in g.inputs], "output_layers": [[lname[o], 0, 0] for o in g.outputs]},
+           "registered_name": "Functional", "build_config": {"input_shape": [None] + sp(g.nodes[g.inputs[0]].shape[:2]) + [g.nodes[g.inputs[0]].shape[2]]}}
+    return cfg, holders
+
+
+def save_model(graph: Graph, weights: Dict[str, np.ndarray], path: str):
+    """model.save('x.keras') / ModelCheckpoint (2D/Train.py:375): a `.keras`-layout archive - config.json in Keras 2's spelling,
+    metadata.json, model.weights.h5 with `layers/<layer name>/vars/<i>` (a ConvLSTM's under `cell/`) - of a layer graph and its weights
+    (structural names).  `segamd.load_model` / `SegModel.load_weights` read it back; laid out as Keras documents the format, not yet
+    opened by a Keras installation (none here)."""
+    import json
+    import zipfile
+    from .h5lite import H5Writer
+    cfg, holders = config_from_graph(graph)
+    w = H5Writer()
+    w.create_group("vars")
+    for lc in cfg["config"]["layers"]:
+        w.create_group(f"layers/{lc['name']}/vars")
+    for lname, sub, pnames in holders:
+        base = f"layers/{lname}/{sub + '/' if sub else ''}vars"
+        w.create_group(base)
+        for i, pn in enumerate(pnames):
+            if pn not in weights:
+                raise KerasImportError(f"no value for parameter {pn!r}")
+            a = np.asarray(weights[pn], np.float32)
+            if graph.ndim == 1 and a.ndim == 4 and a.shape[0] == 1:
+                a = a[0]                                  # Conv1D / ConvLSTM1D kernels are (k, Cin, Cout)
+            w.create_dataset(f"{base}/{i}", a)
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        z.writestr("metadata.json", json.dumps({"keras_version": "2.15.0", "date_saved": "", "written_by": "segamd.keras_import.save_model"}))
+        z.writestr("config.json", json.dumps(cfg))
+        z.writestr("model.weights.h5", w.tobytes())

@@ -618,10 +618,11 @@ class SegModel:
         return out
 
     def save_weights(self, path: str):
-        """.npz (or .safetensors, by extension) keyed by structural parameter names, Keras layouts (the reference saves .keras
-        files, Train.py:375: `save_keras_file`)."""
+        """By extension: `.keras` - what the reference's ModelCheckpoint writes (Train.py:375) - a Keras-layout archive of this model
+        (graph + weights: `segamd.load_model(path)` rebuilds it from the file alone; `save_keras_file(path, like=)` instead fills
+        an existing Keras checkpoint); `.safetensors` / `.npz` keyed by structural parameter names, Keras layouts."""
         from .harness import save_weights_file
-        save_weights_file(self.get_weights(), path)
+        save_weights_file(self.get_weights(), path, self.graph)
 
     def load_weights(self, path: str, config: Optional[str] = None):
         """model.load_weights (Train.py:363,367): a weight file of this package (.npz / .safetensors) or a Keras checkpoint of the
