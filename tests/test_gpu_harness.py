@@ -254,6 +254,16 @@ def test_predict_any_sample_count_and_folder_loop(tmp_path):
     assert r["cm"].sum() == 6 * 32 * 32 and len(r["dice"]) == 6
     assert sorted(p.name for p in (tmp_path / "pred").iterdir()) == sorted(r["names"])
     assert set(np.unique(np.asarray(Image.open(tmp_path / "pred" / "0.png")))) <= {0, 255}
+    # ... and the files the two scripts of the reference exchange: Train.py checkpoints to '<model>_<width>_Fold_<i>.keras' and dumps the
+    # history to an .h5 (:375, :417-430); Test.py rebuilds the model FROM that checkpoint (:114) - no constructor call - and predicts
+    ckpt = str(tmp_path / "UNetPP_32_Fold_1.keras")
+    m.save_weights(ckpt)
+    H.save_history_h5(hist, str(tmp_path / "UNetPP_Fold_1_History.h5"))
+    assert H.load_history_h5(str(tmp_path / "UNetPP_Fold_1_History.h5"))["loss"] == [float(v) for v in hist["loss"]]
+    r2 = H.predict_directory(ckpt, str(idir), str(mdir), str(tmp_path / "pred2"), threshold=0.5)
+    assert np.array_equal(r2["cm"], r["cm"]) and np.array_equal(r2["dice"], r["dice"])
+    for name in r["names"]:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "pred" / name)), np.asarray(Image.open(tmp_path / "pred2" / name)))
 
 
 def test_compiled_metrics_are_logged_under_keras_names():

@@ -143,3 +143,19 @@ print("libhdf5", h5py.version.hdf5_version, "ok")
         pytest.skip("the /opt/conda interpreter has no h5py here")
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ok" in r.stdout
+
+
+def test_history_file_of_the_training_script(tmp_path):
+    """Train.py:417-430 dumps model_history.history with h5py, one dataset per key: the same file without h5py, and back."""
+    from segamd import harness
+    hist = {"loss": [0.9, 0.5, 0.31], "val_loss": [1.0, 0.7, 0.6], "lr": [2e-4, 2e-4, 2e-5], "out_mean_io_u": [0.1, 0.3, 0.35]}
+    p = str(tmp_path / "UNet_Fold_1_History.h5")
+    harness.save_history_h5(hist, p)
+    assert harness.load_history_h5(p) == hist
+    if os.path.exists(CONDA):
+        script = f"import h5py\nwith h5py.File(r'{p}', 'r') as f:\n    print(sorted(f.keys()), list(f['lr'][()]), f['loss'].dtype)"
+        env = {k: v for k, v in os.environ.items() if k not in ("PYTHONHOME", "PYTHONPATH")}
+        r = subprocess.run([CONDA, "-c", script], capture_output=True, text=True, env=env, timeout=120)
+        if "No module named 'h5py'" not in r.stderr:
+            assert r.returncode == 0, r.stderr[-1000:]
+            assert r.stdout.strip() == "['loss', 'lr', 'out_mean_io_u', 'val_loss'] [0.0002, 0.0002, 2e-05] float64"

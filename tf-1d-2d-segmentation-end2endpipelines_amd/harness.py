@@ -304,7 +304,13 @@ def predict_directory(model, image_dir: str, mask_dir: str, save_dir: Optional[s
     thresholded, written to save_dir under the image's name as an 8-bit 'L' image of `mask * round(norm / classes)`,
     and accumulated into the fold's confusion matrices and per-image Dice scores.
 
+    `model` may be the path of a checkpoint (`..._Fold_1.keras`): Test.py:114 loads the model from the file, so does this
+    (keras_import.load_model).
+
     Returns {'names', 'cm' (classes x classes), 'cm_per_class' (classes x 2 x 2), 'dice' (per image)}."""
+    if isinstance(model, (str, os.PathLike)):
+        from .keras_import import load_model
+        model = load_model(os.fspath(model))
     from PIL import Image
     from . import data as D
     H, W = img_size if img_size is not None else model.graph.nodes[model.graph.inputs[0]].shape[:2]
@@ -355,6 +361,23 @@ def predict_directory(model, image_dir: str, mask_dir: str, save_dir: Optional[s
         cmc += D.multilabel_confusion_matrix(yt, yp, labels)
         dices.append(D.dice(msk, m[..., 0]))
     return {"names": imgs, "cm": cm, "cm_per_class": cmc, "dice": np.asarray(dices)}
+
+
+# ------------------------------------------------------------------------------------------------ f1: the history file
+def save_history_h5(history: Dict[str, Sequence[float]], path: str):
+    """Train.py:417-430: `model_history.history` as an HDF5 file with one dataset per key (`loss`, `val_loss`, `lr`, metric names),
+    written without h5py (h5lite.H5Writer); h5py / the reference's plotting code read it as they read their own."""
+    from .h5lite import H5Writer
+    w = H5Writer()
+    for k, v in history.items():
+        w.create_dataset(k, np.asarray(v, np.float64))
+    w.save(path)
+
+
+def load_history_h5(path: str) -> Dict[str, List[float]]:
+    from .h5lite import H5File
+    with H5File(path) as f:
+        return {k: [float(x) for x in np.asarray(f[k].read()).reshape(-1)] for k in f.keys()}
 
 
 # ------------------------------------------------------------------------------------------------ f3: weight files
