@@ -166,3 +166,28 @@ def test_one_loader_takes_every_weight_file_by_what_it_is(tmp_path):
     assert set(back) == set(want) and all(np.array_equal(back[k], want[k]) for k in want)
     with pytest.raises(ValueError, match="needs the builder graph"):
         harness.load_weights_file(os.path.join(FILES, fname))
+
+
+def test_damaged_checkpoints_raise_kerasfileerror(tmp_path):
+    import random
+    rng = random.Random(3)
+    for fname in ("unet1d.keras", "unet3p_weights_only.h5"):
+        raw = open(os.path.join(FILES, fname), "rb").read()
+        cfg = _config_for(fname, "h5_weights" if fname.endswith(".h5") else "keras")
+        outcomes = set()
+        for i in range(120):
+            b = bytearray(raw)
+            if i % 5 == 0:
+                b = b[:rng.randrange(16, len(b))]
+            else:
+                for _m in range(rng.choice([1, 2, 8])):
+                    pos = rng.randrange(0, len(b))
+                    b[pos] = rng.choice([0, 0xFF, rng.randrange(256)])
+            p = tmp_path / ("m_" + fname)
+            p.write_bytes(bytes(b))
+            try:
+                KF.KerasFileModel(str(p), cfg)
+                outcomes.add("ok")
+            except KF.KerasFileError:
+                outcomes.add("refused")
+        assert "refused" in outcomes and outcomes <= {"ok", "refused"}, (fname, outcomes)          # (a zip member's CRC catches every flip)

@@ -38,6 +38,21 @@ class H5Error(ValueError):
     pass
 
 
+def _guard(fn):
+    """A damaged file (a truncated download, a flipped bit in an offset) must surface as H5Error, whatever the parser tripped over."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except (H5Error, KeyError):
+            raise
+        except (struct.error, IndexError, TypeError, ValueError, OverflowError, UnicodeDecodeError, zlib.error, MemoryError, RecursionError) as e:
+            raise H5Error(f"corrupt or truncated HDF5 file ({type(e).__name__}: {str(e)[:160]})") from None
+    return wrapped
+
+
 # ------------------------------------------------------------------------------------------------------------------ datatypes
 class _Type:
     """A parsed datatype message: `kind` in {"num", "str", "vstr", "vlen"}; `dtype` the numpy dtype of one stored element."""
@@ -76,6 +91,7 @@ class H5File:
     """Read-only view of an HDF5 file: `H5File(path)` (memory-mapped), `H5File(bytes)` or `H5File(file-like)`.  Behaves like the root
     group: `f["layers/conv2d/vars/0"].read()`, `f.keys()`, `f.attrs`, `"x" in f`, `f.visit_datasets()`."""
 
+    @_guard
     def __init__(self, src: Union[str, os.PathLike, bytes, bytearray, memoryview, object]):
         self._fh = self._mm = None
         if isinstance(src, (str, os.PathLike)):
@@ -185,8 +201,12 @@ class H5File:
             size0 = self._u(p, w)
             blocks = [(p + w, size0)]
             extra = 2 if hflags & 0x04 else 0
+            nblocks = 0
             while blocks:
                 p, n = blocks.pop(0)
+                nblocks += 1
+                if nblocks > 4096:
+                    raise H5Error("object header continuation blocks form a cycle")
                 end = p + n
                 while p + 4 + extra <= end:
                     t, sz, fl = self._u(p, 1), self._u(p + 1, 2), self._u(p + 3, 1)
@@ -207,8 +227,12 @@ class H5File:
         nmsg = self._u(addr + 2, 2)
         blocks = [(addr + 16, self._u(addr + 8, 4))]
         seen = 0
+        nblocks = 0
         while blocks and seen < nmsg:
             p, n = blocks.pop(0)
+            nblocks += 1
+            if nblocks > 4096:
+                raise H5Error("object header continuation blocks form a cycle")
             end = p + n
             while p + 8 <= end and seen < nmsg:
                 t, sz, fl = self._u(p, 2), self._u(p + 2, 2), self._u(p + 4, 1)
@@ -295,6 +319,7 @@ class _Node:
         return None
 
     @property
+    @_guard
     def attrs(self) -> Dict[str, object]:
         if self._attrs is None:
             f, out = self.file, {}
@@ -333,8 +358,11 @@ class _Node:
 
 
 class Dataset(_Node):
+    @_guard
     def __init__(self, f, addr, name):
         super().__init__(f, addr, name)
+        if self._first(0x03) is None or self._first(0x01) is None or self._first(0x08) is None:
+            raise H5Error(f"{name}: a dataset without its datatype / dataspace / layout message")
         fl, d, sz = self._first(0x03)
         if fl & 0x02:
             raise H5Error(f"{name}: committed (shared) datatypes are outside the subset h5lite reads")
@@ -347,12 +375,17 @@ class Dataset(_Node):
         a = self.read()
         return a if key == () or key is Ellipsis else a[key]
 
+    @_guard
     def read(self):
         """The whole dataset as a numpy array (a scalar dataspace gives a numpy scalar / str)."""
         f, t = self.file, self._type
         if self.shape is None:
             return None
-        count = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        count = 1
+        for s_ in self.shape:
+            count *= int(s_)
+        if count * t.size > 1100 * len(f.buf) + (1 << 20):          # (deflate expands at most ~1030 x: no file of this size holds that)
+            raise H5Error(f"{self.name}: shape {self.shape} x {t.size} bytes is more than this {len(f.buf)}-byte file can hold: corrupt dataspace")
         _fl, d, sz = self._first(0x08)
         ver = f._u(d, 1)
         if ver in (1, 2):
@@ -489,10 +522,12 @@ class Dataset(_Node):
         nd = len(cdims) + 1
         filters = self._filters()
 
-        def walk(a):
+        def walk(a, above=256):
             if f._bytes(a, 4) != b"TREE" or f._u(a + 4, 1) != 1:
                 raise H5Error(f"{self.name}: chunk B-tree node expected at {a}")
             level, n = f._u(a + 5, 1), f._u(a + 6, 2)
+            if level >= above:
+                raise H5Error(f"{self.name}: B-tree levels do not fall towards the leaves (a cycle)")
             p = a + 8 + 2 * f.O
             ksz = 8 + 8 * nd
             for _ in range(n):
@@ -501,7 +536,7 @@ class Dataset(_Node):
                 child = f._addr(p + ksz)
                 p += ksz + f.O
                 if level:
-                    walk(child)
+                    walk(child, level)
                 else:
                     self._place(out, f._bytes(child, size), mask, off, cdims, filters)
 
@@ -510,10 +545,12 @@ class Dataset(_Node):
 
 
 class Group(_Node):
+    @_guard
     def __init__(self, f, addr, name):
         super().__init__(f, addr, name)
         self._links: Optional[Dict[str, int]] = None
 
+    @_guard
     def _load(self) -> Dict[str, int]:
         if self._links is not None:
             return self._links
@@ -533,16 +570,18 @@ class Group(_Node):
                     raw = f._bytes(hdata + off, min(hsize - off, 2 * len(raw)))
                 return raw.split(b"\0", 1)[0].decode("utf-8")
 
-            def walk(a):
+            def walk(a, above=256):
                 if f._bytes(a, 4) != b"TREE" or f._u(a + 4, 1) != 0:
                     raise H5Error(f"{self.name}: group B-tree node expected at {a}")
                 level, n = f._u(a + 5, 1), f._u(a + 6, 2)
+                if level >= above:
+                    raise H5Error(f"{self.name}: B-tree levels do not fall towards the leaves (a cycle)")
                 p = a + 8 + 2 * f.O + f.L
                 for _ in range(n):
                     child = f._addr(p)
                     p += f.O + f.L
                     if level:
-                        walk(child)
+                        walk(child, level)
                         continue
                     if f._bytes(child, 4) != b"SNOD":
                         raise H5Error(f"{self.name}: symbol table node expected at {child}")
@@ -581,6 +620,8 @@ class Group(_Node):
                 p += n
                 if ltype == 0:
                     links[nm] = f._addr(p)
+        if any(not k or "/" in k for k in links):
+            raise H5Error(f"{self.name}: a link with an empty name or a '/' in it: corrupt group")
         self._links = links
         return links
 
@@ -603,8 +644,11 @@ class Group(_Node):
     def items(self):
         return [(k, self[k]) for k in self.keys()]
 
+    @_guard
     def __getitem__(self, key: str):
         node = self
+        if node.name.count("/") > 64:
+            raise H5Error(f"{node.name[:80]}...: groups nested more than 64 deep (a link that points back up the tree)")
         for part in [p for p in key.split("/") if p]:
             if not isinstance(node, Group):
                 raise KeyError(f"{key!r}: {node.name!r} is a dataset")

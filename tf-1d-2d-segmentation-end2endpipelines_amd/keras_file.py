@@ -34,6 +34,7 @@ import io
 import json
 import re
 import zipfile
+import zlib
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -129,6 +130,18 @@ class KerasFileModel:
     """What a Keras checkpoint file says about its model: `layers` (name, class, inbound layers, weights), `output_layers`."""
 
     def __init__(self, path: str, config: Optional[str] = None):
+        try:
+            self._open(path, config)
+        except KerasFileError:
+            raise
+        except H5Error as e:
+            raise KerasFileError(f"{path}: {e}") from None
+        except (zipfile.BadZipFile, zlib.error, json.JSONDecodeError, UnicodeDecodeError, KeyError, TypeError, AttributeError, IndexError, OSError, EOFError, NotImplementedError) as e:
+            if isinstance(e, FileNotFoundError):
+                raise
+            raise KerasFileError(f"{path}: damaged or not a Keras checkpoint ({type(e).__name__}: {str(e)[:160]})") from None
+
+    def _open(self, path: str, config: Optional[str]):
         self.path = path
         self.kind = None
         self._zip_members: Dict[str, bytes] = {}
