@@ -162,3 +162,36 @@ def test_a_model_saved_as_keras_archive_comes_back_from_the_file_alone(dec, kw, 
     cfg = kfile.config
     assert all("/" not in l["name"] and l["config"]["name"] == l["name"] for l in cfg["config"]["layers"])
     assert json.loads(json.dumps(cfg)) == cfg
+
+
+def test_mangled_configurations_raise_kerasimporterror():
+    """Random edits of a real configuration - dropped keys, wrong types, rewired inputs, changed extents: a graph comes out, or
+    KerasImportError; nothing else."""
+    import random
+    rng = random.Random(11)
+    base = _config_of("unet_lstm_ag_ds.keras")
+    built = refused = 0
+    for _ in range(300):
+        cfg = copy.deepcopy(base)
+        layers = cfg["config"]["layers"]
+        for _m in range(rng.choice([1, 1, 2, 3])):
+            l = rng.choice(layers)
+            what = rng.random()
+            if what < 0.3 and l["config"]:
+                l["config"].pop(rng.choice(list(l["config"])))
+            elif what < 0.55 and l["config"]:
+                l["config"][rng.choice(list(l["config"]))] = rng.choice([None, -1, 0, 7, "x", [3], [1, 2, 3], {}, 2.5, True])
+            elif what < 0.7:
+                l["inbound_nodes"] = rng.choice(layers)["inbound_nodes"]
+            elif what < 0.8:
+                l["class_name"] = rng.choice(["Conv2D", "Dense", "Add", "Concatenate", "Reshape", "Cropping2D", "BatchNormalization"])
+            elif what < 0.9:
+                layers.remove(l)
+            else:
+                cfg["config"]["output_layers"] = rng.choice([[], [["nope", 0, 0]], None, [[l["name"], 0, 0]]])
+        try:
+            KI.graph_from_keras_config(cfg)
+            built += 1
+        except KI.KerasImportError:
+            refused += 1
+    assert built > 20 and refused > 100

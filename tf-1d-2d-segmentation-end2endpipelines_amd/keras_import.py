@@ -55,7 +55,17 @@ def _ints(v, n) -> Tuple[int, ...]:
 
 
 def graph_from_keras_config(cfg: dict) -> Graph:
-    """The builder graph of a serialised functional Keras model (module docstring)."""
+    """The builder graph of a serialised functional Keras model (module docstring).  Whatever is wrong with the configuration - a layer
+    the engine would compute differently, shapes that do not fit, a missing key - comes out as KerasImportError."""
+    try:
+        return _graph_from_keras_config(cfg)
+    except KerasImportError:
+        raise
+    except (KeyError, TypeError, ValueError, IndexError, AttributeError, ArithmeticError) as e:
+        raise KerasImportError(f"the model configuration does not describe a UNet-family model of the reference ({type(e).__name__}: {str(e)[:200]})") from None
+
+
+def _graph_from_keras_config(cfg: dict) -> Graph:
     if cfg.get("class_name") not in ("Functional", "Model"):
         raise KerasImportError(f"a {cfg.get('class_name')} model (the reference builds functional models)")
     body = cfg["config"]
@@ -202,6 +212,8 @@ def graph_from_keras_config(cfg: dict) -> Graph:
 
     try:
         out_names = _refs(body["output_layers"])
+        if not out_names:
+            raise KerasImportError("the model configuration names no output layer")
         order, state, stack = [], {}, [(n, 0) for n in reversed(out_names)]          # iterative depth-first post-order from the outputs
         while stack:
             n, i = stack.pop()
