@@ -202,3 +202,15 @@ def test_damaged_files_raise_h5error_whatever_the_parser_trips_over():
         except (H.H5Error, KeyError):
             refused += 1
     assert ok > 100 and refused > 100
+
+
+def test_outcome_files_of_the_1d_notebook(tmp_path):
+    """1D_Segmentation.ipynb writes its test signals, targets and predictions as datasets 'SM' / 'App' / 'App_Pred' of one .h5."""
+    from segamd import harness
+    rng = np.random.default_rng(0)
+    arrays = {"SM": rng.standard_normal((5, 64, 3)).astype(np.float32), "App": rng.standard_normal((5, 64, 1)), "App_Pred": rng.standard_normal((5, 64, 1)).astype(np.float32),
+              "labels/fold": np.arange(5, dtype=np.int64)}
+    p = str(tmp_path / "UNet_Ch3_F1_P1_Kettle.h5")
+    harness.save_arrays_h5(p, arrays)
+    back = harness.load_arrays_h5(p)
+    assert set(back) == set(arrays) and all(back[k].dtype == arrays[k].dtype and np.array_equal(back[k], arrays[k]) for k in arrays)

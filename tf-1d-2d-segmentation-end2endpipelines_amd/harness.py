@@ -374,6 +374,23 @@ def save_history_h5(history: Dict[str, Sequence[float]], path: str):
     w.save(path)
 
 
+def save_arrays_h5(path: str, arrays: Dict[str, np.ndarray]):
+    """The 1D notebook's outcome files (`1D_Segmentation.ipynb`: `File.create_dataset('SM' / 'App' / 'App_Pred', data=...)`): named
+    arrays, one dataset each (nested names make groups), float / integer dtypes as they are."""
+    from .h5lite import H5Writer
+    w = H5Writer()
+    for k, v in arrays.items():
+        w.create_dataset(k, np.asarray(v))
+    w.save(path)
+
+
+def load_arrays_h5(path: str) -> Dict[str, np.ndarray]:
+    """... and `fl_Data = h5py.File(path, 'r'); fl_Data['SM']`: every dataset of the file by its path."""
+    from .h5lite import H5File
+    with H5File(path) as f:
+        return {k: np.asarray(d.read()) for k, d in f.visit_datasets()}
+
+
 def load_history_h5(path: str) -> Dict[str, List[float]]:
     from .h5lite import H5File
     with H5File(path) as f:
