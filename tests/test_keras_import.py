@@ -195,3 +195,11 @@ def test_mangled_configurations_raise_kerasimporterror():
         except KI.KerasImportError:
             refused += 1
     assert built > 20 and refused > 100
+
+
+def test_load_model_needs_no_gpu_to_read_the_file_and_the_engine_still_has_no_cpu_fallback():
+    m = segamd.load_model(os.path.join(FILES, "unetpp_named.keras"))
+    assert not m.built and len(m._weights_at_build) == 60 and m.graph.nodes[m.graph.inputs[0]].shape == (32, 32, 3)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.predict(np.zeros((2, 32, 32, 3), np.float32))
