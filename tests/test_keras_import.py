@@ -27,6 +27,9 @@ def _builder_graph(dec, kw):
     kw = dict(kw)
     if dec == "UNet1D":
         return segamd.UNet1D(**kw).graph_UNet()
+    if dec.startswith("1D:"):
+        cls, method = dec[3:].split(".")
+        return getattr((segamd.BCDUNet if cls == "BCDUNet" else segamd.UNet1D)(**kw), "graph_" + method)()
     w, d = kw.pop("model_width"), kw.pop("model_depth")
     return segamd.unet_model_builder(dec, 32, 32, w, d, train_mode="from_scratch", **kw).graph()
 
@@ -128,6 +131,11 @@ BUILDS = [
     ("UNetE", dict(model_width=4, model_depth=2, num_channels=2)),
     ("UNet1D", dict(length=64, model_depth=2, num_channel=2, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=1, lstm=1, ag=1)),
     ("UNet1D", dict(length=64, model_depth=2, num_channel=1, model_width=4, kernel_size=5, problem_type="Classification", output_nums=3, ae=1, feature_number=6)),
+    ("UNetP", dict(model_width=4, model_depth=3, num_channels=3, ds=1)),
+    ("UNetPP", dict(model_width=6, model_depth=2, num_channels=5, lstm=1, is_transconv=False)),
+    ("1D:UNet.UNetPP", dict(length=64, model_depth=3, num_channel=2, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=1)),
+    ("1D:UNet.MultiResUNet", dict(length=64, model_depth=2, num_channel=1, model_width=8, kernel_size=3, problem_type="Regression", output_nums=1, ds=0, alpha=1)),
+    ("1D:BCDUNet.BCDUNet", dict(length=64, model_depth=2, num_channel=1, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=0, lstm=1, dense_loop=2)),
 ]
 
 
