@@ -185,12 +185,15 @@ def ref_conv(xs, kern, bias, kind, strides):
 
 
 # ------------------------------------------------------------------------------------------------ whole-model compare
-def oracle_run(g, w_np, x, targets, loss, emulate_fp16=False, impose=None):
+def oracle_run(g, w_np, x, targets, loss, emulate_fp16=False, impose=None, dtype=torch.float32):
     """Forward (training-mode BN) + loss + backward of the oracle primitives wired by graph g.  Returns what
     compare_model needs; computed once and shared when several engine modes are compared at an expensive size.
-    impose: branch decisions of another run (ir_interp.run_graph)."""
-    W = {k: torch.from_numpy(np.array(v, np.float32)).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
+    impose: branch decisions of another run (ir_interp.run_graph).  dtype=torch.float64: the same arithmetic in double precision -
+    what the fp32 oracle's own rounding costs, gradient by gradient (tools/fuzz_models.py)."""
+    W = {k: torch.from_numpy(np.array(v, np.float32)).to(dtype).requires_grad_(not (k.endswith("moving_mean") or k.endswith("moving_variance")))
          for k, v in w_np.items()}
+    x = x.to(dtype)
+    targets = [t.to(dtype) if t.is_floating_point() else t for t in targets]
     outs_ref, vals = run_graph(g, x, W, training=True, return_all=True, emulate_fp16=emulate_fp16, impose=impose)
     for v in vals.values():
         if v.requires_grad:
