@@ -314,6 +314,9 @@ def run_case(call, make, xf, loss, dtype, rng):
     msg += tail_note
     if VERBOSE:
         top = sorted(arith, key=arith.get, reverse=True)[:8]
+        if os.environ.get("FUZZ_WATCH"):          # (also list the parameters whose name contains one of these comma-separated fragments)
+            frags = os.environ["FUZZ_WATCH"].split(",")
+            top += [k for k in sorted(arith) if k not in top and any(f in k for f in frags)]
         msg += "".join(f"\n        {k:40s} err {r['gl2_imposed'][k][0]:.3e} (relative {arith[k]:.1e}, conditioning {sens.get(k, 0.0):.1e}) norm {r['gl2_imposed'][k][1]:.3e} (largest norm {gn:.3e}) own-decisions err {r['gl2'][k][0]:.3e}" for k in top)
         msg += "\n        activation gradients off by more than 1e-3 of their own maximum (graph order): " + "; ".join(
             f"{n} {e / (m_ + 1e-30):.1e}" for n, e, m_ in r["agrads"] if e > 1e-3 * m_)[:3000]
