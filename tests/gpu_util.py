@@ -220,7 +220,11 @@ def gpu_decisions(model):
                 continue
             if n.name in lazy:
                 op = lazy[n.name]
-                pre = op.z.values().cpu() * op.scale[:op.cout].cpu() + op.shift[:op.cout].cpu()
+                # (the kernels normalise on load with ONE fused multiply-add, `z * scale + shift` contracted by hipcc: its sign is the sign
+                # of the exact value.  float32 multiply-then-add rounds twice and puts an element or two per ten million on the other
+                # side of zero - one such element moves a BatchNormalization beta of a 256 x 192 model by 3e-3 (round 5, --big seed 21
+                # case 129).  In double precision the product is exact and the sum keeps 53 bits: the fused operation's sign.)
+                pre = op.z.values().cpu().double() * op.scale[:op.cout].cpu().double() + op.shift[:op.cout].cpu().double()
                 dec[n.name] = pre > 0
             elif t.buf.numel() and getattr(t, "materialised", True):
                 dec[n.name] = t.values().cpu() > 0
