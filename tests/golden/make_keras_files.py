@@ -86,10 +86,17 @@ def keras_view(g, rng, one_d, name_offset=17):
             layer_of[i] = emit("BatchNormalization", auto("BatchNormalization"),
                                dict(axis=[2 if one_d else 3], momentum=a["momentum"], epsilon=a["eps"], center=True, scale=True), ins, planted(n, n.params))
         elif n.kind == "act":
+            # the reference writes Activation('ReLU') / Activation('LeakyReLU') in its Conv_Block / trans_conv2D (unet_variants.py:7, 17):
+            # Keras 2 resolves those to layer objects and serialises the activation as a dictionary; Activation('relu') / ('sigmoid')
+            # elsewhere stay strings.  Every other ReLU here takes the dictionary form, so that both spellings are in the fixtures.
+            nm = n.name if i in outset else auto("Activation")
             if a["fn"] == "leaky_relu":
-                layer_of[i] = emit("LeakyReLU", auto("LeakyReLU"), dict(alpha=a["alpha"]), ins)
+                act = {"class_name": "LeakyReLU", "config": {"name": "leaky_re_lu", "trainable": True, "dtype": "float32", "alpha": a["alpha"]}}
+            elif a["fn"] == "relu" and counters.get("Activation", 0) % 2 == 0:
+                act = {"class_name": "ReLU", "config": {"name": "re_lu", "trainable": True, "dtype": "float32", "max_value": None, "negative_slope": 0.0, "threshold": 0.0}}
             else:
-                layer_of[i] = emit("Activation", n.name if i in outset else auto("Activation"), dict(activation=a["fn"]), ins)
+                act = a["fn"]
+            layer_of[i] = emit("Activation", nm, dict(activation=act), ins)
         elif n.kind == "maxpool":
             layer_of[i] = emit("MaxPooling2D", auto("MaxPooling2D"), dict(pool_size=sp(a["size"]), strides=sp(a["size"]), padding="valid"), ins)
         elif n.kind == "upsample":

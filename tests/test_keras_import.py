@@ -112,11 +112,26 @@ def test_both_spellings_of_the_input_shape_and_of_leaky_relu():
     cfg = _config_of("unetpp_named.keras")
     ic = _layer(cfg, "InputLayer")["config"]
     ic["batch_shape"] = ic.pop("batch_input_shape")          # Keras 3
-    lr = _layer(cfg, "LeakyReLU")["config"]
-    lr["negative_slope"] = lr.pop("alpha")
+    leaky = [l for l in cfg["config"]["layers"] if l["class_name"] == "Activation" and isinstance(l["config"]["activation"], dict)
+             and l["config"]["activation"]["class_name"] == "LeakyReLU"]
+    assert leaky                                            # (the reference's Activation('LeakyReLU'): a serialised layer object)
+    lr = leaky[0]["config"]["activation"]["config"]
+    lr["negative_slope"] = lr.pop("alpha")                  # Keras 3's name for it
+    if len(leaky) > 1:
+        leaky[1]["config"]["activation"] = "LeakyReLU"      # the name as written in the reference: the layer's default slope, 0.3
     g = KI.graph_from_keras_config(cfg)
     assert g.nodes[g.inputs[0]].shape == (32, 32, 3)
-    assert any(n.kind == "act" and n.attrs["fn"] == "leaky_relu" and abs(n.attrs["alpha"] - 0.3) < 1e-7 for n in g.nodes)
+    slopes = [n.attrs["alpha"] for n in g.nodes if n.kind == "act" and n.attrs["fn"] == "leaky_relu"]
+    assert len(slopes) == len(leaky) and all(abs(a - 0.3) < 1e-7 for a in slopes)
+    leaky[0]["config"]["activation"] = "leaky_relu"         # Keras 3's FUNCTION: slope 0.2
+    g = KI.graph_from_keras_config(cfg)
+    assert sorted(round(n.attrs["alpha"], 3) for n in g.nodes if n.kind == "act" and n.attrs["fn"] == "leaky_relu")[0] == 0.2
+    relu = next(l for l in cfg["config"]["layers"] if l["class_name"] == "Activation" and isinstance(l["config"]["activation"], dict)
+                and l["config"]["activation"]["class_name"] == "ReLU")
+    relu["config"]["activation"]["config"]["max_value"] = 6.0
+    with pytest.raises(KI.KerasImportError, match="max_value"):
+        KI.graph_from_keras_config(cfg)
+    relu["config"]["activation"]["config"]["max_value"] = None
     ic["batch_shape"] = [None, None, None, 3]
     with pytest.raises(KI.KerasImportError, match="fixed"):
         KI.graph_from_keras_config(cfg)

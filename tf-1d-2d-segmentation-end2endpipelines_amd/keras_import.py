@@ -34,16 +34,43 @@ class KerasImportError(ValueError):
     pass
 
 
-_ACTS = {"relu": "relu", "sigmoid": "sigmoid", "softmax": "softmax", "linear": None, None: None, "leaky_relu": "leaky_relu"}
+_ACTS = {"relu": "relu", "sigmoid": "sigmoid", "softmax": "softmax", "linear": None, "leakyrelu": "leaky_relu", "leaky_relu": "leaky_relu"}
+
+
+def _activation(v, layer) -> Tuple[Optional[str], float]:
+    """(activation of this package or None for linear, slope of a leaky ReLU) of a serialised Keras activation.  The reference writes
+    `Activation('ReLU')` / `Activation('LeakyReLU')` (unet_variants.py:7, 17): Keras 2 resolves those names to LAYER objects and
+    serialises them as `{"class_name": "LeakyReLU", "config": {"alpha": 0.3, ...}}`; plain function names (`'relu'`, `'sigmoid'`)
+    stay strings.  The layer `LeakyReLU` defaults to a slope of 0.3, Keras 3's FUNCTION `leaky_relu` to 0.2."""
+    alpha = 0.0
+    if isinstance(v, dict):
+        cfg = v.get("config") or {}
+        cls = v.get("class_name")
+        if cls in ("ReLU", "LeakyReLU", "Softmax"):
+            if cls == "ReLU":
+                if cfg.get("max_value") is not None or float(cfg.get("threshold", 0.0) or 0.0) != 0.0:
+                    raise KerasImportError(f"layer {layer!r}: ReLU with max_value / threshold")
+                slope = float(cfg.get("negative_slope", 0.0) or 0.0)
+                return ("relu", 0.0) if slope == 0.0 else ("leaky_relu", slope)
+            if cls == "LeakyReLU":
+                return "leaky_relu", float(cfg.get("negative_slope", cfg.get("alpha", 0.3)))
+            return "softmax", 0.0
+        v = cls if cls not in (None, "function") else cfg.get("name", cfg) if isinstance(cfg, dict) else cfg
+    if v is None:
+        return None, 0.0
+    key = str(v).lower()
+    if key not in _ACTS:
+        raise KerasImportError(f"layer {layer!r}: activation {v!r} is not one the hot path has (relu, leaky_relu, sigmoid, softmax, linear)")
+    if _ACTS[key] == "leaky_relu":
+        alpha = 0.3 if key == "leakyrelu" else 0.2
+    return _ACTS[key], alpha
 
 
 def _act_name(v, layer):
-    if isinstance(v, dict):                              # a serialised activation object ({"class_name": ..., "config": ...})
-        v = (v.get("config") or {}).get("name") or v.get("class_name")
-        v = v.lower() if isinstance(v, str) else v
-    if v not in _ACTS:
-        raise KerasImportError(f"layer {layer!r}: activation {v!r} is not one the hot path has (relu, leaky_relu, sigmoid, softmax, linear)")
-    return _ACTS[v]
+    fn, _alpha = _activation(v, layer)
+    if fn == "leaky_relu":
+        raise KerasImportError(f"layer {layer!r}: a leaky ReLU as the fused activation of a convolution (the reference uses separate layers)")
+    return fn
 
 
 def _ints(v, n) -> Tuple[int, ...]:
@@ -127,8 +154,8 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             need(bool(c.get("center", True)) and bool(c.get("scale", True)), name, "center / scale switched off")
             out = g.bn(xs[0], name, eps=float(c.get("epsilon", 1e-3)), momentum=float(c.get("momentum", 0.99)))
         elif cls == "Activation":
-            a = _act_name(c.get("activation"), name)
-            out = xs[0] if a is None else g.act(xs[0], a, name)
+            a, slope = _activation(c.get("activation"), name)
+            out = xs[0] if a is None else g.act(xs[0], a, name, alpha=slope)
         elif cls == "ReLU":
             need(c.get("max_value") is None and float(c.get("threshold", 0.0) or 0.0) == 0.0, name, "max_value / threshold")
             slope = float(c.get("negative_slope", 0.0) or 0.0)
