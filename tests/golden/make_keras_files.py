@@ -33,7 +33,7 @@ CASES = [      # (file, decoder, constructor keywords, layout)
 ]
 
 ONE_D = {"Conv2D": "Conv1D", "Conv2DTranspose": "Conv1DTranspose", "MaxPooling2D": "MaxPooling1D", "UpSampling2D": "UpSampling1D", "ConvLSTM2D": "ConvLSTM1D"}
-AUTO = {"Conv2D": "conv2d", "Conv2DTranspose": "conv2d_transpose", "BatchNormalization": "batch_normalization", "Activation": "activation",
+AUTO = {"TFOpLambda": "tf.math.multiply", "Conv2D": "conv2d", "Conv2DTranspose": "conv2d_transpose", "BatchNormalization": "batch_normalization", "Activation": "activation",
         "LeakyReLU": "leaky_re_lu", "MaxPooling2D": "max_pooling2d", "UpSampling2D": "up_sampling2d", "Concatenate": "concatenate", "Add": "add",
         "Multiply": "multiply", "ConvLSTM2D": "conv_lstm2d", "InputLayer": "input", "Reshape": "reshape", "Flatten": "flatten", "Dense": "dense"}
 
@@ -77,7 +77,8 @@ def keras_view(g, rng, one_d, name_offset=17):
             layer_of[i] = emit("InputLayer", "input_1", dict(batch_input_shape=[None] + sp((H, W)) + [C], dtype="float32", sparse=False), [])
         elif n.kind in ("conv", "convT"):
             cls = "Conv2D" if n.kind == "conv" else "Conv2DTranspose"
-            cfg = dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp(a["strides"]), padding="same", data_format="channels_last",
+            pointwise = all(k == 1 for k in sp(a["kernel"])) and n.kind == "conv"          # the reference leaves padding at 'valid' on its 1x1 convs
+            cfg = dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp(a["strides"]), padding="valid" if pointwise else "same", data_format="channels_last",
                        dilation_rate=sp((1, 1)), groups=1, activation=a.get("activation") or "linear", use_bias=a.get("use_bias", True))
             if n.kind == "convT":
                 cfg["output_padding"] = None
@@ -112,7 +113,10 @@ def keras_view(g, rng, one_d, name_offset=17):
         elif n.kind == "add":
             layer_of[i] = emit("Add", auto("Add"), {}, ins)
         elif n.kind == "mul":
-            layer_of[i] = emit("Multiply", auto("Multiply"), {}, ins)
+            # `skip_connection * resampler` (unet_variants.py:81): TF 2.x wraps the operator in a TFOpLambda layer; the layouts that
+            # carry Keras 3's spelling get its Multiply operation instead (stage 2 looks at the class)
+            layer_of[i] = emit("TFOpLambda", f"tf.math.multiply_{counters.setdefault('TFOpLambda', 0)}", dict(function="math.multiply"), ins)
+            counters["TFOpLambda"] += 1
         elif n.kind == "convlstm":
             Hi, Wi, Ci = g.nodes[n.inputs[0]].shape
             r = emit("Reshape", auto("Reshape"), dict(target_shape=[1] + sp((Hi, Wi)) + [Ci]), ins)
@@ -184,11 +188,17 @@ def stage2(tmp):
         def node(l):
             if not l["inbound"]:
                 return []
+            if l["cls"] == "TFOpLambda" and layout != "keras_named_k3":          # TF 2.x: the second operand travels in the call's kwargs
+                a_, b_ = l["inbound"]
+                return [[a_, 0, 0, {"y": [b_, 0, 0], "name": None}]]
             if layout == "keras_named_k3":              # Keras 3 spelling
                 kts = [{"class_name": "__keras_tensor__", "config": {"shape": [None], "dtype": "float32", "keras_history": [n, 0, 0]}} for n in l["inbound"]]
                 return [{"args": [kts if len(kts) > 1 else kts[0]], "kwargs": {}}]
             return [[[n, 0, 0, {}] for n in l["inbound"]]]
 
+        for l in layers:
+            if l["cls"] == "TFOpLambda" and layout == "keras_named_k3":          # Keras 3: the operator is an operation of class Multiply
+                l["cls"], l["config"] = "Multiply", {"name": l["name"]}
         cfg_layers = [{"module": "keras.layers", "class_name": l["cls"], "config": dict(l["config"], trainable=True, dtype="float32"),
                        "registered_name": None, "name": l["name"], "inbound_nodes": node(l)} for l in layers]
         outs = [[n, 0, 0] for n in case["outputs"]]

@@ -65,6 +65,8 @@ def _refs(x) -> List[str]:
     elif isinstance(x, (list, tuple)):
         if len(x) >= 3 and isinstance(x[0], str) and isinstance(x[1], int) and isinstance(x[2], int):
             out.append(x[0])
+            if len(x) >= 4 and isinstance(x[3], dict):   # Keras 2 keeps further tensor arguments in the call's kwargs: `a * b` is the
+                out += _refs(x[3])                       # TFOpLambda node ["a", 0, 0, {"y": ["b", 0, 0], "name": null}]
         else:
             for v in x:
                 out += _refs(v)
@@ -178,6 +180,7 @@ class KerasFileModel:
         for lc in body["layers"]:
             name = lc.get("name") or lc["config"]["name"]
             layer = _layer_of_class(lc["class_name"], name)
+            layer.symbol = str((lc.get("config") or {}).get("function", ""))          # (TFOpLambda: 'math.multiply')
             by_name[name] = layer
             self.layers.append(layer)
         for lc, layer in zip(body["layers"], self.layers):

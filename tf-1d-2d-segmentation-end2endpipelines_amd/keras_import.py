@@ -11,7 +11,8 @@ node the builders of this package would have emitted for it, and takes the weigh
 Layers understood - the ones the UNet-family builders of the reference emit (`2D/models/unet_variants.py`, `1D/Models/
 unet_variants.py`, `BCDUNet.py`): InputLayer; Conv1D/2D and Conv1D/2DTranspose with padding='same', no dilation; BatchNormalization
 over the channel axis; Activation / ReLU / LeakyReLU / Softmax; MaxPooling (stride = pool size); UpSampling (nearest / bilinear);
-Concatenate over channels (nested concatenates are flattened - `Concat_Block` folds pairwise); Add; Multiply; ConvLSTM1D/2D on a
+Concatenate over channels (nested concatenates are flattened - `Concat_Block` folds pairwise); Add; Multiply - also as the operator
+`a * b`, TF 2.x's TFOpLambda of math.multiply (Attention_Block); ConvLSTM1D/2D on a
 length-1 sequence (the Reshape in front of it is absorbed); Flatten -> Dense -> Dense -> Reshape as the autoencoder bottleneck;
 Dropout-family layers and shape-preserving Reshapes as identity (inference semantics: the engine has no dropout, and says so).
 Anything else - 'valid' padding, dilation, a Dense that is not part of that bottleneck, Lambda, shared layers, nested models - raises
@@ -121,7 +122,10 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             raise KerasImportError(f"layer {layer!r} ({layers[layer]['class_name']}): {what}")
 
     def same_padding(c, name):
-        need(str(c.get("padding", "valid")).lower() == "same", name, f"padding={c.get('padding')!r} (the hot path is padding='same')")
+        # (a 1 x 1 kernel needs no padding: 'valid' - the default the reference leaves on its attention-gate convs and heads,
+        # unet_variants.py:69-75 - gives ceil(extent / stride) outputs like 'same')
+        pointwise = all(k == 1 for k in _ints(c.get("kernel_size", 0), ndim))
+        need(str(c.get("padding", "valid")).lower() == "same" or pointwise, name, f"padding={c.get('padding')!r} with a kernel of {c.get('kernel_size')} (the hot path is padding='same')")
         need(all(d == 1 for d in _ints(c.get("dilation_rate", 1), ndim)), name, f"dilation_rate={c.get('dilation_rate')}")
         need(c.get("data_format") in (None, "channels_last"), name, f"data_format={c.get('data_format')!r}")
         need(int(c.get("groups", 1) or 1) == 1, name, f"groups={c.get('groups')}")
@@ -185,7 +189,7 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             out = g.concat(parts, name)
         elif cls == "Add":
             out = g.add(xs, name)
-        elif cls == "Multiply":
+        elif cls == "Multiply" or (cls == "TFOpLambda" and "multiply" in str(c.get("function", name))):
             need(len(xs) == 2, name, f"{len(xs)} factors")
             a, b = xs
             if a.shape[2] == 1 and b.shape[2] != 1:      # (the one-channel gate is the second operand of Graph.mul)

@@ -21,6 +21,8 @@ Differences between the two graphs the walk absorbs:
   * `Concat_Block` folds pairwise (`concatenate([concatenate([a, b]), c])`, unet_variants.py:27-32); the builders emit one
     n-ary concat: both sides are flattened to their leaf list before they are compared
   * the autoencoder bottleneck is Flatten -> Dense -> Dense -> Reshape in Keras and ONE `dense_ae` node here
+  * `a * b` on Keras tensors (Attention_Block, unet_variants.py:81) is a `TFOpLambda` layer of `math.multiply` in TF 2.x, a `Multiply`
+    operation in Keras 3, and the `mul` node here
   * a conv head with a fused activation is one Conv layer on both sides; `Activation('ReLU')` may be an `Activation`, a
     `ReLU` or a `LeakyReLU` layer depending on the Keras version
 """
@@ -67,6 +69,15 @@ def _kind(layer) -> str:
     cls = layer.__class__.__name__
     if cls in _PASS_THROUGH:
         return "skip"
+    if cls == "TFOpLambda":
+        # `skip_connection * resampler` in Attention_Block (unet_variants.py:81) is not a Multiply layer: TF 2.x wraps the operator in
+        # a TFOpLambda layer named 'tf.math.multiply' (Keras 3: an operation of class Multiply, which the table below knows)
+        sym = str(getattr(layer, "symbol", "") or getattr(layer, "name", ""))
+        if "multiply" in sym:
+            return "mul"
+        if sym.endswith("add") or "add_v2" in sym:
+            return "add"
+        raise KerasMapError(f"layer {layer.name!r}: TFOpLambda of {sym!r} is not part of the UNet-family hot path")
     k = _KIND_OF_CLASS.get(cls)
     if k is None:
         raise KerasMapError(f"layer {layer.name!r}: class {cls} is not part of the UNet-family hot path")
