@@ -45,6 +45,7 @@ def keras_view(g, rng, one_d, name_offset=17):
     the autoencoder bottleneck (:41-47), separate Activation / LeakyReLU layers, heads with their explicit names."""
     counters, layers, layer_of = {}, [], {}
     outset = set(g.outputs)
+    cons, sequences = g.consumers(), set()
     sp = (lambda hw: [int(hw[1])] if one_d else [int(hw[0]), int(hw[1])])
 
     def auto(cls):
@@ -107,9 +108,16 @@ def keras_view(g, rng, one_d, name_offset=17):
             layer_of[i] = emit("UpSampling2D", auto("UpSampling2D"), cfg, ins)
         elif n.kind == "concat":
             cur = ins[0]
+            feeds_lstm = [g.nodes[j].kind for j in cons.get(i, [])] == ["convlstm"]
+            if feeds_lstm:          # unet_variants.py:145-147: each input reshaped to a length-1 sequence, THEN concatenated
+                ins = [emit("Reshape", auto("Reshape"), dict(target_shape=[1] + sp(g.nodes[j].shape[:2]) + [g.nodes[j].shape[2]]), [l_])
+                       for j, l_ in zip(n.inputs, ins)]
+                cur = ins[0]
             for nxt in ins[1:]:
                 cur = emit("Concatenate", auto("Concatenate"), dict(axis=-1), [cur, nxt])
             layer_of[i] = cur
+            if feeds_lstm:
+                sequences.add(i)
         elif n.kind == "add":
             layer_of[i] = emit("Add", auto("Add"), {}, ins)
         elif n.kind == "mul":
@@ -119,7 +127,7 @@ def keras_view(g, rng, one_d, name_offset=17):
             counters["TFOpLambda"] += 1
         elif n.kind == "convlstm":
             Hi, Wi, Ci = g.nodes[n.inputs[0]].shape
-            r = emit("Reshape", auto("Reshape"), dict(target_shape=[1] + sp((Hi, Wi)) + [Ci]), ins)
+            r = ins[0] if n.inputs[0] in sequences else emit("Reshape", auto("Reshape"), dict(target_shape=[1] + sp((Hi, Wi)) + [Ci]), ins)
             layer_of[i] = emit("ConvLSTM2D", auto("ConvLSTM2D"),
                                dict(filters=C, kernel_size=sp(a["kernel"]), strides=sp((1, 1)), padding="same", dilation_rate=sp((1, 1)), activation="tanh",
                                     recurrent_activation="hard_sigmoid", use_bias=True, return_sequences=False, go_backwards=True, stateful=False),

@@ -226,3 +226,16 @@ def test_load_model_needs_no_gpu_to_read_the_file_and_the_engine_still_has_no_cp
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             m.predict(np.zeros((2, 32, 32, 3), np.float32))
+
+
+def test_only_concatenate_and_the_convlstm_touch_the_length_one_sequence():
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    layers = {l["name"]: l for l in cfg["config"]["layers"]}
+    lstm = _layer(cfg, "ConvLSTM2D")
+    cat = layers[KF._refs(lstm["inbound_nodes"])[0]]
+    assert cat["class_name"] == "Concatenate" and all(layers[r]["class_name"] == "Reshape" for r in KF._refs(cat["inbound_nodes"]))
+    g = KI.graph_from_keras_config(cfg)                  # Reshape((1, H, W, C)) twice -> Concatenate (5-D) -> ConvLSTM2D, as unet_variants.py:145-149
+    assert sum(1 for i in g.live_nodes() if g.nodes[i].kind == "convlstm") == 2
+    cat["class_name"], cat["config"] = "Add", {"name": cat["name"]}
+    with pytest.raises(KI.KerasImportError, match="length-1 sequence"):
+        KI.graph_from_keras_config(cfg)

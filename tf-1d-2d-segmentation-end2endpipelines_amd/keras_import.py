@@ -116,6 +116,7 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
     g = Graph(ndim=ndim, name=body.get("name", "model"))
     sym: Dict[str, Sym] = {}
     flat_shape: Dict[str, Tuple[int, ...]] = {}           # Keras-side shapes of layers that have no node of their own (Flatten, Dense)
+    seq: set = set()                                      # layers whose Keras tensor carries the length-1 time axis of a ConvLSTM input
 
     def need(cond, layer, what):
         if not cond:
@@ -182,7 +183,14 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             need(interp in ("nearest", "bilinear"), name, f"interpolation={interp!r}")
             out = g.upsample(xs[0], k1(c.get("size", 2)), name, interpolation=interp)
         elif cls == "Concatenate":
-            need(c.get("axis", -1) in (-1, ndim + 1), name, f"axis={c.get('axis')} (channels)")
+            need(c.get("axis", -1) in (-1, ndim + 1, ndim + 2), name, f"axis={c.get('axis')} (channels)")
+            # (the reference reshapes the skip connection and the decoder tensor to (1, H, W, C) EACH and concatenates the two
+            # sequences in front of the ConvLSTM, unet_variants.py:145-147: the time axis rides through the concatenation)
+            in_seq = [s_ in seq for s_ in srcs]
+            need(all(in_seq) or not any(in_seq), name, "a concatenation of sequences with plain tensors")
+            if all(in_seq):
+                seq.add(name)
+                need(c.get("axis", -1) in (-1, ndim + 2), name, f"axis={c.get('axis')} (channels of the sequence)")
             parts: List[Sym] = []
             for s, x in zip(srcs, xs):                   # concatenate([concatenate([a, b]), c]) == concatenate([a, b, c])
                 parts += [Sym(g, j) for j in x.node.inputs] if x.node.kind == "concat" else [x]
@@ -203,7 +211,7 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             # defaults - tanh and HARD sigmoid, what the kernels compute: a file that says 'sigmoid' (Keras 3's default) is refused)
             need(str(c.get("activation", "tanh")) == "tanh" and str(c.get("recurrent_activation", "hard_sigmoid")) == "hard_sigmoid",
                  name, f"activation={c.get('activation')!r} / recurrent_activation={c.get('recurrent_activation')!r} (the engine's gates are tanh / hard_sigmoid)")
-            need((flat_shape.get(srcs[0]) or (0,))[0] == 1, name, "its input is not a length-1 sequence (Reshape((1, ...)) in front of it)")
+            need(srcs[0] in seq, name, "its input is not a length-1 sequence (Reshape((1, ...)) in front of it)")
             out = g.convlstm(xs[0], int(c["filters"]), k1(c["kernel_size"]), name)
         elif cls in ("Dropout", "SpatialDropout1D", "SpatialDropout2D", "Identity"):
             out = xs[0]
@@ -232,12 +240,13 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             else:
                 shp = xs[0].shape if ndim == 2 else xs[0].shape[1:]
                 need(target in (tuple(shp), (1,) + tuple(shp)), name, f"target_shape={target} of a tensor {tuple(shp)} (only the length-1 sequence axis in front of a ConvLSTM)")
-                flat_shape[name] = target if len(target) == len(shp) + 1 else ()
+                if len(target) == len(shp) + 1:
+                    seq.add(name)
                 out = xs[0]
         else:
             raise KerasImportError(f"layer {name!r}: class {cls} is not part of the UNet-family hot path")
-        if cls not in ("Reshape",) and name not in flat_shape:
-            flat_shape[name] = ()
+        if name not in seq and any(s_ in seq for s_ in srcs) and cls not in ("ConvLSTM1D", "ConvLSTM2D"):
+            raise KerasImportError(f"layer {name!r} ({cls}): applied to the length-1 sequence of a ConvLSTM input (only Concatenate and the ConvLSTM itself are)")
         sym[name] = out
         return out
 
