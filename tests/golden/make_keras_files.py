@@ -30,6 +30,7 @@ CASES = [      # (file, decoder, constructor keywords, layout)
     ("multires_legacy.h5", "MultiResUNet", dict(model_width=8, model_depth=1, num_channels=3, ag=1, alpha=1.0), "h5_model"),
     ("unet3p_weights_only.h5", "UNet3P", dict(model_width=4, model_depth=2, num_channels=3), "h5_weights"),
     ("unet1d.keras", "UNet1D", dict(length=64, model_depth=2, num_channel=2, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=1), "keras_counted"),
+    ("unet1d_lstm_ag.keras", "UNet1D", dict(length=64, model_depth=2, num_channel=1, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=0, ag=1, lstm=1), "keras_counted"),
 ]
 
 ONE_D = {"Conv2D": "Conv1D", "Conv2DTranspose": "Conv1DTranspose", "MaxPooling2D": "MaxPooling1D", "UpSampling2D": "UpSampling1D", "ConvLSTM2D": "ConvLSTM1D"}
