@@ -421,3 +421,25 @@ def save_model(graph: Graph, weights: Dict[str, np.ndarray], path: str):
         z.writestr("metadata.json", json.dumps({"keras_version": "2.15.0", "date_saved": "", "written_by": "segamd.keras_import.save_model"}))
         z.writestr("config.json", json.dumps(cfg))
         z.writestr("model.weights.h5", w.tobytes())
+
+
+def describe(path: str, config: Optional[str] = None) -> str:
+    """What a checkpoint file is and whether this engine takes it: format, layer classes, parameters, input / outputs - or the layer
+    that is in the way.  `python tools/keras_info.py x.keras` prints it (no GPU needed)."""
+    from collections import Counter
+    kfile = KerasFileModel(path, config)
+    classes = Counter(l.__class__.__name__ for l in kfile.layers)
+    held = sum(int(np.prod(w.shape)) for l in kfile.layers for w in l._w)
+    lines = [f"{path}: {'.keras archive' if kfile.kind == 'keras' else 'HDF5 file'}, model {kfile.config['config'].get('name')!r}, {len(kfile.layers)} layers, "
+             f"{held:,} weight values in {sum(len(l._w) for l in kfile.layers)} arrays",
+             "  layer classes: " + ", ".join(f"{k} x {v}" for k, v in sorted(classes.items()))]
+    try:
+        g = graph_from_keras_config(kfile.config)
+        w = weights_of_imported_graph(kfile, g)
+        i0 = g.nodes[g.inputs[0]]
+        lines.append(f"  imports as a {g.ndim}-D graph of {len(g.live_nodes())} nodes, {g.count_params():,} parameters ({sum(int(np.prod(v.shape)) for v in w.values()):,} found in the file); "
+                     f"input {tuple(i0.shape if g.ndim == 2 else i0.shape[1:])}; outputs " + ", ".join(f"{n} {tuple(g.nodes[o].shape if g.ndim == 2 else g.nodes[o].shape[1:])}" for n, o in zip(g.output_names, g.outputs)))
+        lines.append(f"  {2 * g.macs() / 1e6:,.1f} MFLOP per sample forward")
+    except KerasImportError as e:
+        lines.append(f"  NOT importable: {e}")
+    return "\n".join(lines)
