@@ -249,3 +249,14 @@ def test_describe_says_what_a_file_is_and_what_is_in_the_way(tmp_path):
     pool["config"]["strides"] = [1, 1]
     text = KI.describe(os.path.join(FILES, "unet_lstm_ag_ds.keras"), config=json.dumps(cfg))
     assert "NOT importable" in text and pool["name"] in text and "strides" in text
+
+
+def test_random_builder_calls_survive_the_archive_round_trip():
+    """A fixed sample of tools/fuzz_archives.py (CPU only): 40 random constructor calls of the builder API -> save_weights('x.keras') ->
+    the archive alone back to a graph (load_model's path) and onto the constructor call (load_weights's path); the imported graph
+    computes what the builder's graph computes, bit for bit."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_archives as FA
+    ok, refused, fails = FA.run(5, 40, verbose=False)
+    assert not fails, fails[:3]
+    assert ok >= 30
