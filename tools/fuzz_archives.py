@@ -5,6 +5,7 @@ model.weights.h5 through h5lite) -> the archive alone back to a graph and weight
 (`load_weights`'s path).  The imported graph must compute what the builder's graph computes, bit for bit, in the oracle's interpreter.
 
     python tools/fuzz_archives.py <seed> <n>          # ~6 configurations a second
+    python tools/fuzz_archives.py <seed> <n> --keras2 # the archive as TF 2.13 - 2.15 would spell it for the reference's code (keras_view)
 
 Build-authored test tooling (uses the oracle's interpreter: not part of the product path)."""
 import os
@@ -23,7 +24,52 @@ from ir_interp import run_graph
 import fuzz_models as FZ
 
 
-def run(seed, n, verbose=True):
+def write_keras2_archive(g, one_d, path, rng_np):
+    """The archive TF 2.13 - 2.15 would leave for builder graph `g`, in the reference's own spelling (tests/golden/make_keras_files.py
+    `keras_view`: Activation('ReLU') as a serialised layer object, a * b as a TFOpLambda with its second operand in the call's kwargs,
+    1x1 convs at padding='valid', Reshape + 5-D concatenate in front of a ConvLSTM, pairwise concatenates, auto-names, model.layers out
+    of creation order) with class-counter weight keys - written with h5lite.  Returns {structural parameter name: array}."""
+    import json
+    import zipfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_keras_files as MK
+    from segamd.h5lite import H5Writer
+    from segamd.keras_file import _snake
+    layers, outputs = MK.keras_view(g, rng_np, one_d)
+    planted = {}
+    w = H5Writer()
+    w.create_group("vars")
+    used = {}
+    cfg_layers = []
+    for l in layers:
+        base = _snake(l["cls"])
+        used[base] = used.get(base, -1) + 1
+        key = base if used[base] == 0 else f"{base}_{used[base]}"
+        holder = f"layers/{key}/cell/vars" if l["cls"].startswith("ConvLSTM") else f"layers/{key}/vars"
+        w.create_group(f"layers/{key}/vars")
+        w.create_group(holder)
+        for i, (pname, arr) in enumerate(l["weights"]):
+            planted[pname] = arr
+            a = arr[0] if (one_d and arr.ndim == 4 and arr.shape[0] == 1) else arr
+            w.create_dataset(f"{holder}/{i}", a)
+        if l["cls"] == "TFOpLambda" and l["inbound"]:
+            a_, b_ = l["inbound"]
+            node = [[a_, 0, 0, {"y": [b_, 0, 0], "name": None}]]
+        else:
+            node = [[[n_, 0, 0, {}] for n_ in l["inbound"]]] if l["inbound"] else []
+        cfg_layers.append({"module": "keras.layers", "class_name": l["cls"], "config": dict(l["config"], trainable=True, dtype="float32"),
+                           "registered_name": None, "name": l["name"], "inbound_nodes": node})
+    config = {"module": "keras.src.engine.functional", "class_name": "Functional",
+              "config": {"name": "model", "trainable": True, "layers": cfg_layers,
+                         "input_layers": [[l["name"], 0, 0] for l in layers if l["cls"] == "InputLayer"], "output_layers": [[n_, 0, 0] for n_ in outputs]}}
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        z.writestr("metadata.json", json.dumps({"keras_version": "2.13.1"}))
+        z.writestr("config.json", json.dumps(config))
+        z.writestr("model.weights.h5", w.tobytes())
+    return planted
+
+
+def run(seed, n, verbose=True, keras2=False):
   rng = random.Random(seed)
   ok = refused = 0
   fails = []
@@ -46,7 +92,10 @@ def run(seed, n, verbose=True):
               v = wr.standard_normal(p.shape).astype(np.float32)
               w[p.name] = (np.abs(v) + 0.5 if p.name.endswith("moving_variance") else v / np.sqrt(np.prod(p.shape[:-1])) if len(p.shape) >= 2 else v).astype(np.float32)
           path = os.path.join(tmp, "m.keras")
-          harness.save_weights_file(w, path, g)
+          if keras2:
+              w = write_keras2_archive(g, g.ndim == 1, path, wr)
+          else:
+              harness.save_weights_file(w, path, g)
           kfile = KF.KerasFileModel(path)
           gi = KI.graph_from_keras_config(kfile.config)
           wi = KI.weights_of_imported_graph(kfile, gi)
@@ -71,5 +120,6 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     seed, n = int(sys.argv[1]), int(sys.argv[2])
     t0 = time.time()
-    ok, refused, fails = run(seed, n)
-    print(f"==== archive round trip over random builder calls: {ok} ok, {refused} refused as the reference refuses them, {len(fails)} failed, in {time.time() - t0:.0f} s (seed {seed})")
+    keras2 = "--keras2" in sys.argv
+    ok, refused, fails = run(seed, n, keras2=keras2)
+    print(f"==== archive round trip over random builder calls{' (TF 2.x spelling)' if keras2 else ''}: {ok} ok, {refused} refused as the reference refuses them, {len(fails)} failed, in {time.time() - t0:.0f} s (seed {seed})")
