@@ -180,8 +180,8 @@ def stage1(tmp):
     np.savez(os.path.join(OUT, "planted.npz"), **planted)
 
 
-WEIGHT_NAMES = {"Conv": ("kernel", "bias"), "BatchNormalization": ("gamma", "beta", "moving_mean", "moving_variance"),
-                "ConvLSTM": ("kernel", "recurrent_kernel", "bias"), "Dense": ("kernel", "bias")}
+WEIGHT_NAMES = {"ConvLSTM": ("kernel", "recurrent_kernel", "bias"), "Conv": ("kernel", "bias"),
+                "BatchNormalization": ("gamma", "beta", "moving_mean", "moving_variance"), "Dense": ("kernel", "bias")}
 
 
 def stage2(tmp):

@@ -6,6 +6,7 @@ model.weights.h5 through h5lite) -> the archive alone back to a graph and weight
 
     python tools/fuzz_archives.py <seed> <n>          # ~6 configurations a second
     python tools/fuzz_archives.py <seed> <n> --keras2 # the archive as TF 2.13 - 2.15 would spell it for the reference's code (keras_view)
+    python tools/fuzz_archives.py <seed> <n> --h5     # the same model as a legacy whole-model .h5 (model_config attribute, weights by name)
 
 Build-authored test tooling (uses the oracle's interpreter: not part of the product path)."""
 import os
@@ -24,7 +25,7 @@ from ir_interp import run_graph
 import fuzz_models as FZ
 
 
-def write_keras2_archive(g, one_d, path, rng_np):
+def write_keras2_archive(g, one_d, path, rng_np, legacy=False):
     """The archive TF 2.13 - 2.15 would leave for builder graph `g`, in the reference's own spelling (tests/golden/make_keras_files.py
     `keras_view`: Activation('ReLU') as a serialised layer object, a * b as a TFOpLambda with its second operand in the call's kwargs,
     1x1 convs at padding='valid', Reshape + 5-D concatenate in front of a ConvLSTM, pairwise concatenates, auto-names, model.layers out
@@ -62,6 +63,26 @@ def write_keras2_archive(g, one_d, path, rng_np):
     config = {"module": "keras.src.engine.functional", "class_name": "Functional",
               "config": {"name": "model", "trainable": True, "layers": cfg_layers,
                          "input_layers": [[l["name"], 0, 0] for l in layers if l["cls"] == "InputLayer"], "output_layers": [[n_, 0, 0] for n_ in outputs]}}
+    if legacy:
+        # model.save('x.h5'): the configuration as the root attribute `model_config`, the weights under model_weights/<layer>/ by name
+        names = {"ConvLSTM": ("kernel", "recurrent_kernel", "bias"), "Conv": ("kernel", "bias"),
+                 "BatchNormalization": ("gamma", "beta", "moving_mean", "moving_variance"), "Dense": ("kernel", "bias")}
+        w = H5Writer()
+        w.set_attr("/", "model_config", json.dumps(config))
+        w.set_attr("/", "keras_version", "2.11.0")
+        w.set_attr("/", "backend", "tensorflow")
+        w.create_group("model_weights")
+        w.set_attr("model_weights", "layer_names", [l["name"].encode() for l in layers])
+        for l in layers:
+            w.create_group(f"model_weights/{l['name']}")
+            fam = next((v for k, v in names.items() if l["cls"].startswith(k)), ())
+            wn = [f"{l['name']}/{fam[i]}:0" for i in range(len(l["weights"]))]
+            if wn:
+                w.set_attr(f"model_weights/{l['name']}", "weight_names", [n_.encode() for n_ in wn])
+            for n_, (pname, arr) in zip(wn, l["weights"]):
+                w.create_dataset(f"model_weights/{l['name']}/{n_}", arr[0] if (one_d and arr.ndim == 4 and arr.shape[0] == 1) else arr)
+        w.save(path)
+        return planted
     with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
         z.writestr("metadata.json", json.dumps({"keras_version": "2.13.1"}))
         z.writestr("config.json", json.dumps(config))
@@ -69,7 +90,7 @@ def write_keras2_archive(g, one_d, path, rng_np):
     return planted
 
 
-def run(seed, n, verbose=True, keras2=False):
+def run(seed, n, verbose=True, keras2=False, legacy=False):
   rng = random.Random(seed)
   ok = refused = 0
   fails = []
@@ -91,9 +112,9 @@ def run(seed, n, verbose=True, keras2=False):
           for p in g.param_specs():
               v = wr.standard_normal(p.shape).astype(np.float32)
               w[p.name] = (np.abs(v) + 0.5 if p.name.endswith("moving_variance") else v / np.sqrt(np.prod(p.shape[:-1])) if len(p.shape) >= 2 else v).astype(np.float32)
-          path = os.path.join(tmp, "m.keras")
-          if keras2:
-              w = write_keras2_archive(g, g.ndim == 1, path, wr)
+          path = os.path.join(tmp, "m.h5" if legacy else "m.keras")
+          if keras2 or legacy:
+              w = write_keras2_archive(g, g.ndim == 1, path, wr, legacy)
           else:
               harness.save_weights_file(w, path, g)
           kfile = KF.KerasFileModel(path)
@@ -120,6 +141,6 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     seed, n = int(sys.argv[1]), int(sys.argv[2])
     t0 = time.time()
-    keras2 = "--keras2" in sys.argv
-    ok, refused, fails = run(seed, n, keras2=keras2)
-    print(f"==== archive round trip over random builder calls{' (TF 2.x spelling)' if keras2 else ''}: {ok} ok, {refused} refused as the reference refuses them, {len(fails)} failed, in {time.time() - t0:.0f} s (seed {seed})")
+    keras2, legacy = "--keras2" in sys.argv, "--h5" in sys.argv
+    ok, refused, fails = run(seed, n, keras2=keras2, legacy=legacy)
+    print(f"==== archive round trip over random builder calls{' (legacy whole-model .h5, TF 2.x spelling)' if legacy else ' (TF 2.x spelling)' if keras2 else ''}: {ok} ok, {refused} refused as the reference refuses them, {len(fails)} failed, in {time.time() - t0:.0f} s (seed {seed})")
