@@ -25,11 +25,13 @@ CONDA = "/opt/conda/bin/python3.9"
 
 CASES = [      # (file, decoder, constructor keywords, layout)
     ("unet_lstm_ag_ds.keras", "UNet", dict(model_width=4, model_depth=2, num_channels=1, lstm=1, ag=1, ds=1), "keras_counted"),
-    ("unetpp_named.keras", "UNetPP", dict(model_width=4, model_depth=2, num_channels=3, ds=1), "keras_named_k3"),
+    ("unetpp_keras3.keras", "UNetPP", dict(model_width=4, model_depth=2, num_channels=3, ds=1), "keras_counted_k3"),
     ("unet_ae_tf212.keras", "UNet", dict(model_width=4, model_depth=2, num_channels=3, ae=1, feature_number=12), "keras_tf212"),
     ("multires_legacy.h5", "MultiResUNet", dict(model_width=8, model_depth=1, num_channels=3, ag=1, alpha=1.0), "h5_model"),
     ("unet3p_weights_only.h5", "UNet3P", dict(model_width=4, model_depth=2, num_channels=3), "h5_weights"),
     ("unet1d.keras", "UNet1D", dict(length=64, model_depth=2, num_channel=2, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=1), "keras_counted"),
+    # auto-names of a FRESH process (conv2d, conv2d_1, ...): the same strings as the counted weight keys, which follow model.layers order
+    ("unet_fresh_names.keras", "UNet", dict(model_width=4, model_depth=2, num_channels=3, ag=1, ds=1), "keras_counted_fresh"),
     ("unet1d_lstm_ag.keras", "UNet1D", dict(length=64, model_depth=2, num_channel=1, model_width=4, kernel_size=3, problem_type="Regression", output_nums=1, ds=0, ag=1, lstm=1), "keras_counted"),
 ]
 
@@ -53,7 +55,8 @@ def keras_view(g, rng, one_d, name_offset=17):
         i = counters.get(cls, name_offset)
         counters[cls] = i + 1
         base = AUTO[cls]
-        return f"{base.replace('2d', '1d') if one_d else base}_{i}"
+        base = base.replace('2d', '1d') if one_d else base
+        return base if i == 0 else f"{base}_{i}"          # (a fresh process: conv2d, conv2d_1, ... - the strings of the counted weight keys, in CREATION order)
 
     def emit(cls, name, cfg, inbound, weights=()):
         layers.append(dict(name=name, cls=ONE_D.get(cls, cls) if one_d else cls, config=dict(cfg, name=name), inbound=list(inbound), weights=list(weights)))
@@ -124,7 +127,8 @@ def keras_view(g, rng, one_d, name_offset=17):
         elif n.kind == "mul":
             # `skip_connection * resampler` (unet_variants.py:81): TF 2.x wraps the operator in a TFOpLambda layer; the layouts that
             # carry Keras 3's spelling get its Multiply operation instead (stage 2 looks at the class)
-            layer_of[i] = emit("TFOpLambda", f"tf.math.multiply_{counters.setdefault('TFOpLambda', 0)}", dict(function="math.multiply"), ins)
+            k_ = counters.setdefault("TFOpLambda", 0)
+            layer_of[i] = emit("TFOpLambda", "tf.math.multiply" if k_ == 0 else f"tf.math.multiply_{k_}", dict(function="math.multiply"), ins)
             counters["TFOpLambda"] += 1
         elif n.kind == "convlstm":
             Hi, Wi, Ci = g.nodes[n.inputs[0]].shape
@@ -160,7 +164,7 @@ def stage1(tmp):
         else:
             w, d = kw.pop("model_width"), kw.pop("model_depth")
             g = segamd.unet_model_builder(dec, 32, 32, w, d, train_mode="from_scratch", **kw).graph()
-        layers, outputs = keras_view(g, np.random.default_rng(100 + ci), one_d)
+        layers, outputs = keras_view(g, np.random.default_rng(100 + ci), one_d, name_offset=0 if layout.endswith("_fresh") else 17)
         for l in layers:
             keys = []
             for wi, (pname, w) in enumerate(l["weights"]):
@@ -197,16 +201,16 @@ def stage2(tmp):
         def node(l):
             if not l["inbound"]:
                 return []
-            if l["cls"] == "TFOpLambda" and layout != "keras_named_k3":          # TF 2.x: the second operand travels in the call's kwargs
+            if l["cls"] == "TFOpLambda" and layout != "keras_counted_k3":          # TF 2.x: the second operand travels in the call's kwargs
                 a_, b_ = l["inbound"]
                 return [[a_, 0, 0, {"y": [b_, 0, 0], "name": None}]]
-            if layout == "keras_named_k3":              # Keras 3 spelling
+            if layout == "keras_counted_k3":              # Keras 3 spelling
                 kts = [{"class_name": "__keras_tensor__", "config": {"shape": [None], "dtype": "float32", "keras_history": [n, 0, 0]}} for n in l["inbound"]]
                 return [{"args": [kts if len(kts) > 1 else kts[0]], "kwargs": {}}]
             return [[[n, 0, 0, {}] for n in l["inbound"]]]
 
         for l in layers:
-            if l["cls"] == "TFOpLambda" and layout == "keras_named_k3":          # Keras 3: the operator is an operation of class Multiply
+            if l["cls"] == "TFOpLambda" and layout == "keras_counted_k3":          # Keras 3: the operator is an operation of class Multiply
                 l["cls"], l["config"] = "Multiply", {"name": l["name"]}
         cfg_layers = [{"module": "keras.layers", "class_name": l["cls"], "config": dict(l["config"], trainable=True, dtype="float32"),
                        "registered_name": None, "name": l["name"], "inbound_nodes": node(l)} for l in layers]
@@ -214,7 +218,7 @@ def stage2(tmp):
         config = {"module": "keras.src.engine.functional", "class_name": "Functional",
                   "config": {"name": "model", "trainable": True, "layers": cfg_layers,
                              "input_layers": [[l["name"], 0, 0] for l in layers if l["cls"] == "InputLayer"],
-                             "output_layers": outs[0] if (layout == "keras_named_k3" and len(outs) == 1) else outs},
+                             "output_layers": outs[0] if (layout == "keras_counted_k3" and len(outs) == 1) else outs},
                   "registered_name": "Functional", "build_config": {"input_shape": None}}
         path = os.path.join(OUT, case["file"])
         if layout.startswith("keras"):
@@ -231,7 +235,7 @@ def stage2(tmp):
                     else:
                         used[base] = 0
                         counted = base
-                    key = l["name"] if layout == "keras_named_k3" else counted
+                    key = counted
                     g = f.create_group(f"{top}/{key}")
                     holder = g
                     g.create_group("vars")

@@ -191,3 +191,19 @@ def test_damaged_checkpoints_raise_kerasfileerror(tmp_path):
             except KF.KerasFileError:
                 outcomes.add("refused")
         assert "refused" in outcomes and outcomes <= {"ok", "refused"}, (fname, outcomes)          # (a zip member's CRC catches every flip)
+
+
+def test_fresh_process_auto_names_do_not_fool_the_weight_lookup():
+    """In a fresh process Keras names its layers conv2d, conv2d_1, ... in CREATION order and files their weights under conv2d, conv2d_1,
+    ... in model.layers order - the same strings, another assignment.  Reading the keys as layer names would put weights into the wrong
+    layers of equal shape without an error; the counted reading must win."""
+    fname, dec, kw, layout = next(c for c in CASES if c[0] == "unet_fresh_names.keras")
+    m = KF.KerasFileModel(os.path.join(FILES, fname))
+    names = {l.name for l in m.layers}
+    keys = set(m.h5["layers"].keys())
+    assert {"conv2d", "conv2d_1", "batch_normalization", "batch_normalization_1"} <= names & keys          # the ambiguity is real in this file
+    by_name_differs = [l.name for l in m.layers if l._paths and not l._paths[0].startswith(f"layers/{l.name}/")]
+    assert by_name_differs                                 # ... and the two readings disagree for some layers
+    got = KF.load_keras_file(os.path.join(FILES, fname), _graph(dec, kw))
+    want = _planted(fname)
+    assert set(got) == set(want) and all(np.array_equal(got[k].reshape(v.shape), v) for k, v in want.items())

@@ -109,7 +109,7 @@ def test_layers_outside_the_hot_path_shared_layers_and_loose_dense_layers_are_re
 
 
 def test_both_spellings_of_the_input_shape_and_of_leaky_relu():
-    cfg = _config_of("unetpp_named.keras")
+    cfg = _config_of("unetpp_keras3.keras")
     ic = _layer(cfg, "InputLayer")["config"]
     ic["batch_shape"] = ic.pop("batch_input_shape")          # Keras 3
     leaky = [l for l in cfg["config"]["layers"] if l["class_name"] == "Activation" and isinstance(l["config"]["activation"], dict)
@@ -221,7 +221,7 @@ def test_mangled_configurations_raise_kerasimporterror():
 
 
 def test_load_model_needs_no_gpu_to_read_the_file_and_the_engine_still_has_no_cpu_fallback():
-    m = segamd.load_model(os.path.join(FILES, "unetpp_named.keras"))
+    m = segamd.load_model(os.path.join(FILES, "unetpp_keras3.keras"))
     assert not m.built and len(m._weights_at_build) == 60 and m.graph.nodes[m.graph.inputs[0]].shape == (32, 32, 3)
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -19,8 +19,9 @@ files this reader will see, held against the captured weights by `tests/test_tf_
   * `.keras` archive (Keras "v3" saving format, TF >= 2.12): a zip of `config.json` (the functional model: `config.layers[*]` with
     `class_name`, `name`, `inbound_nodes`; `config.output_layers`), `metadata.json` and `model.weights.h5` whose groups are
     `layers/<key>/vars/<i>` - sub-objects of a layer one level down (`layers/conv_lstm2d/cell/vars/0..2`) - where `<key>` is the
-    layer's name in newer Keras versions and the snake-cased class name with a running counter in model.layers order (`conv2d`,
-    `conv2d_1`, ...) in older ones; TF 2.12 called the top group `_layer_checkpoint_dependencies`.  All three are tried.
+    snake-cased CLASS name with a running counter in model.layers order (`conv2d`, `conv2d_1`, ...: Keras does not use the layers'
+    own names there, on purpose); TF 2.12 called the top group `_layer_checkpoint_dependencies`.  A file keyed by layer names is
+    read too, when it has no counted keys.
   * legacy whole-model HDF5 (`model.save('x.h5')`): root attribute `model_config` (the same JSON), group `model_weights` with the
     attribute `layer_names`, per layer a group with the attribute `weight_names` listing its datasets in `get_weights()` order.
   * legacy weights-only HDF5 (`model.save_weights('x.h5')`) and `.weights.h5`: the weight groups alone; the layer graph has to come
@@ -202,16 +203,20 @@ class KerasFileModel:
         if top is not None:                                              # the .keras / .weights.h5 layout
             g = h5[top]
             keys = set(g.keys())
-            by_layer_name = all(l.name in keys for l in self.layers if l.__class__.__name__ != "InputLayer")
-            used: Dict[str, int] = {}
+            # Keras addresses the layers of the `layers` container by the snake-cased CLASS name with a running counter in
+            # model.layers order - deliberately not by `layer.name` ("names are usually autogenerated and thus not reproducible",
+            # saving_lib).  In a fresh process the auto-names ARE conv2d, conv2d_1, ... - the same strings in another order - so
+            # the counted reading must win whenever it fits; the by-name reading is only for files that have no counted keys.
+            counted_of, used = {}, {}
             for layer in self.layers:
                 base = _snake(layer.__class__.__name__)
-                if base in used:
-                    used[base] += 1
-                    counted = f"{base}_{used[base]}"
-                else:
-                    used[base] = 0
-                    counted = base
+                used[base] = used.get(base, -1) + 1
+                counted_of[id(layer)] = base if used[base] == 0 else f"{base}_{used[base]}"
+            weightless = ("InputLayer",)
+            counted_ok = all(counted_of[id(l)] in keys for l in self.layers if l.__class__.__name__ not in weightless)
+            by_layer_name = not counted_ok and all(l.name in keys for l in self.layers if l.__class__.__name__ not in weightless)
+            for layer in self.layers:
+                counted = counted_of[id(layer)]
                 key = layer.name if by_layer_name else counted
                 if key not in keys:
                     if layer.__class__.__name__ == "InputLayer":

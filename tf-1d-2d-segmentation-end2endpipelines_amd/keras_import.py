@@ -28,7 +28,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .graph import Graph, Sym
-from .keras_file import KerasFileError, KerasFileModel, _refs
+from .keras_file import KerasFileError, KerasFileModel, _refs, _snake
 
 
 class KerasImportError(ValueError):
@@ -396,7 +396,7 @@ def config_from_graph(g: Graph) -> Tuple[dict, List[Tuple[str, str, List[str]]]]
 
 def save_model(graph: Graph, weights: Dict[str, np.ndarray], path: str):
     """model.save('x.keras') / ModelCheckpoint (2D/Train.py:375): a `.keras`-layout archive - config.json in Keras 2's spelling,
-    metadata.json, model.weights.h5 with `layers/<layer name>/vars/<i>` (a ConvLSTM's under `cell/`) - of a layer graph and its weights
+    metadata.json, model.weights.h5 with `layers/<class name + counter>/vars/<i>` as Keras addresses them (a ConvLSTM's under `cell/`) - of a layer graph and its weights
     (structural names).  `segamd.load_model` / `SegModel.load_weights` read it back; laid out as Keras documents the format, not yet
     opened by a Keras installation (none here)."""
     import json
@@ -405,10 +405,14 @@ def save_model(graph: Graph, weights: Dict[str, np.ndarray], path: str):
     cfg, holders = config_from_graph(graph)
     w = H5Writer()
     w.create_group("vars")
-    for lc in cfg["config"]["layers"]:
-        w.create_group(f"layers/{lc['name']}/vars")
+    key_of, used = {}, {}
+    for lc in cfg["config"]["layers"]:                   # Keras' own addressing: snake-cased class name + counter in model.layers order
+        base = _snake(lc["class_name"])
+        used[base] = used.get(base, -1) + 1
+        key_of[lc["name"]] = base if used[base] == 0 else f"{base}_{used[base]}"
+        w.create_group(f"layers/{key_of[lc['name']]}/vars")
     for lname, sub, pnames in holders:
-        base = f"layers/{lname}/{sub + '/' if sub else ''}vars"
+        base = f"layers/{key_of[lname]}/{sub + '/' if sub else ''}vars"
         w.create_group(base)
         for i, pn in enumerate(pnames):
             if pn not in weights:

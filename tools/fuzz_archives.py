@@ -36,7 +36,7 @@ def write_keras2_archive(g, one_d, path, rng_np, legacy=False):
     import make_keras_files as MK
     from segamd.h5lite import H5Writer
     from segamd.keras_file import _snake
-    layers, outputs = MK.keras_view(g, rng_np, one_d)
+    layers, outputs = MK.keras_view(g, rng_np, one_d, name_offset=0 if rng_np.random() < 0.5 else 17)      # (half of them with a fresh process's auto-names)
     planted = {}
     w = H5Writer()
     w.create_group("vars")
