@@ -260,3 +260,17 @@ def test_random_builder_calls_survive_the_archive_round_trip():
     ok, refused, fails = FA.run(5, 40, verbose=False)
     assert not fails, fails[:3]
     assert ok >= 30
+
+
+def test_a_dropout_that_drops_is_refused():
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    pool = _layer(cfg, "MaxPooling2D")
+    name = pool["name"]
+    pool["class_name"], pool["config"] = "Dropout", {"name": name, "rate": 0.0}
+    # (a rate-0 Dropout in place of a pool changes the shapes downstream: what matters here is that IT is accepted and a later layer objects)
+    with pytest.raises(KI.KerasImportError) as e:
+        KI.graph_from_keras_config(cfg)
+    assert name not in str(e.value).split(":")[0]
+    pool["config"]["rate"] = 0.3
+    with pytest.raises(KI.KerasImportError, match="no dropout"):
+        KI.graph_from_keras_config(cfg)

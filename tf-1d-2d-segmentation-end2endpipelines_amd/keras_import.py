@@ -14,7 +14,7 @@ over the channel axis; Activation / ReLU / LeakyReLU / Softmax; MaxPooling (stri
 Concatenate over channels (nested concatenates are flattened - `Concat_Block` folds pairwise); Add; Multiply - also as the operator
 `a * b`, TF 2.x's TFOpLambda of math.multiply (Attention_Block); ConvLSTM1D/2D on a
 length-1 sequence (the Reshape in front of it is absorbed); Flatten -> Dense -> Dense -> Reshape as the autoencoder bottleneck;
-Dropout-family layers and shape-preserving Reshapes as identity (inference semantics: the engine has no dropout, and says so).
+Dropout-family layers of rate 0 and shape-preserving Reshapes as identity (a dropout that drops is refused: the engine has none).
 Anything else - 'valid' padding, dilation, a Dense that is not part of that bottleneck, Lambda, shared layers, nested models - raises
 KerasImportError naming the layer: a model the engine would compute differently is refused, not approximated.
 
@@ -214,6 +214,9 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
             need(srcs[0] in seq, name, "its input is not a length-1 sequence (Reshape((1, ...)) in front of it)")
             out = g.convlstm(xs[0], int(c["filters"]), k1(c["kernel_size"]), name)
         elif cls in ("Dropout", "SpatialDropout1D", "SpatialDropout2D", "Identity"):
+            # (the UNet-family builders of the reference have no dropout; a checkpoint that has would TRAIN differently here - the engine
+            # has none - while predicting the same: refused rather than imported with different training semantics)
+            need(cls == "Identity" or float(c.get("rate", 0.0) or 0.0) == 0.0, name, f"rate={c.get('rate')} (the engine has no dropout: the model would train differently)")
             out = xs[0]
         elif cls == "Flatten":
             H, W, C = xs[0].shape
