@@ -274,3 +274,12 @@ def test_a_dropout_that_drops_is_refused():
     pool["config"]["rate"] = 0.3
     with pytest.raises(KI.KerasImportError, match="no dropout"):
         KI.graph_from_keras_config(cfg)
+
+
+def test_a_frozen_layer_is_refused():
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    l = _layer(cfg, "BatchNormalization")
+    l["config"]["trainable"] = False
+    with pytest.raises(KI.KerasImportError, match="frozen layer") as e:
+        KI.graph_from_keras_config(cfg)
+    assert l["name"] in str(e.value)
