@@ -283,3 +283,14 @@ def test_a_frozen_layer_is_refused():
     with pytest.raises(KI.KerasImportError, match="frozen layer") as e:
         KI.graph_from_keras_config(cfg)
     assert l["name"] in str(e.value)
+
+
+def test_regularisers_and_constraints_are_refused():
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    l = _layer(cfg, "Conv2D")
+    l["config"]["kernel_regularizer"] = {"class_name": "L2", "config": {"l2": 0.01}}
+    with pytest.raises(KI.KerasImportError, match="kernel_regularizer"):
+        KI.graph_from_keras_config(cfg)
+    l["config"]["kernel_regularizer"] = None                  # (what get_config() writes when there is none)
+    l["config"]["bias_constraint"] = None
+    KI.graph_from_keras_config(cfg)

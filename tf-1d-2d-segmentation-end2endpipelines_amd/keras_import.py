@@ -139,6 +139,8 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
         xs = [sym[s] for s in srcs]
         k1 = (lambda v: _ints(v, ndim) if ndim == 2 else _ints(v, 1)[0])
         out: Optional[Sym]
+        extra = [k for k, v in c.items() if k.endswith(("_regularizer", "_constraint")) and v is not None]
+        need(not extra, name, f"{', '.join(extra)} set (the engine's loss and update have neither regularisers nor constraints)")
         if cls.startswith(("Conv", "BatchNormalization", "Dense")):
             # (train_mode='pretrained_encoder' freezes the encoder, unet_variants.py:1058: the engine trains every parameter it holds)
             need(c.get("trainable", True) is not False, name, "trainable=False (a frozen layer: the engine would train it)")
