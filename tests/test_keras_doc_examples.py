@@ -6,6 +6,7 @@ tests/test_oracle_primitives.py are what the oracle is pinned by; the `-m gpu` h
 Sources (docstring examples of the TF 2.x API docs):
   tf.keras.layers.MaxPooling2D   - pool (2, 2), strides (2, 2), 'valid' on a 3 x 4 image
   tf.keras.layers.UpSampling2D   - size (1, 2) on arange(12).reshape(2, 2, 1, 3)
+  tf.keras.layers.MaxPooling1D   - pool_size 2, strides 2, 'valid' on [1, 2, 3, 4, 5]
   tf.keras.layers.LeakyReLU      - default alpha 0.3 and alpha = 0.1 on [-3, -1, 0, 2]
   tf.keras.layers.ReLU / activations.relu, activations.sigmoid, activations.tanh, activations.hard_sigmoid (0.2 x + 0.5)
   tf.keras.layers.Concatenate / Add - the documented shapes / values
@@ -33,6 +34,8 @@ def test_oracle_reproduces_the_documented_examples():
     T = torch.from_numpy
     assert torch.equal(K.maxpool(T(MAXPOOL_X), (2, 2)), T(MAXPOOL_Y))          # the odd third row is dropped ('valid')
     assert torch.equal(K.upsample(T(UPS_X), (1, 2), "nearest"), T(UPS_Y))
+    # tf.keras.layers.MaxPooling1D docs: x = [1, 2, 3, 4, 5], pool_size 2, strides 2, 'valid' -> [2, 4] (the odd last sample is dropped)
+    assert K.maxpool(T(np.arange(1, 6, dtype=np.float32).reshape(1, 1, 5, 1)), (1, 2)).reshape(-1).tolist() == [2.0, 4.0]
     assert K.activation(T(ACT_X), "leaky_relu", K.LEAKY_ALPHA).tolist() == pytest.approx([-0.9, -0.3, 0.0, 2.0])
     assert K.activation(T(ACT_X), "leaky_relu", 0.1).tolist() == pytest.approx([-0.3, -0.1, 0.0, 2.0])
     assert K.activation(T(ACT_X), "relu").tolist() == [0.0, 0.0, 0.0, 2.0]
