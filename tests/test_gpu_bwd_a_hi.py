@@ -1,0 +1,35 @@
+"""MI355X, EXPERIMENT (branch r6-2mfma-backward, written without GPU minutes at the end of round 5 - run it first thing): the halo-tile data
+gradient with the incoming gradient read as its hi half (SEG_VARIANT_A_HI: two MFMAs per product).  What it must show before anything
+else is built on it: same result as the three-MFMA launch to ~2^-11 of dz (elementwise, unbiased), nothing else changed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import gpu_util as U
+
+ffi, M = U.ffi, U.M
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 32, 32, 64, 64), (1, 64, 64, 32, 17), (2, 16, 32, 40, 96)])
+def test_hi_only_gradient_operand_matches_the_three_mfma_launch(N, H, W, cin, cout):
+    torch.manual_seed(0)
+    x = torch.randn(N, H, W, cin)
+    kern = (np.random.default_rng(0).standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    tile = (256, 64 if cout > 32 else 32)
+    full, _s, pad0 = U.igemm_conv([x], kern, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=3)
+    half, _s, pad1 = U.igemm_conv([x], kern, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=3 | ffi.SEG_VARIANT_A_HI)
+    ref = U.ref_conv([x], kern, None, "conv", (1, 1))
+    e_full = float((full - ref).abs().max() / ref.abs().max())
+    e_half = float((half - ref).abs().max() / ref.abs().max())
+    print(f"three MFMAs {e_full:.1e}, two MFMAs (A operand hi only) {e_half:.1e}")
+    assert pad0 == 0.0 and pad1 == 0.0
+    assert e_full < 2e-5
+    assert 2e-5 < e_half < 2e-3          # ~2^-11 per product, averaged over the contraction: present, and no more than that
+    # unbiased: the mean signed difference is far below the mean absolute difference
+    d = (half - full)
+    assert abs(float(d.mean())) < 0.1 * float(d.abs().mean())
