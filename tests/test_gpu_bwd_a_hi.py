@@ -33,3 +33,21 @@ def test_hi_only_gradient_operand_matches_the_three_mfma_launch(N, H, W, cin, co
     # unbiased: the mean signed difference is far below the mean absolute difference
     d = (half - full)
     assert abs(float(d.mean())) < 0.1 * float(d.abs().mean())
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,kind", [(2, 32, 32, 64, 64, "conv"), (2, 16, 32, 40, 96, "conv"), (2, 16, 16, 64, 64, "convT")])
+def test_hi_only_input_operand_in_the_weight_gradient(N, H, W, cin, cout, kind):
+    torch.manual_seed(1)
+    x = torch.randn(N, H, W, cin)
+    k = (3, 3) if kind == "conv" else (4, 4)
+    s = (1, 1) if kind == "conv" else (2, 2)
+    kshape = (k[0], k[1], cin, cout) if kind == "conv" else (k[0], k[1], cout, cin)
+    Ho, Wo = (H, W) if kind == "conv" else (2 * H, 2 * W)
+    dz = torch.randn(N, Ho, Wo, cout)
+    full = U.igemm_wgrad([x], dz, kshape, kind, s, 2, None, None, f32=True)
+    half = U.igemm_wgrad([x], dz, kshape, kind, s, 2 | ffi.SEG_VARIANT_A_HI, None, None, f32=True)
+    e = float(np.abs(half - full).max() / np.abs(full).max())
+    print(f"weight gradient, input operand hi only against three MFMAs: {e:.1e}")
+    assert 1e-6 < e < 2e-3
+    d = half - full
+    assert abs(float(d.mean())) < 0.1 * float(np.abs(d).mean())

@@ -406,6 +406,8 @@ class ConvOp(Op):
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = variant
+        if F.BWD_A_HI and not f16 and variant == 2 and self.n_rows > 32:
+            wg.variant |= _ffi.SEG_VARIANT_A_HI          # (experiment, == SEG_VARIANT_IN_HI: the activations as their hi half in the weight gradient)
         # the gradient buffer is cleared once per step (backward() / the side stream after the optimiser), and with
         # splitk == 1 every tile has one writer: it may store instead of read-modify-write
         wg.overwrite = 1 if (F.WGRAD_OVERWRITE and variant == 2 and sk == 1) else 0
