@@ -68,6 +68,11 @@ typedef struct seg_geom {
  * inference-mode BatchNormalization: with ep_scale = gamma / sqrt(var + eps) and bias = beta + (b - mean) * ep_scale
  * (seg_bn_fold_inference) one launch is the whole Conv_Block of unet_variants.py:7-14 as model.predict runs it
  * (2DCNN/Test.py:153,161).                                                                                      */
+#define SEG_VARIANT_A_HI 0x1000  /* OR-ed into `variant` of seg_igemm_fwd_f32 (variant 3 only): the A operand - the incoming gradient of a
+                                    data-gradient launch - is read as its hi half, two MFMAs per product instead of three (the weight
+                                    operand stays whole: a b ~= ah bh + ah bl / 2048); never for a forward pass                     */
+#define SEG_VARIANT_IN_HI 0x1000 /* OR-ed into `variant` of seg_igemm_wgrad_f32 (variant 2, tiles of 64 output channels): the input operand
+                                    (the activations) is read as its hi half - two MFMAs per product, dz stays whole             */
 typedef struct seg_igemm_fwd_args {
   seg_geom g;
   int32_t nseg;

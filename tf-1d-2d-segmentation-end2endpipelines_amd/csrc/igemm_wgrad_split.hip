@@ -24,6 +24,15 @@ __device__ __forceinline__ h8 trfrag(const unsigned char* ad, int rstride4) {
     ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACCL, 0, 0, 0);         \
   } while (0)
 
+// EXPERIMENT (SEG_VARIANT_IN_HI, never validated): the INPUT operand of the weight gradient read as its hi half - a b ~= ah bh + al bh / 2048
+// with a = dz whole, b = the activations' hi half.  The lo fragment of every tap's halo read goes (5 of the 12 fragment reads per K
+// block of the 3x3 kernel) and a third of the MFMAs; the activations lose 2^-11, elementwise.
+#define SEG_MMA_SPLIT_BHI(ACC, ACCL, AH, AL, BH)                                  \
+  do {                                                                            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);           \
+    ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, ACCL, 0, 0, 0);         \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 // per-tap kernel (1x1, strided, 1-D convolutions, images the halo patches do not tile): register-staged double buffer,
 // 32 pixels per step.  LDS per operand: a hi tile and a lo tile [32 pixels][BM (BN) halves], rows padded by 64 B.
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_split_kernel(const seg_ige
 // meet in LDS at the end, added in wave order) - 9 MFMA triples per wave and patch instead of 18; a transposed-conv class gives
 // each wave one of its four taps.
 // ---------------------------------------------------------------------------------------------------------
-template <int C, bool TC, bool NARROW = false>
+template <int C, bool TC, bool NARROW = false, bool BHI = false>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const seg_igemm_wgrad_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int R = 64 / C, HC = C + 2, HROWS = (R + 2) * HC;
@@ -389,8 +398,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
         if (s == 4 && (kb >> 1) != TH) continue;
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
         const int off = hb * 128 + offB[hb & 3];
-        const h8 bh = trfrag(Is + off, 4 * 128), bl = trfrag(Is + (off ^ 16), 4 * 128);
-        SEG_MMA_SPLIT(acc[s], accl[s], ah, al, bh, bl);
+        const h8 bh = trfrag(Is + off, 4 * 128);
+        if constexpr (BHI) {
+          SEG_MMA_SPLIT_BHI(acc[s], accl[s], ah, al, bh);
+        } else {
+          const h8 bl = trfrag(Is + (off ^ 16), 4 * 128);
+          SEG_MMA_SPLIT(acc[s], accl[s], ah, al, bh, bl);
+        }
       }
     }
   };
@@ -412,8 +426,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // wave-uniform, run time
         const int swz = (((hb & 3) + jr) >> 1) & 1;
         const int off = (hb + jr) * 128 + (((2 * grp) ^ swz) << 4) + sub;
-        const h8 bh = trfrag(Is + off, 4 * 128), bl = trfrag(Is + (off ^ 16), 4 * 128);
-        SEG_MMA_SPLIT(acc[s], accl[s], ah, al, bh, bl);
+        const h8 bh = trfrag(Is + off, 4 * 128);
+        if constexpr (BHI) {
+          SEG_MMA_SPLIT_BHI(acc[s], accl[s], ah, al, bh);
+        } else {
+          const h8 bl = trfrag(Is + (off ^ 16), 4 * 128);
+          SEG_MMA_SPLIT(acc[s], accl[s], ah, al, bh, bl);
+        }
       }
     }
   };
@@ -517,6 +536,13 @@ template __global__ void igemm_wgrad_halo_split_kernel<8, false, true>(const seg
 template __global__ void igemm_wgrad_halo_split_kernel<32, true, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<16, true, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<8, true, true>(const seg_igemm_wgrad_args);
+// input operand as its hi half (experiment): the 3x3 layers and the per-class transposed-conv form, 64-channel tiles
+template __global__ void igemm_wgrad_halo_split_kernel<32, false, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, false, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, false, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<32, true, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, true, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, true, false, true>(const seg_igemm_wgrad_args);
 
 // ---------------------------------------------------------------------------------------------------------
 // Conv2DTranspose(4x4, stride 2), parity mode, two sub-pixel classes per block (the class row py: classes (py, 0) and (py, 1);
@@ -529,7 +555,7 @@ template __global__ void igemm_wgrad_halo_split_kernel<8, true, true>(const seg_
 // fragments and the three column shifts of its input row (10 fragment reads) for 4 MFMA triples per K block: dx = 0 feeds
 // both classes.  Per MFMA: 0.83 fragment reads instead of 1.0, 25 KB of LDS-DMA per 32 px and class pair instead of 2 x 16.5 KB.
 // ---------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool BHI = false>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(const seg_igemm_wgrad_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PX = 32, R = PX / C, HC = C + 2, HROWS = (R + 1) * HC;
@@ -679,13 +705,21 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
       // tap row iy reads halo row yy + 1 - iy for either class row (dy = {0,-1} + py, halo row 0 = input row y0 - 1 + py)
       const int hb0 = (yy + 1 - IY) * HC + xx0 + 1;                  // halo row of pixel 0 of this K block at dx = 0
       const int om = (hb0 - 1) * 128 + offB[(hb0 - 1) & 3], oz = hb0 * 128 + offB[hb0 & 3], op = (hb0 + 1) * 128 + offB[(hb0 + 1) & 3];
-      const h8 bzh = trfrag(Is + oz, 4 * 128), bzl = trfrag(Is + (oz ^ 16), 4 * 128);
-      SEG_MMA_SPLIT(acc[0], accl[0], a0h, a0l, bzh, bzl);
-      SEG_MMA_SPLIT(acc[3], accl[3], a1h, a1l, bzh, bzl);
-      const h8 bmh = trfrag(Is + om, 4 * 128), bml = trfrag(Is + (om ^ 16), 4 * 128);
-      SEG_MMA_SPLIT(acc[1], accl[1], a0h, a0l, bmh, bml);
-      const h8 bph = trfrag(Is + op, 4 * 128), bpl = trfrag(Is + (op ^ 16), 4 * 128);
-      SEG_MMA_SPLIT(acc[2], accl[2], a1h, a1l, bph, bpl);
+      if constexpr (BHI) {
+        const h8 bzh = trfrag(Is + oz, 4 * 128), bmh = trfrag(Is + om, 4 * 128), bph = trfrag(Is + op, 4 * 128);
+        SEG_MMA_SPLIT_BHI(acc[0], accl[0], a0h, a0l, bzh);
+        SEG_MMA_SPLIT_BHI(acc[3], accl[3], a1h, a1l, bzh);
+        SEG_MMA_SPLIT_BHI(acc[1], accl[1], a0h, a0l, bmh);
+        SEG_MMA_SPLIT_BHI(acc[2], accl[2], a1h, a1l, bph);
+      } else {
+        const h8 bzh = trfrag(Is + oz, 4 * 128), bzl = trfrag(Is + (oz ^ 16), 4 * 128);
+        SEG_MMA_SPLIT(acc[0], accl[0], a0h, a0l, bzh, bzl);
+        SEG_MMA_SPLIT(acc[3], accl[3], a1h, a1l, bzh, bzl);
+        const h8 bmh = trfrag(Is + om, 4 * 128), bml = trfrag(Is + (om ^ 16), 4 * 128);
+        SEG_MMA_SPLIT(acc[1], accl[1], a0h, a0l, bmh, bml);
+        const h8 bph = trfrag(Is + op, 4 * 128), bpl = trfrag(Is + (op ^ 16), 4 * 128);
+        SEG_MMA_SPLIT(acc[2], accl[2], a1h, a1l, bph, bpl);
+      }
     }
   };
   auto run = [&](auto iyc) {
@@ -736,6 +770,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
 template __global__ void igemm_wgrad_halo_split_tc2_kernel<32>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_tc2_kernel<16>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_tc2_kernel<8>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<32, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<16, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<8, true>(const seg_igemm_wgrad_args);
 
 }  // namespace
 
@@ -762,6 +799,7 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
     // transposed conv whose taps follow the class-pair table: both classes of a class row per block
     static const char* tc2_env = std::getenv("SEG_WGRAD_TC2");
     const bool tc2 = !narrow && seg_wgrad_halo_class_groups(&a->g) == 2 && (tc2_env == nullptr || std::atoi(tc2_env) != 0);
+    const bool in_hi = !narrow && (a->variant & SEG_VARIANT_IN_HI) != 0;       // experiment: the input operand as its hi half (64-channel tiles)
     if (narrow && a->g.ncls == 1) {
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false, true>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false, true>), grid, dim3(256), lds, st, *a);
@@ -770,11 +808,24 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true, true>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true, true>), grid, dim3(256), lds, st, *a);
       else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true, true>), grid, dim3(256), lds, st, *a);
+    } else if (tc2 && in_hi) {
+      dim3 grid2(grid.x, 2, grid.z);
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<32, true>), grid2, dim3(256), (size_t)2 * (16384 + 9 * 1024), st, *a);
+      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<16, true>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<8, true>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
     } else if (tc2) {
       dim3 grid2(grid.x, 2, grid.z);
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<32>), grid2, dim3(256), (size_t)2 * (16384 + 9 * 1024), st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<16>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
       else hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<8>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
+    } else if (in_hi && a->g.ncls == 1) {
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false, false, true>), grid, dim3(256), lds, st, *a);
+      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false, false, true>), grid, dim3(256), lds, st, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, false, false, true>), grid, dim3(256), lds, st, *a);
+    } else if (in_hi) {
+      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true, false, true>), grid, dim3(256), lds, st, *a);
+      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true, false, true>), grid, dim3(256), lds, st, *a);
+      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true, false, true>), grid, dim3(256), lds, st, *a);
     } else if (a->g.ncls == 1) {
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false>), grid, dim3(256), lds, st, *a);
