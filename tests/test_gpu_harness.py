@@ -365,10 +365,14 @@ def test_nonfinite_counter_is_read_one_step_late_without_joining_the_side_stream
     m.train_step = real_step
     assert hist["nonfinite_grads"] == [11.0] and m.grad_target == 512.0
     # fit(): back-off on a skipped step, growth after a run of clean ones
-    H.LOSS_SCALE_GROWTH_INTERVAL, keep = 3, H.LOSS_SCALE_GROWTH_INTERVAL
+    keep = m.loss_scale_growth_interval
     try:
         m.grad_target = m.grad_target_max / 4          # (the parity mode's default target is 32, the throughput mode's 1024)
-        H.fit(m, [(x, t)] * 8, epochs=1)
+        H.fit(m, [(x, t)] * 8, epochs=1, loss_scale_growth_interval=3)
+        assert m.loss_scale_growth_interval == 3
         assert m.grad_target_max / 4 < m.grad_target <= m.grad_target_max
+        m.loss_scale_growth_interval = 5               # a value set on the model survives a fit() that does not name one
+        H.fit(m, [(x, t)], epochs=1)
+        assert m.loss_scale_growth_interval == 5
     finally:
-        H.LOSS_SCALE_GROWTH_INTERVAL = keep
+        m.loss_scale_growth_interval = keep

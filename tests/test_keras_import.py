@@ -102,6 +102,34 @@ def test_layers_outside_the_hot_path_shared_layers_and_loose_dense_layers_are_re
     _layer(cfg, "Flatten")["class_name"] = "Dropout"          # a Dense on an unflattened tensor
     with pytest.raises(KI.KerasImportError, match="outside the Flatten -> Dense -> Dense -> Reshape bottleneck"):
         KI.graph_from_keras_config(cfg)
+    # a Flatten / Dense that is a model output, or that something other than the next link of the bottleneck reads, has no node of
+    # its own: importing it would return the tensor in front of the Flatten and drop the Dense weights (advisor, round 5)
+    cfg = _config_of("unet_ae_tf212.keras")
+    dense = [l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Dense"]
+    cfg["config"]["output_layers"] = [[dense[0], 0, 0]]
+    with pytest.raises(KI.KerasImportError, match="is a model output"):
+        KI.graph_from_keras_config(cfg)
+    cfg = _config_of("unet_ae_tf212.keras")
+    flat = _layer(cfg, "Flatten")["name"]
+    cfg["config"]["output_layers"] = cfg["config"]["output_layers"] + [[flat, 0, 0]]
+    with pytest.raises(KI.KerasImportError, match="is a model output"):
+        KI.graph_from_keras_config(cfg)
+    cfg = _config_of("unet_ae_tf212.keras")
+    extra = copy.deepcopy(_layer(cfg, "Activation"))
+    extra["name"] = extra["config"]["name"] = "reads_the_first_dense"
+    extra["inbound_nodes"] = [[[dense[0], 0, 0, {}]]]
+    cfg["config"]["layers"].append(extra)
+    cfg["config"]["output_layers"] = cfg["config"]["output_layers"] + [["reads_the_first_dense", 0, 0]]
+    with pytest.raises(KI.KerasImportError, match="not the next link"):
+        KI.graph_from_keras_config(cfg)
+    # a non-linear activation fused into a conv that is not an output: refused at import time, by layer name
+    cfg = _config_of("unet_lstm_ag_ds.keras")
+    outs = {r[0] for r in cfg["config"]["output_layers"]}
+    inner = next(l for l in cfg["config"]["layers"] if l["class_name"] == "Conv2D" and l["name"] not in outs)
+    inner["config"]["activation"] = "relu"
+    with pytest.raises(KI.KerasImportError, match="fused into a convolution that is not an output") as e:
+        KI.graph_from_keras_config(cfg)
+    assert inner["name"] in str(e.value)
     cfg = _config_of("unet_lstm_ag_ds.keras")
     cfg["class_name"] = "Sequential"
     with pytest.raises(KI.KerasImportError, match="Sequential"):

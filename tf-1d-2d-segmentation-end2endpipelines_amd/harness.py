@@ -210,20 +210,20 @@ def evaluate(model, batches: Iterable, loss: Optional[str] = None, return_dict: 
     return logs
 
 
-LOSS_SCALE_GROWTH_INTERVAL = 200     # clean steps after which a backed-off scale doubles again (dynamic loss scaling)
-
-
 def fit(model, train_batches, epochs: int, val_batches=None,
-        callbacks: Sequence = (), verbose: bool = False) -> Dict[str, List[float]]:
+        callbacks: Sequence = (), verbose: bool = False, loss_scale_growth_interval: Optional[int] = None) -> Dict[str, List[float]]:
     """model.fit(...) of Train.py:394-415: per epoch one pass over the training loader (optimiser step per batch), then
     validation, then the callbacks in order.  A loader is a callable returning an iterable of (x, targets), or such an
     iterable itself (data.CustomDataGenerator: its on_epoch_end() reshuffles after every epoch, as Keras calls it).
-    Returns `history.history`."""
+    Returns `history.history`.  `loss_scale_growth_interval=` sets the model's attribute of that name (clean optimiser steps after
+    which a backed-off loss scale doubles again; default: what the model has - `flags.LOSS_SCALE_GROWTH_INTERVAL` unless the caller
+    changed it).  In graph mode (`graphed_train_step`) the replayed step has no host-side feedback: the scale is adjusted at the
+    epoch-end drain only."""
     hist: Dict[str, List[float]] = {}
     state = FitState(model)
     ms = _metric_set(model)
-    if hasattr(model, "loss_scale_growth_interval"):
-        model.loss_scale_growth_interval = LOSS_SCALE_GROWTH_INTERVAL
+    if loss_scale_growth_interval is not None:
+        model.loss_scale_growth_interval = int(loss_scale_growth_interval)
     for epoch in range(int(epochs)):
         tot, n, skipped = 0.0, 0, 0
         if ms is not None:

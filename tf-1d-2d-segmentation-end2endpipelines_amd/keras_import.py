@@ -23,6 +23,8 @@ The configuration keys are restated from the Keras layer documentation (`get_con
 written by Keras itself yet (`tools/tf_capture_spec.py` saves them on a TensorFlow machine)."""
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -149,8 +151,13 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
         elif cls in ("Conv1D", "Conv2D"):
             need(cls == f"Conv{ndim}D", name, f"in a {ndim}-D model")
             same_padding(c, name)
+            fused = _act_name(c.get("activation"), name)
+            # (the engine fuses an activation into a conv only where the reference does - the output heads, unet_variants.py:300-302;
+            # anywhere else SegModel.build would refuse it later, on the GPU and without the layer's name)
+            need(fused is None or name in out_names, name, f"activation={c.get('activation')!r} fused into a convolution that is not an output "
+                 "(the reference's blocks use a separate Activation layer)")
             out = g.conv(xs[0], int(c["filters"]), k1(c["kernel_size"]), name, strides=k1(c.get("strides", 1)),
-                         use_bias=bool(c.get("use_bias", True)), activation=_act_name(c.get("activation"), name))
+                         use_bias=bool(c.get("use_bias", True)), activation=fused)
         elif cls in ("Conv1DTranspose", "Conv2DTranspose"):
             same_padding(c, name)
             need(c.get("output_padding") is None, name, f"output_padding={c.get('output_padding')}")
@@ -281,6 +288,15 @@ def _graph_from_keras_config(cfg: dict) -> Graph:
                 order.append(n)
         for n in order:
             build(n)
+        # Flatten and Dense have no node of their own: they exist only as links of Flatten -> Dense -> Dense -> Reshape, which the
+        # closing Reshape turns into ONE bottleneck node.  A link that is a model output, or that anything but the next link reads,
+        # would import as the tensor in front of the Flatten with its weights dropped - refused, not approximated.
+        for n in flat_shape:
+            readers = [m for m in order if n in ins_of[m]]
+            nxt = ("Dense",) if layers[n]["class_name"] == "Flatten" or layers[ins_of[n][0]]["class_name"] == "Flatten" else ("Reshape",)
+            need(n not in out_names, n, "is a model output (only the Flatten -> Dense -> Dense -> Reshape bottleneck is part of the hot path)")
+            need(len(readers) == 1 and layers[readers[0]]["class_name"] in nxt, n,
+                 f"is read by {readers or 'nothing'} - not the next link of a Flatten -> Dense -> Dense -> Reshape bottleneck")
     except KeyError as e:
         raise KerasImportError(f"the configuration names a layer or key that is not there: {e}") from None
     g.set_outputs([sym[n] for n in out_names], out_names)
@@ -429,10 +445,16 @@ def save_model(graph: Graph, weights: Dict[str, np.ndarray], path: str):
             if graph.ndim == 1 and a.ndim == 4 and a.shape[0] == 1:
                 a = a[0]                                  # Conv1D / ConvLSTM1D kernels are (k, Cin, Cout)
             w.create_dataset(f"{base}/{i}", a)
-    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
-        z.writestr("metadata.json", json.dumps({"keras_version": "2.15.0", "date_saved": "", "written_by": "segamd.keras_import.save_model"}))
-        z.writestr("config.json", json.dumps(cfg))
-        z.writestr("model.weights.h5", w.tobytes())
+    tmp = f"{path}.tmp{os.getpid()}"                     # (ModelCheckpoint rewrites the best file in place: a kill mid-write must not cost the previous one)
+    try:
+        with zipfile.ZipFile(tmp, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("metadata.json", json.dumps({"keras_version": "2.15.0", "date_saved": "", "written_by": "segamd.keras_import.save_model"}))
+            z.writestr("config.json", json.dumps(cfg))
+            z.writestr("model.weights.h5", w.tobytes())
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def describe(path: str, config: Optional[str] = None) -> str:
