@@ -242,6 +242,15 @@ def gpu_decisions(model):
     return dec
 
 
+def decisions_equal(a, b) -> bool:
+    """gpu_decisions() of two runs: the same nodes, the same decisions on every element."""
+    if isinstance(a, dict):
+        return isinstance(b, dict) and a.keys() == b.keys() and all(decisions_equal(a[k], b[k]) for k in a)
+    if isinstance(a, (tuple, list)):
+        return len(a) == len(b) and all(decisions_equal(p, q) for p, q in zip(a, b))
+    return torch.equal(a, b)
+
+
 def decision_flips(dec, vals, g):
     """How many of the imposed decisions differ from the ones the oracle takes on its own: {node name: (differing, elements)}."""
     out = {}
@@ -257,7 +266,7 @@ def decision_flips(dec, vals, g):
     return out
 
 
-def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, oracle=None, impose_decisions=False):
+def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, oracle=None, impose_decisions=False, imposed_oracle=None):
     """Runs forward(training) + loss + backward on the GPU model and on the oracle primitives wired by the same
     graph (the wiring itself is checked against the independent oracle wiring in test_graph_builders.py).
     Returns per-node forward errors, loss pair, per-node activation-gradient errors and per-parameter gradient
@@ -326,7 +335,14 @@ def compare_model(model, x, targets, loss, verbose=False, emulate_fp16=False, or
         # what is left is arithmetic - the flip-induced part of the gradient error is res["gl2"] minus this
         dec = gpu_decisions(model)
         res["flips"] = decision_flips(dec, vals, g)
-        orb = oracle_run(g, model.get_weights(), x, targets, loss, emulate_fp16, impose=dec)
+        # (imposed_oracle: the imposed-decision oracle pass of ANOTHER model with the same weights and - asserted here - the same
+        # decisions: the forward pass of the two backward modes is the same bits, so one pass serves both)
+        if imposed_oracle is not None:
+            orb, dec0 = imposed_oracle
+            assert decisions_equal(dec0, dec), "the two runs took different branch decisions: their forward passes differ"
+        else:
+            orb = oracle_run(g, model.get_weights(), x, targets, loss, emulate_fp16, impose=dec)
+        res["imposed_oracle"] = (orb, dec)
         res["gl2_imposed"] = {}
         for k, t in orb["W"].items():
             if t.grad is None or k not in grads:

@@ -68,3 +68,21 @@ def test_spawn_relays_output_and_keeps_the_json_line_last(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert r.returncode == 3
     assert lines[0] == "banner" and lines[-1] == '{"metric": "m", "value": 1}'
+
+
+def test_bench_gpus_4_starts_four_ranks_that_refuse_to_run_without_a_gpu():
+    """The real bench.py as the launcher of a 4-rank job (gloo, as the one-GPU box shares its device): here, without a GPU, every one
+    of the four ranks must stop with the "no CPU fallback" message and the launcher must hand the failure on - the product path never
+    degrades to a CPU run.  (The same command on the GPU box runs four ranks on the shared device: tests/test_gpu_dp.py.)"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("this is the no-GPU leg; tests/test_gpu_dp.py runs the command for real")
+    env = dict(os.environ, SEG_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "tiny", "--steps", "1", "--warmup", "0",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert (r.stderr + r.stdout).count("bench.py needs an MI355X (no CPU fallback)") == 4
+    assert '"metric"' not in r.stdout

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the data-parallel exchange step (dp.py) - identical initial weights on every rank, one
+"""CPU, world sizes 2 / 4 / 8, gloo: the data-parallel exchange step (dp.py) - identical initial weights on every rank, one
 sum all-reduce of the flat gradient buffer in buckets, averaging folded into the optimiser's gmul = 1/world."""
 import importlib
 import os
@@ -31,7 +31,8 @@ def _worker(rank, world, port, q):
         # 1. bucketed flat all-reduce
         buf = torch.arange(1000, dtype=torch.float32) * (rank + 1)
         dp.allreduce_flat(buf, bucket_elems=300)
-        ok1 = torch.equal(buf, torch.arange(1000, dtype=torch.float32) * 3)
+        tot = float(world * (world + 1) // 2)                # sum over ranks of (rank + 1): what every planted gradient must add up to
+        ok1 = torch.equal(buf, torch.arange(1000, dtype=torch.float32) * tot)
         # 2. DataParallel wiring on a dry-run model (host logic only; buffers on the CPU)
         M._DryRun.on = True
         m = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
@@ -50,7 +51,7 @@ def _worker(rank, world, port, q):
             return None
         m.backward = noop_backward                       # keep the per-rank gradient we planted
         m.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m.out_heads])
-        ok3 = bool((m.store.G == 3.0).all()) and m.world_size == world and "seg_adam_step_ex" in M._DryRun.log
+        ok3 = bool((m.store.G == tot).all()) and m.world_size == world and "seg_adam_step_ex" in M._DryRun.log
         # 3. overlapped exchange: the backward sweep hands over op-aligned slices as they become final
         m2 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
         m2.build(2, dtype="f16")
@@ -75,7 +76,7 @@ def _worker(rank, world, port, q):
         want = [(lo, hi) for (lo, hi, _), h in zip(reversed(bk), reversed(holds)) if not h] + \
                [(lo, hi) for (lo, hi, _), h in zip(bk, holds) if h]
         ok4 = tiles and len(bk) > 2 and order == sorted(order) and seen[:len(bk)] == want and holds[0] \
-            and bool((m2.store.G[:m2.store.n_train] == 3.0).all()) and not d2.pending and len(bk) <= n_adam <= len(bk) + 1
+            and bool((m2.store.G[:m2.store.n_train] == tot).all()) and not d2.pending and len(bk) <= n_adam <= len(bk) + 1
         # 4. the same with bf16 slices (the default with more than one rank): every finished slice is packed, the all-reduce
         #    runs on the bf16 image, the optimiser reads its gradient from there.  The optimiser state of a model that has
         #    already taken steps travels with the weights.
@@ -93,7 +94,7 @@ def _worker(rank, world, port, q):
         M._DryRun.log.clear()
         m3.train_step(torch.rand(2, 32, 32, 3), [torch.rand(*h.y.shape) for h in m3.out_heads])
         nb = len(m3.grad_buckets())
-        ok5 = ok5 and M._DryRun.log.count("seg_cast_f32_bf16") == nb and bool((m3.store.G16[:m3.store.n_train].float() == 3.0).all())
+        ok5 = ok5 and M._DryRun.log.count("seg_cast_f32_bf16") == nb and bool((m3.store.G16[:m3.store.n_train].float() == tot).all())
         # 5. a parity-mode model (dtype f32) exchanges the fp32 buffer by default: same numerics on 1 and N GPUs
         m4 = pkg.unet_model_builder("UNetPP", 32, 32, 16, 2, ds=1, train_mode="from_scratch").ResNet50()
         m4.build(2, dtype="f32")
@@ -106,15 +107,18 @@ def _worker(rank, world, port, q):
         q.put((rank, False, False, False, traceback.format_exc()))
 
 
-def test_dp_two_ranks_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dp_ranks_gloo(world):
+    """The first 8-GPU run is the driver's: the size-dependent parts of the exchange (the hold-back schedule of bucket_holds(), whose
+    estimate scales with 2 (w - 1) / w, the issue order it implies, the per-slice optimiser launches, the bf16 image) are walked here
+    at every world size the scaling run uses."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     for rank, ok1, ok2, ok3, err in res:
@@ -158,5 +162,59 @@ def test_bucket_holds_follow_the_queue_model():
             assert h[0] and len(h) == len(bk)                                  # the sweep's last slice can never finish before it ends
         finally:
             M.F.DP_BUSBW_GBS = old
+    finally:
+        M._DryRun.on = False
+
+
+def test_c3_exchange_plan_at_eight_ranks():
+    """Planner only (dry run, no process group): the bucket plan of the headline model - UNet++ d5 w64 +DS, 256 x 256, 16 images per
+    rank, parity mode - at the world sizes of the scaling run, and the order in which a backward sweep hands the slices to RCCL
+    (DESIGN section 6).  At 8 ranks: the early-closing urgent slice (the encoder's first levels, ~25 MB) and the two bottleneck slices
+    behind it (227 + 151 MB) become final in the last few percent of the sweep - their ring all-reduce could not finish before it ends,
+    so they are held back; the decoder's three slices go out as they complete (reverse order), then the held ones in FORWARD order, the
+    urgent slice first: the next forward pass needs it first."""
+    M = importlib.import_module(PKG + ".model")
+    pkg = importlib.import_module(PKG)
+    M._DryRun.on = True
+    try:
+        m = pkg.unet_model_builder(decoder_name="UNetPP", model_width=64, model_depth=5, ds=1, length=256, width=256, num_channels=3,
+                                   train_mode="from_scratch").ResNet50()
+        m.build(16, dtype="f32")
+        m.bucket_elems = 32 << 20                                              # DataParallel's default: 128 MB of fp32 gradients
+        one = m.grad_buckets()
+        assert m.bucket_holds() == [False] * len(one)                          # a single rank exchanges nothing and holds nothing
+        plans = {}
+        for w in (2, 4, 8):
+            m.world_size = w
+            bk, holds = m.grad_buckets(), m.bucket_holds()
+            assert bk[0][0] == 0 and bk[-1][1] == m.store.n_train and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
+            assert [oi for _lo, _hi, oi in bk] == sorted(oi for _lo, _hi, oi in bk)        # slices follow the forward order of the ops
+            mb = [(hi - lo) * 4 / 1e6 for lo, hi, _oi in bk]
+            assert len(bk) == 6 and 20 < mb[0] < 30 and mb[0] == min(mb[:-1])   # more than one rank: the urgent slice closes early
+            assert abs(sum(mb) - 795.4) < 1.0                                  # 198.85 M parameters in fp32: what every rank sends per step
+            assert holds[0] and not holds[-1] and holds == sorted(holds, reverse=True)     # held slices are a prefix (the sweep ends there)
+            plans[w] = holds
+        assert plans[8] == [True, True, True, False, False, False]            # DESIGN section 6: "C3, 8 ranks: slices 0-2 held"
+        assert sum(plans[2]) <= sum(plans[4]) <= sum(plans[8])                  # 2 (w - 1) / w grows with the world: never fewer holds
+        # the issue order of one sweep at 8 ranks, as backward() produces it
+        bk = m.grad_buckets()
+        seen = []
+        m.bucket_hook = lambda lo, hi: seen.append((lo, hi))
+        m.bucket_waits = lambda: []
+        for op in m.ops:
+            op.backward = (lambda: None)
+        m.backward(None)
+        assert seen == [(bk[5][0], bk[5][1]), (bk[4][0], bk[4][1]), (bk[3][0], bk[3][1]),
+                        (bk[0][0], bk[0][1]), (bk[1][0], bk[1][1]), (bk[2][0], bk[2][1])]
+        # a slower fabric than assumed holds more, a faster one fewer - never the last-completing (= first) slice
+        old = M.F.DP_BUSBW_GBS
+        try:
+            M.F.DP_BUSBW_GBS = 50.0
+            slow = m.bucket_holds()
+            M.F.DP_BUSBW_GBS = 2000.0
+            fast = m.bucket_holds()
+        finally:
+            M.F.DP_BUSBW_GBS = old
+        assert sum(slow) >= 3 >= sum(fast) >= 1 and fast[0]
     finally:
         M._DryRun.on = False

@@ -62,6 +62,9 @@ F16_RMS = {"C1": 5e-3, "C2": 6e-4, "C3": 6e-4, "C5": 6e-4, "C4": 2e-2}
 #            element carries its whole value upstream: measured 6.5e-4 / 3.0e-3 / 1.1e-3 / 1.8e-2 / 3.0e-3.
 ARITH_L2_CFG = {"C4": 2e-4}
 ARITH_L2_DEFAULT = 5e-5
+# backward="2mfma" (two MFMAs per product in the backward GEMMs: dz / the layer input read as their fp16 hi halves): the same reading
+# (decisions imposed, per parameter tensor, same noise floor) held to the tolerance the north star states for the outputs
+ARITH_L2_2MFMA = 1e-3
 GRAD_L2 = {"C4": 5e-2}            # (default 1e-2)
 NOISE_FLOOR = 1e-6                # absolute summation noise allowed on any gradient tensor, relative to the model's largest gradient norm
 ZERO_FLOOR = 2e-4                 # summation noise of a mathematically zero gradient (conv bias in front of BN), relative to the model's largest gradient norm
@@ -119,7 +122,7 @@ def test_baseline_config_at_its_own_size(cfg):
     torch.manual_seed(11)
     n = ORACLE_BATCH[cfg]
     model32, x, targets, loss = CONFIGS[cfg](n)
-    model32.build(n, dtype="f32")
+    model32.build(n, dtype="f32", backward="3mfma")
     w = model32.get_weights()
     oracle = U.oracle_run(model32.graph, w, x, targets, loss)
     deep = lambda name: any(name.startswith(p) for p in ("latent", "enc6", "enc5", "X41", "X4", "dec0", "bottleneck"))
@@ -183,7 +186,40 @@ def test_baseline_config_at_its_own_size(cfg):
     _record(cfg, "f32_ties", {"near_tie_pixels": ties, "mask_pixels_differing": flipped, "mask_pixels": npx, "band": TIE_BAND})
     assert flipped <= ties
     assert pads_are_zero(model32) is None
+
+    # ---- parity mode with two MFMAs per product in the BACKWARD GEMMs (build(backward="2mfma")): the forward pass is the same bits
+    # (outputs, masks, every decision - asserted), so the strict leg's imposed-decision oracle pass serves this one too; every parameter
+    # gradient within ARITH_L2_2MFMA = 1e-3 relative L2 of it (same per-tensor form and noise floor as above)
+    strict_outs = [got for got, _ref in r["out_tensors"]]
+    imposed_oracle = r["imposed_oracle"]
     del model32, r
+    torch.cuda.empty_cache()
+    model2, _x, _t, _l = CONFIGS[cfg](n)
+    model2.build(n, dtype="f32", backward="2mfma")
+    model2.set_weights(w)
+    r = U.compare_model(model2, x, targets, loss, oracle=oracle, impose_decisions=True, imposed_oracle=imposed_oracle)
+    for (got, _ref), want in zip(r["out_tensors"], strict_outs):
+        assert torch.equal(got, want), f"{cfg}: the forward pass of backward='2mfma' differs from the strict mode's"
+    gn = max(nrm for _e, nrm in r["gl2"].values())
+    zero = r["zero_grad_params"]
+    imposed2 = {k: e / (ARITH_L2_2MFMA * nrm + NOISE_FLOOR * gn) * ARITH_L2_2MFMA for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero}
+    plain2 = {k: e / nrm for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero and nrm > 1e-2 * gn}
+    own2 = {k: e / (nrm + 5e-3 * gn) for k, (e, nrm) in r["gl2"].items()}
+    zero_noise2 = max((e / gn for k, (e, _n) in r["gl2_imposed"].items() if k in zero), default=0.0)
+    wk = max(imposed2, key=imposed2.get)
+    _record(cfg, "f32_gradients_2mfma_backward", {"rel_l2_decisions_imposed_worst_well_conditioned": max(plain2.values()),
+                                                  "rel_l2_decisions_imposed_worst": imposed2[wk], "rel_l2_decisions_imposed_worst_tensor": wk,
+                                                  "rel_l2_decisions_imposed_median": float(np.median(list(imposed2.values()))),
+                                                  "rel_l2_own_decisions_worst": max(own2.values()),
+                                                  "zero_gradient_bias_noise_over_largest_norm": zero_noise2,
+                                                  "forward_bit_identical_to_the_strict_mode": True, "tolerance": ARITH_L2_2MFMA})
+    for k, v in imposed2.items():
+        assert v < ARITH_L2_2MFMA, (cfg, "2mfma", k, v)
+    assert zero_noise2 < ZERO_FLOOR, (cfg, zero_noise2)
+    for k, (e, nrm) in r["gl2"].items():
+        assert e < GRAD_L2.get(cfg, 1e-2) * (nrm + 5e-3 * gn), (cfg, "2mfma", k, e, nrm)
+    assert pads_are_zero(model2) is None
+    del model2, r, imposed_oracle
     torch.cuda.empty_cache()
 
     # ---- throughput mode (fp16 MFMA operands) against the SAME fp32 oracle
@@ -232,7 +268,7 @@ def test_c3_forward_and_backward_at_the_benched_batch_match_the_oracle():
     parameter gradient to ARITH_L2 with the decisions imposed and to GRAD_L2 against the oracle's own."""
     torch.manual_seed(21)
     model, x, targets, loss = CONFIGS["C3"](16)
-    model.build(16, dtype="f32")
+    model.build(16, dtype="f32", backward="3mfma")
     r = U.compare_model(model, x, targets, loss, impose_decisions=True)
     flips = ties = 0
     for got, ref in r["out_tensors"]:

@@ -55,5 +55,8 @@ HEAD_INJECT = os.environ.get("SEG_HEAD_INJECT", "1") != "0"            # ... and
 WGRAD_BLOCKS = 1536       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = 256   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
-BWD_A_HI = os.environ.get("SEG_BWD_A_HI", "0") == "1"         # EXPERIMENT (never validated on a GPU): parity mode, halo-tile data
-                                                            # gradients read the incoming gradient as its hi half - two MFMAs per product instead of three
+# parity mode, the BACKWARD GEMMs only: "3mfma" = every product a b ~= ah bh + (al bh + ah bl) / 2048 like the forward pass; "2mfma" = the data
+# gradients read the incoming gradient dz as its hi half (ah bh + ah bl / 2048), the weight gradients the layer INPUT as its hi half
+# (ah bh + al bh / 2048) - a third of the MFMAs and of the LDS fragment reads go, the rounded operand loses 2^-12 rms, elementwise and
+# unbiased; the forward pass, `predict` and the masks are the same bits in both modes (SegModel.build(backward=)).
+BACKWARD = os.environ.get("SEG_BACKWARD", "3mfma")

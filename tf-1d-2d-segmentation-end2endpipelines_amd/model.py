@@ -137,6 +137,7 @@ class SegModel:
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
+        self.backward_mode, self.bwd2 = None, False       # build(backward=): MFMAs per product of the backward GEMMs (parity mode)
         if batch_size is not None:
             self.build(batch_size)
 
@@ -264,7 +265,13 @@ class SegModel:
     def _enter(self):
         _Mode.sfx = "" if self.dtype == "f16" else "_f32"
 
-    def build(self, batch_size: int, dtype: Optional[str] = None):
+    def build(self, batch_size: int, dtype: Optional[str] = None, backward: Optional[str] = None):
+        """backward (parity mode only; the throughput mode has one MFMA per product everywhere): "3mfma" | "2mfma" - how many fp16 MFMAs
+        a product of the BACKWARD GEMMs costs (flags.BACKWARD is the default).  The forward pass is the same in both."""
+        backward = backward or self.backward_mode or F.BACKWARD
+        if backward not in ("3mfma", "2mfma"):
+            raise ValueError("backward must be '3mfma' or '2mfma'")
+        self.backward_mode = backward
         if dtype is not None:
             if dtype not in ("f16", "f32"):
                 raise ValueError("dtype must be 'f16' or 'f32'")
@@ -272,6 +279,7 @@ class SegModel:
                 self.grad_target = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.grad_target_max = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.dtype = dtype
+        self.bwd2 = self.dtype == "f32" and self.backward_mode == "2mfma"
         self._enter()
         DevTensor.dtype = torch.float16 if self.dtype == "f16" else torch.float32
         if not _DryRun.on:
