@@ -73,6 +73,8 @@ typedef struct seg_geom {
                                     operand stays whole: a b ~= ah bh + ah bl / 2048); never for a forward pass                     */
 #define SEG_VARIANT_IN_HI 0x1000 /* OR-ed into `variant` of seg_igemm_wgrad_f32 (variant 2, tiles of 64 output channels): the input operand
                                     (the activations) is read as its hi half - two MFMAs per product, dz stays whole             */
+#define SEG_VARIANT_DZ_HI 0x2000 /* ... together with SEG_VARIANT_IN_HI: dz as its hi half as well - ONE MFMA per product (a b ~= ah bh).  The
+                                    weight gradient ends a chain: its rounding lands once in dW and is inherited by no other gradient */
 typedef struct seg_igemm_fwd_args {
   seg_geom g;
   int32_t nseg;

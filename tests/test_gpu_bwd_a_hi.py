@@ -65,6 +65,14 @@ def test_hi_only_input_operand_in_the_weight_gradient(N, H, W, cin, cout, kind):
     half = U.igemm_wgrad([x], dz, kshape, kind, s, 2 | ffi.SEG_VARIANT_A_HI, None, None, f32=True)
     full_of_hi = U.igemm_wgrad([U.h16(x)], dz, kshape, kind, s, 2, None, None, f32=True)
     assert np.array_equal(half, full_of_hi)              # the definition: the three-MFMA launch on the input's hi half
+    # one MFMA per product: dz as its hi half as well
+    one = U.igemm_wgrad([x], dz, kshape, kind, s, 2 | ffi.SEG_VARIANT_IN_HI | ffi.SEG_VARIANT_DZ_HI, None, None, f32=True)
+    full_of_both_hi = U.igemm_wgrad([U.h16(x)], U.h16(dz), kshape, kind, s, 2, None, None, f32=True)
+    e1 = float(np.abs(one - full_of_both_hi).max() / np.abs(full).max())
+    assert e1 < 1e-6, e1                                 # (one accumulator instead of two: the same products in another summation order)
+    e2 = float(np.abs(one - full).max() / np.abs(full).max())
+    print(f"weight gradient, both operands hi only against three MFMAs: {e2:.1e}")
+    assert 1e-6 < e2 < 7e-4
     e = float(np.abs(half - full).max() / np.abs(full).max())
     print(f"weight gradient, input operand hi only against three MFMAs: {e:.1e}")
     assert 1e-6 < e < 5e-4
@@ -83,7 +91,7 @@ def test_the_backward_mode_changes_the_backward_pass_only():
     for mode in ("3mfma", "2mfma"):
         m = segamd.unet_model_builder("UNetPP", 64, 64, 16, 3, num_channels=3, ds=1, train_mode="from_scratch").ResNet50()
         m.build(2, dtype="f32", backward=mode)
-        assert m.backward_mode == mode and m.bwd2 == (mode == "2mfma")
+        assert m.backward_mode == mode and (m.bwd_d, m.bwd_w) == ((2, 2) if mode == "2mfma" else (3, 3))
         if res:
             m.set_weights(res["3mfma"][3])
         w = m.get_weights()

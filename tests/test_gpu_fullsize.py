@@ -194,33 +194,36 @@ def test_baseline_config_at_its_own_size(cfg):
     imposed_oracle = r["imposed_oracle"]
     del model32, r
     torch.cuda.empty_cache()
-    model2, _x, _t, _l = CONFIGS[cfg](n)
-    model2.build(n, dtype="f32", backward="2mfma")
-    model2.set_weights(w)
-    r = U.compare_model(model2, x, targets, loss, oracle=oracle, impose_decisions=True, imposed_oracle=imposed_oracle)
-    for (got, _ref), want in zip(r["out_tensors"], strict_outs):
-        assert torch.equal(got, want), f"{cfg}: the forward pass of backward='2mfma' differs from the strict mode's"
-    gn = max(nrm for _e, nrm in r["gl2"].values())
-    zero = r["zero_grad_params"]
-    imposed2 = {k: e / (ARITH_L2_2MFMA * nrm + NOISE_FLOOR * gn) * ARITH_L2_2MFMA for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero}
-    plain2 = {k: e / nrm for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero and nrm > 1e-2 * gn}
-    own2 = {k: e / (nrm + 5e-3 * gn) for k, (e, nrm) in r["gl2"].items()}
-    zero_noise2 = max((e / gn for k, (e, _n) in r["gl2_imposed"].items() if k in zero), default=0.0)
-    wk = max(imposed2, key=imposed2.get)
-    _record(cfg, "f32_gradients_2mfma_backward", {"rel_l2_decisions_imposed_worst_well_conditioned": max(plain2.values()),
-                                                  "rel_l2_decisions_imposed_worst": imposed2[wk], "rel_l2_decisions_imposed_worst_tensor": wk,
-                                                  "rel_l2_decisions_imposed_median": float(np.median(list(imposed2.values()))),
-                                                  "rel_l2_own_decisions_worst": max(own2.values()),
-                                                  "zero_gradient_bias_noise_over_largest_norm": zero_noise2,
-                                                  "forward_bit_identical_to_the_strict_mode": True, "tolerance": ARITH_L2_2MFMA})
-    for k, v in imposed2.items():
-        assert v < ARITH_L2_2MFMA, (cfg, "2mfma", k, v)
-    assert zero_noise2 < ZERO_FLOOR, (cfg, zero_noise2)
-    for k, (e, nrm) in r["gl2"].items():
-        assert e < GRAD_L2.get(cfg, 1e-2) * (nrm + 5e-3 * gn), (cfg, "2mfma", k, e, nrm)
-    assert pads_are_zero(model2) is None
-    del model2, r, imposed_oracle
-    torch.cuda.empty_cache()
+    for mode in os.environ.get("SEG_FULLSIZE_BWD_MODES", "2mfma").split(","):
+        model2, _x, _t, _l = CONFIGS[cfg](n)
+        model2.build(n, dtype="f32", backward=mode)
+        model2.set_weights(w)
+        r = U.compare_model(model2, x, targets, loss, oracle=oracle, impose_decisions=True, imposed_oracle=imposed_oracle)
+        for (got, _ref), want in zip(r["out_tensors"], strict_outs):
+            assert torch.equal(got, want), f"{cfg}: the forward pass of backward={mode!r} differs from the strict mode's"
+        gn = max(nrm for _e, nrm in r["gl2"].values())
+        zero = r["zero_grad_params"]
+        imposed2 = {k: e / (ARITH_L2_2MFMA * nrm + NOISE_FLOOR * gn) * ARITH_L2_2MFMA for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero}
+        plain2 = {k: e / nrm for k, (e, nrm) in r["gl2_imposed"].items() if k not in zero and nrm > 1e-2 * gn}
+        own2 = {k: e / (nrm + 5e-3 * gn) for k, (e, nrm) in r["gl2"].items()}
+        zero_noise2 = max((e / gn for k, (e, _n) in r["gl2_imposed"].items() if k in zero), default=0.0)
+        wk = max(imposed2, key=imposed2.get)
+        _record(cfg, f"f32_gradients_backward_{mode}", {"rel_l2_decisions_imposed_worst_well_conditioned": max(plain2.values()),
+                                                       "rel_l2_decisions_imposed_worst": imposed2[wk], "rel_l2_decisions_imposed_worst_tensor": wk,
+                                                       "rel_l2_decisions_imposed_median": float(np.median(list(imposed2.values()))),
+                                                       "rel_l2_own_decisions_worst": max(own2.values()),
+                                                       "zero_gradient_bias_noise_over_largest_norm": zero_noise2,
+                                                       "forward_bit_identical_to_the_strict_mode": True, "tolerance": ARITH_L2_2MFMA})
+        if os.environ.get("SEG_FULLSIZE_BWD_REPORT_ONLY") != "1":
+            for k, v in imposed2.items():
+                assert v < ARITH_L2_2MFMA, (cfg, mode, k, v)
+            assert zero_noise2 < ZERO_FLOOR, (cfg, zero_noise2)
+            for k, (e, nrm) in r["gl2"].items():
+                assert e < GRAD_L2.get(cfg, 1e-2) * (nrm + 5e-3 * gn), (cfg, mode, k, e, nrm)
+        assert pads_are_zero(model2) is None
+        del model2, r
+        torch.cuda.empty_cache()
+    del imposed_oracle
 
     # ---- throughput mode (fp16 MFMA operands) against the SAME fp32 oracle
     model16, _x, _t, _l = CONFIGS[cfg](n)

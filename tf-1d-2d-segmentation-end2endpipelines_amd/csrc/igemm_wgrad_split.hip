@@ -33,6 +33,14 @@ __device__ __forceinline__ h8 trfrag(const unsigned char* ad, int rstride4) {
     ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, ACCL, 0, 0, 0);         \
   } while (0)
 
+// SEG_VARIANT_IN_HI | SEG_VARIANT_DZ_HI: BOTH operands as their hi halves - one MFMA per product, one accumulator set, two of the four
+// fragment reads (a b ~= ah bh).  The weight gradient is the END of a chain: its rounding (2^-12 rms on each operand, elementwise,
+// unbiased) lands once in dW and is not carried into any other gradient - unlike a data gradient's, which every layer below inherits.
+#define SEG_MMA_HI(ACC, AH, BH)                                                   \
+  do {                                                                            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);           \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 // per-tap kernel (1x1, strided, 1-D convolutions, images the halo patches do not tile): register-staged double buffer,
 // 32 pixels per step.  LDS per operand: a hi tile and a lo tile [32 pixels][BM (BN) halves], rows padded by 64 B.
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_split_kernel(const seg_ige
 // meet in LDS at the end, added in wave order) - 9 MFMA triples per wave and patch instead of 18; a transposed-conv class gives
 // each wave one of its four taps.
 // ---------------------------------------------------------------------------------------------------------
-template <int C, bool TC, bool NARROW = false, bool BHI = false>
+template <int C, bool TC, bool NARROW = false, int BHI = 0>      // BHI: 0 three MFMAs per product, 1 the input operand's hi half (two), 2 both hi halves (one)
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const seg_igemm_wgrad_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int R = 64 / C, HC = C + 2, HROWS = (R + 2) * HC;
@@ -391,7 +399,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int yy = kb_yy(kb), xx0 = kb_xx(kb);
-      const h8 ah = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256), al = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
+      const h8 ah = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256);
+      h8 al;
+      if constexpr (BHI != 2) al = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const int t = s < 4 ? TH * 5 + s : 4;
@@ -399,7 +409,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
         const int hb = (yy + t / 3) * HC + xx0 + t % 3;            // halo row of pixel 0 of this K block under tap t
         const int off = hb * 128 + offB[hb & 3];
         const h8 bh = trfrag(Is + off, 4 * 128);
-        if constexpr (BHI) {
+        if constexpr (BHI == 2) {
+          SEG_MMA_HI(acc[s], ah, bh);
+        } else if constexpr (BHI == 1) {
           SEG_MMA_SPLIT_BHI(acc[s], accl[s], ah, al, bh);
         } else {
           const h8 bl = trfrag(Is + (off ^ 16), 4 * 128);
@@ -414,8 +426,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int yy = kb_yy(kb), xx0 = kb_xx(kb);
-      const h8 ah = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256), al = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
-      if (do_bias) {                                                 // wave-uniform
+      const h8 ah = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256);
+      h8 al;
+      if constexpr (BHI != 2) al = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
+      if (do_bias) {                                                 // wave-uniform (the bias gradient keeps both halves of dz in every mode)
+        if constexpr (BHI == 2) al = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ones, accb, 0, 0, 0);
         accbl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ones, accbl, 0, 0, 0);
       }
@@ -427,7 +442,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
         const int swz = (((hb & 3) + jr) >> 1) & 1;
         const int off = (hb + jr) * 128 + (((2 * grp) ^ swz) << 4) + sub;
         const h8 bh = trfrag(Is + off, 4 * 128);
-        if constexpr (BHI) {
+        if constexpr (BHI == 2) {
+          SEG_MMA_HI(acc[s], ah, bh);
+        } else if constexpr (BHI == 1) {
           SEG_MMA_SPLIT_BHI(acc[s], accl[s], ah, al, bh);
         } else {
           const h8 bl = trfrag(Is + (off ^ 16), 4 * 128);
@@ -451,10 +468,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
   if (TC || NARROW || th == 0) run(std::integral_constant<int, 0>{});
   else run(std::integral_constant<int, 1>{});
 
+  if constexpr (BHI != 2) {
 #pragma unroll
-  for (int t = 0; t < NACC; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] += accl[t][q] * SPLIT_INV;
+      for (int q = 0; q < 16; ++q) acc[t][q] += accl[t][q] * SPLIT_INV;
+  }
   if constexpr (!TC && NARROW) {      // the four K blocks of tap 8: waves 1-3 hand their partial tiles to wave 0 through LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -537,12 +556,19 @@ template __global__ void igemm_wgrad_halo_split_kernel<32, true, true>(const seg
 template __global__ void igemm_wgrad_halo_split_kernel<16, true, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<8, true, true>(const seg_igemm_wgrad_args);
 // input operand as its hi half (experiment): the 3x3 layers and the per-class transposed-conv form, 64-channel tiles
-template __global__ void igemm_wgrad_halo_split_kernel<32, false, false, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_kernel<16, false, false, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_kernel<8, false, false, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_kernel<32, true, false, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_kernel<16, true, false, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_kernel<8, true, false, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<32, false, false, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, false, false, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, false, false, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<32, true, false, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, true, false, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, true, false, 1>(const seg_igemm_wgrad_args);
+// both operands as their hi halves (one MFMA per product)
+template __global__ void igemm_wgrad_halo_split_kernel<32, false, false, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, false, false, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, false, false, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<32, true, false, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<16, true, false, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_kernel<8, true, false, 2>(const seg_igemm_wgrad_args);
 
 // ---------------------------------------------------------------------------------------------------------
 // Conv2DTranspose(4x4, stride 2), parity mode, two sub-pixel classes per block (the class row py: classes (py, 0) and (py, 1);
@@ -555,7 +581,7 @@ template __global__ void igemm_wgrad_halo_split_kernel<8, true, false, true>(con
 // fragments and the three column shifts of its input row (10 fragment reads) for 4 MFMA triples per K block: dx = 0 feeds
 // both classes.  Per MFMA: 0.83 fragment reads instead of 1.0, 25 KB of LDS-DMA per 32 px and class pair instead of 2 x 16.5 KB.
 // ---------------------------------------------------------------------------------------------------------
-template <int C, bool BHI = false>
+template <int C, int BHI = 0>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(const seg_igemm_wgrad_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PX = 32, R = PX / C, HC = C + 2, HROWS = (R + 1) * HC;
@@ -694,9 +720,17 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
     for (int kb = 0; kb < PX / 16; ++kb) {
       constexpr int KPR = C >= 16 ? C / 16 : 1;
       const int yy = C >= 16 ? kb / KPR : 2 * kb, xx0 = C >= 16 ? (kb % KPR) * 16 : 0;
-      const h8 a0h = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256), a0l = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
-      const h8 a1h = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAh, 4 * 256), a1l = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAl, 4 * 256);
-      if (do_bias) {                                                 // wave-uniform
+      const h8 a0h = trfrag(Zs + kb * 16 * 256 + offAh, 4 * 256), a1h = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAh, 4 * 256);
+      h8 a0l, a1l;
+      if constexpr (BHI != 2) {
+        a0l = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
+        a1l = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAl, 4 * 256);
+      }
+      if (do_bias) {                                                 // wave-uniform (the bias gradient keeps both halves of dz in every mode)
+        if constexpr (BHI == 2) {
+          a0l = trfrag(Zs + kb * 16 * 256 + offAl, 4 * 256);
+          a1l = trfrag(Zs + Z_BYTES + kb * 16 * 256 + offAl, 4 * 256);
+        }
         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, ones, accb, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, ones, accb, 0, 0, 0);
         accbl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, ones, accbl, 0, 0, 0);
@@ -705,7 +739,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
       // tap row iy reads halo row yy + 1 - iy for either class row (dy = {0,-1} + py, halo row 0 = input row y0 - 1 + py)
       const int hb0 = (yy + 1 - IY) * HC + xx0 + 1;                  // halo row of pixel 0 of this K block at dx = 0
       const int om = (hb0 - 1) * 128 + offB[(hb0 - 1) & 3], oz = hb0 * 128 + offB[hb0 & 3], op = (hb0 + 1) * 128 + offB[(hb0 + 1) & 3];
-      if constexpr (BHI) {
+      if constexpr (BHI == 2) {
+        const h8 bzh = trfrag(Is + oz, 4 * 128), bmh = trfrag(Is + om, 4 * 128), bph = trfrag(Is + op, 4 * 128);
+        SEG_MMA_HI(acc[0], a0h, bzh);
+        SEG_MMA_HI(acc[3], a1h, bzh);
+        SEG_MMA_HI(acc[1], a0h, bmh);
+        SEG_MMA_HI(acc[2], a1h, bph);
+      } else if constexpr (BHI == 1) {
         const h8 bzh = trfrag(Is + oz, 4 * 128), bmh = trfrag(Is + om, 4 * 128), bph = trfrag(Is + op, 4 * 128);
         SEG_MMA_SPLIT_BHI(acc[0], accl[0], a0h, a0l, bzh);
         SEG_MMA_SPLIT_BHI(acc[3], accl[3], a1h, a1l, bzh);
@@ -736,10 +776,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
   if (iy == 0) run(std::integral_constant<int, 0>{});
   else run(std::integral_constant<int, 1>{});
 
+  if constexpr (BHI != 2) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] += accl[t][q] * SPLIT_INV;
+      for (int q = 0; q < 16; ++q) acc[t][q] += accl[t][q] * SPLIT_INV;
+  }
 
   float sc_mul = p.scale;
   if (p.scale_ptr != nullptr) sc_mul *= *p.scale_ptr;
@@ -770,11 +812,27 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
 template __global__ void igemm_wgrad_halo_split_tc2_kernel<32>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_tc2_kernel<16>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_tc2_kernel<8>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_tc2_kernel<32, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_tc2_kernel<16, true>(const seg_igemm_wgrad_args);
-template __global__ void igemm_wgrad_halo_split_tc2_kernel<8, true>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<32, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<16, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<8, 1>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<32, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<16, 2>(const seg_igemm_wgrad_args);
+template __global__ void igemm_wgrad_halo_split_tc2_kernel<8, 2>(const seg_igemm_wgrad_args);
 
 }  // namespace
+
+template <bool TC, int HI>
+static void launch_wgrad_halo_split(int pc, dim3 grid, size_t lds, hipStream_t st, const seg_igemm_wgrad_args& a) {
+  if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, TC, false, HI>), grid, dim3(256), lds, st, a);
+  else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, TC, false, HI>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, TC, false, HI>), grid, dim3(256), lds, st, a);
+}
+template <int HI>
+static void launch_wgrad_tc2(int pc, dim3 grid2, hipStream_t st, const seg_igemm_wgrad_args& a) {
+  if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<32, HI>), grid2, dim3(256), (size_t)2 * (16384 + 9 * 1024), st, a);
+  else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<16, HI>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, a);
+  else hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<8, HI>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, a);
+}
 
 extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t stream) {
   if (const int rc = check_wgrad_args(a, "seg_igemm_wgrad_f32")) return rc;
@@ -799,7 +857,9 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
     // transposed conv whose taps follow the class-pair table: both classes of a class row per block
     static const char* tc2_env = std::getenv("SEG_WGRAD_TC2");
     const bool tc2 = !narrow && seg_wgrad_halo_class_groups(&a->g) == 2 && (tc2_env == nullptr || std::atoi(tc2_env) != 0);
-    const bool in_hi = !narrow && (a->variant & SEG_VARIANT_IN_HI) != 0;       // experiment: the input operand as its hi half (64-channel tiles)
+    // operand halves (64-channel tiles): 0 both operands whole (three MFMAs per product), 1 the input as its hi half (two), 2 dz as well (one)
+    const int hi = narrow ? 0 : ((a->variant & SEG_VARIANT_IN_HI) ? ((a->variant & SEG_VARIANT_DZ_HI) ? 2 : 1) : 0);
+    SEG_CHECK_ARG(!(a->variant & SEG_VARIANT_DZ_HI) || (a->variant & SEG_VARIANT_IN_HI), "seg_igemm_wgrad_f32: SEG_VARIANT_DZ_HI comes with SEG_VARIANT_IN_HI (one MFMA per product)");
     if (narrow && a->g.ncls == 1) {
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false, true>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false, true>), grid, dim3(256), lds, st, *a);
@@ -808,32 +868,19 @@ extern "C" int seg_igemm_wgrad_f32(const seg_igemm_wgrad_args* a, seg_stream_t s
       if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true, true>), grid, dim3(256), lds, st, *a);
       else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true, true>), grid, dim3(256), lds, st, *a);
       else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true, true>), grid, dim3(256), lds, st, *a);
-    } else if (tc2 && in_hi) {
-      dim3 grid2(grid.x, 2, grid.z);
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<32, true>), grid2, dim3(256), (size_t)2 * (16384 + 9 * 1024), st, *a);
-      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<16, true>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<8, true>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
     } else if (tc2) {
       dim3 grid2(grid.x, 2, grid.z);
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<32>), grid2, dim3(256), (size_t)2 * (16384 + 9 * 1024), st, *a);
-      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<16>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_split_tc2_kernel<8>), grid2, dim3(256), (size_t)2 * (16384 + 7 * 1024), st, *a);
-    } else if (in_hi && a->g.ncls == 1) {
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false, false, true>), grid, dim3(256), lds, st, *a);
-      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false, false, true>), grid, dim3(256), lds, st, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, false, false, true>), grid, dim3(256), lds, st, *a);
-    } else if (in_hi) {
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true, false, true>), grid, dim3(256), lds, st, *a);
-      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true, false, true>), grid, dim3(256), lds, st, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true, false, true>), grid, dim3(256), lds, st, *a);
+      if (hi == 2) launch_wgrad_tc2<2>(pc, grid2, st, *a);
+      else if (hi == 1) launch_wgrad_tc2<1>(pc, grid2, st, *a);
+      else launch_wgrad_tc2<0>(pc, grid2, st, *a);
     } else if (a->g.ncls == 1) {
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, false>), grid, dim3(256), lds, st, *a);
-      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, false>), grid, dim3(256), lds, st, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, false>), grid, dim3(256), lds, st, *a);
+      if (hi == 2) launch_wgrad_halo_split<false, 2>(pc, grid, lds, st, *a);
+      else if (hi == 1) launch_wgrad_halo_split<false, 1>(pc, grid, lds, st, *a);
+      else launch_wgrad_halo_split<false, 0>(pc, grid, lds, st, *a);
     } else {
-      if (pc == 32) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<32, true>), grid, dim3(256), lds, st, *a);
-      else if (pc == 16) hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<16, true>), grid, dim3(256), lds, st, *a);
-      else hipLaunchKernelGGL((igemm_wgrad_halo_split_kernel<8, true>), grid, dim3(256), lds, st, *a);
+      if (hi == 2) launch_wgrad_halo_split<true, 2>(pc, grid, lds, st, *a);
+      else if (hi == 1) launch_wgrad_halo_split<true, 1>(pc, grid, lds, st, *a);
+      else launch_wgrad_halo_split<true, 0>(pc, grid, lds, st, *a);
     }
     SEG_CHECK_LAUNCH("seg_igemm_wgrad_f32 (halo)");
     return seg_launch_wgrad_reduce(*a, st);

@@ -137,7 +137,7 @@ class SegModel:
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
-        self.backward_mode, self.bwd2 = None, False       # build(backward=): MFMAs per product of the backward GEMMs (parity mode)
+        self.backward_mode, self.bwd_d, self.bwd_w = None, 3, 3       # build(backward=): MFMAs per product of the backward GEMMs (parity mode)
         if batch_size is not None:
             self.build(batch_size)
 
@@ -266,11 +266,14 @@ class SegModel:
         _Mode.sfx = "" if self.dtype == "f16" else "_f32"
 
     def build(self, batch_size: int, dtype: Optional[str] = None, backward: Optional[str] = None):
-        """backward (parity mode only; the throughput mode has one MFMA per product everywhere): "3mfma" | "2mfma" - how many fp16 MFMAs
-        a product of the BACKWARD GEMMs costs (flags.BACKWARD is the default).  The forward pass is the same in both."""
+        """backward (parity mode only; the throughput mode has one MFMA per product everywhere): how many fp16 MFMAs a product of the
+        BACKWARD GEMMs costs - "d<D>w<W>" with D in {3, 2} for the data gradients and W in {3, 2, 1} for the weight gradients;
+        "3mfma" = "d3w3" (every product as in the forward pass), "2mfma" = "d2w2" (flags.BACKWARD is the default).  The forward
+        pass is the same bits in every mode."""
         backward = backward or self.backward_mode or F.BACKWARD
-        if backward not in ("3mfma", "2mfma"):
-            raise ValueError("backward must be '3mfma' or '2mfma'")
+        spec = {"3mfma": "d3w3", "2mfma": "d2w2"}.get(backward, backward)
+        if spec not in ("d3w3", "d3w2", "d3w1", "d2w3", "d2w2", "d2w1"):
+            raise ValueError("backward must be '3mfma', '2mfma' or 'd<3|2>w<3|2|1>'")
         self.backward_mode = backward
         if dtype is not None:
             if dtype not in ("f16", "f32"):
@@ -279,7 +282,7 @@ class SegModel:
                 self.grad_target = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.grad_target_max = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.dtype = dtype
-        self.bwd2 = self.dtype == "f32" and self.backward_mode == "2mfma"
+        self.bwd_d, self.bwd_w = (int(spec[1]), int(spec[3])) if self.dtype == "f32" else (1, 1)     # MFMAs per product: data / weight gradients
         self._enter()
         DevTensor.dtype = torch.float16 if self.dtype == "f16" else torch.float32
         if not _DryRun.on:

@@ -406,8 +406,10 @@ class ConvOp(Op):
         wg.tile_m, wg.tile_n, wg.splitk = tm, tn, sk
         wg.scale, wg.scale_ptr = 1.0, self.m.gs.data_ptr() + 4
         wg.variant = variant
-        if self.m.bwd2 and variant == 2 and self.n_rows > 32:
-            wg.variant |= _ffi.SEG_VARIANT_A_HI          # (== SEG_VARIANT_IN_HI: the layer input as its hi half in the weight gradient - two MFMAs per product)
+        if self.m.bwd_w < 3 and variant == 2 and self.n_rows > 32:
+            wg.variant |= _ffi.SEG_VARIANT_IN_HI         # the layer input as its hi half in the weight gradient - two MFMAs per product
+            if self.m.bwd_w == 1:
+                wg.variant |= _ffi.SEG_VARIANT_DZ_HI     # ... and dz: one
         # the gradient buffer is cleared once per step (backward() / the side stream after the optimiser), and with
         # splitk == 1 every tile has one writer: it may store instead of read-modify-write
         wg.overwrite = 1 if (F.WGRAD_OVERWRITE and variant == 2 and sk == 1) else 0
@@ -562,7 +564,7 @@ class ConvOp(Op):
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
             a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16",
                                                                [a.seg_cs[j] for j in range(a.nseg)], width * self.g_dgrad.T_total * self.rows_pad)
-            if self.m.bwd2 and (a.variant & 255) == 3 and self.g_dgrad.ntaps != 4:
+            if self.m.bwd_d == 2 and (a.variant & 255) == 3 and self.g_dgrad.ntaps != 4:
                 a.variant |= _ffi.SEG_VARIANT_A_HI          # (dz as its hi half: two MFMAs per product in the data gradients)
             self.m.fwd_ws_users.append(a)
             self.dg_args.append((a, zero_first, fl))
@@ -682,7 +684,7 @@ class GatherDgrad:
         Md = op0.N * op0.g_dgrad.Hl * op0.g_dgrad.Wl
         a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16",
                                                            [a.seg_cs[j] for j in range(a.nseg)], self.t.cs * op0.g_dgrad.T_total * self.Kg)
-        if self.m.bwd2 and (a.variant & 255) == 3 and op0.g_dgrad.ntaps != 4:
+        if self.m.bwd_d == 2 and (a.variant & 255) == 3 and op0.g_dgrad.ntaps != 4:
             a.variant |= _ffi.SEG_VARIANT_A_HI
         self.m.fwd_ws_users.append(a)
         self.args = a
