@@ -71,6 +71,8 @@ typedef struct seg_geom {
 #define SEG_VARIANT_A_HI 0x1000  /* OR-ed into `variant` of seg_igemm_fwd_f32 (variant 3 only): the A operand - the incoming gradient of a
                                     data-gradient launch - is read as its hi half, two MFMAs per product instead of three (the weight
                                     operand stays whole: a b ~= ah bh + ah bl / 2048); never for a forward pass                     */
+#define SEG_VARIANT_B_HI 0x2000  /* ... or its B operand - the (transposed) weights - instead: a b ~= ah bh + al bh / 2048; dz keeps its 22 bits
+                                    and its range (weights are O(1): no element of them sits below fp16's normal range)                */
 #define SEG_VARIANT_IN_HI 0x1000 /* OR-ed into `variant` of seg_igemm_wgrad_f32 (variant 2, tiles of 64 output channels): the input operand
                                     (the activations) is read as its hi half - two MFMAs per product, dz stays whole             */
 #define SEG_VARIANT_DZ_HI 0x2000 /* ... together with SEG_VARIANT_IN_HI: dz as its hi half as well - ONE MFMA per product (a b ~= ah bh).  The

@@ -49,6 +49,14 @@ def test_hi_only_gradient_operand(N, H, W, cins, cout, kind):
     assert 1e-6 < e < 5e-4                               # 2^-12 rms per element of the operand, averaged over the contraction
     d = half - full
     assert abs(float(d.mean())) < 0.1 * float(d.abs().mean())       # unbiased
+    # SEG_VARIANT_B_HI: the weight operand as its hi half instead (what a data-gradient launch of backward="b2w*" does)
+    kern_hi = U.h16(torch.from_numpy(kern)).numpy()
+    halfb, _s, padb = U.igemm_conv(xs, kern, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=3 | ffi.SEG_VARIANT_B_HI)
+    full_of_bhi, _s, _p = U.igemm_conv(xs, kern_hi, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=3)
+    assert padb == 0.0 and torch.equal(halfb, full_of_bhi)
+    eb = rel(halfb, exact)
+    print(f"B operand hi only against the fp32 convolution: {eb:.1e}")
+    assert 1e-6 < eb < 5e-4
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,kind", [(2, 32, 32, 64, 64, "conv"), (2, 16, 32, 40, 96, "conv"), (2, 16, 16, 64, 64, "convT"),
@@ -64,7 +72,8 @@ def test_hi_only_input_operand_in_the_weight_gradient(N, H, W, cin, cout, kind):
     full = U.igemm_wgrad([x], dz, kshape, kind, s, 2, None, None, f32=True)
     half = U.igemm_wgrad([x], dz, kshape, kind, s, 2 | ffi.SEG_VARIANT_A_HI, None, None, f32=True)
     full_of_hi = U.igemm_wgrad([U.h16(x)], dz, kshape, kind, s, 2, None, None, f32=True)
-    assert np.array_equal(half, full_of_hi)              # the definition: the three-MFMA launch on the input's hi half
+    # the definition: the three-MFMA launch on the input's hi half (to the summation order of the pixel split's atomics)
+    assert float(np.abs(half - full_of_hi).max() / np.abs(full).max()) < 1e-6
     # one MFMA per product: dz as its hi half as well
     one = U.igemm_wgrad([x], dz, kshape, kind, s, 2 | ffi.SEG_VARIANT_IN_HI | ffi.SEG_VARIANT_DZ_HI, None, None, f32=True)
     full_of_both_hi = U.igemm_wgrad([U.h16(x)], U.h16(dz), kshape, kind, s, 2, None, None, f32=True)

@@ -187,14 +187,17 @@ def test_baseline_config_at_its_own_size(cfg):
     assert flipped <= ties
     assert pads_are_zero(model32) is None
 
-    # ---- parity mode with two MFMAs per product in the BACKWARD GEMMs (build(backward="2mfma")): the forward pass is the same bits
-    # (outputs, masks, every decision - asserted), so the strict leg's imposed-decision oracle pass serves this one too; every parameter
-    # gradient within ARITH_L2_2MFMA = 1e-3 relative L2 of it (same per-tensor form and noise floor as above)
+    # ---- the product's default, build(backward="auto"): two MFMAs per product in the backward GEMMs - data gradients with the weight
+    # operand as its fp16 hi half where the model's chain of convolutions is short enough (C1, C2, C3, C5: b2w2), weight gradients with
+    # the layer input as its hi half everywhere (C4: d3w2).  The forward pass is the same bits (outputs, masks, every decision -
+    # asserted), so the strict leg's imposed-decision oracle pass serves this one too; every parameter gradient within
+    # ARITH_L2_2MFMA = 1e-3 relative L2 of it (same per-tensor form and noise floor as above).  SEG_FULLSIZE_BWD_MODES=b2w1,d2w2,...
+    # reports other modes (gpurun_out/fullsize_report.json)
     strict_outs = [got for got, _ref in r["out_tensors"]]
     imposed_oracle = r["imposed_oracle"]
     del model32, r
     torch.cuda.empty_cache()
-    for mode in os.environ.get("SEG_FULLSIZE_BWD_MODES", "2mfma").split(","):
+    for mode in os.environ.get("SEG_FULLSIZE_BWD_MODES", "auto").split(","):
         model2, _x, _t, _l = CONFIGS[cfg](n)
         model2.build(n, dtype="f32", backward=mode)
         model2.set_weights(w)
@@ -208,7 +211,7 @@ def test_baseline_config_at_its_own_size(cfg):
         own2 = {k: e / (nrm + 5e-3 * gn) for k, (e, nrm) in r["gl2"].items()}
         zero_noise2 = max((e / gn for k, (e, _n) in r["gl2_imposed"].items() if k in zero), default=0.0)
         wk = max(imposed2, key=imposed2.get)
-        _record(cfg, f"f32_gradients_backward_{mode}", {"rel_l2_decisions_imposed_worst_well_conditioned": max(plain2.values()),
+        _record(cfg, f"f32_gradients_backward_{mode}", {"resolved_to": model2.backward_spec,"rel_l2_decisions_imposed_worst_well_conditioned": max(plain2.values()),
                                                        "rel_l2_decisions_imposed_worst": imposed2[wk], "rel_l2_decisions_imposed_worst_tensor": wk,
                                                        "rel_l2_decisions_imposed_median": float(np.median(list(imposed2.values()))),
                                                        "rel_l2_own_decisions_worst": max(own2.values()),
@@ -378,12 +381,18 @@ def test_load_keras_model_walks_the_layer_graph_into_the_engine():
 
 
 @pytest.mark.parametrize("cfg,dtype", [("C1", "f16"), ("C2", "f16"), ("C3", "f16"), ("C5", "f16"), ("C4", "f16"),
-                                       ("C1", "f32"), ("C2", "f32"), ("C3", "f32"), ("C4", "f32"), ("C5", "f32")])
+                                       ("C1", "f32"), ("C2", "f32"), ("C3", "f32"), ("C4", "f32"), ("C5", "f32"),
+                                       ("C1", "auto"), ("C2", "auto"), ("C3", "auto"), ("C4", "auto"), ("C5", "auto")])
 def test_three_steps_reduce_the_loss_at_the_baseline_batch(cfg, dtype):
+    """dtype "f32": the parity mode with the strict backward pass; "auto": the parity mode as the product builds it (backward="auto")."""
     torch.manual_seed(5)
     n = BASELINE_BATCH[cfg]
     model, x, targets, loss = CONFIGS[cfg](n)
-    model.build(n, dtype=dtype)
+    if dtype == "auto":
+        model.build(n, dtype="f32", backward="auto")
+        assert model.backward_spec == ("d3w2" if cfg == "C4" else "b2w2")
+    else:
+        model.build(n, dtype=dtype)
     model.compile(loss=loss, lr=2e-4)
     losses = [float(model.train_step(x, targets).cpu()) for _ in range(4)]
     assert all(np.isfinite(losses)), losses
@@ -399,11 +408,11 @@ def test_training_is_bit_reproducible_at_the_headline_config():
     32 x 32 tile of a deep-level data gradient - a write-after-read hazard on an LDS ring slot across s_barrier (fragment reads
     issued but not returned when the slot was refilled), visible only with the other stream's kernels backing up the LDS; every
     ring kernel now waits for its own LDS reads in front of the slot-releasing barrier (tools/repro_probe.py)."""
-    def run(side_stream, steps, grads_only=False, dtype="f16"):
+    def run(side_stream, steps, grads_only=False, dtype="f16", backward=None):
         torch.manual_seed(5)
         model, x, targets, loss = CONFIGS["C3"](16)
         model.use_side_stream = side_stream
-        model.build(16, dtype=dtype)
+        model.build(16, dtype=dtype, backward=backward)
         model.compile(loss=loss, lr=2e-4)
         assert any(op.wg_partial is not None for op in model.ops if hasattr(op, "wg_partial"))
         for _ in range(steps):
@@ -428,3 +437,8 @@ def test_training_is_bit_reproducible_at_the_headline_config():
     p0, s0, g0 = run(True, 2, grads_only=True, dtype="f32")
     p1, s1, g1 = run(True, 2, grads_only=True, dtype="f32")
     assert torch.equal(p0, p1) and torch.equal(s0, s1) and torch.equal(g0, g1), "parity mode: two identical runs differ"
+    del p0, p1, s0, s1, g0, g1
+    # ... and as the product builds it (backward="auto": the two-MFMA forms of the halo kernels)
+    p0, s0, g0 = run(True, 2, grads_only=True, dtype="f32", backward="auto")
+    p1, s1, g1 = run(True, 2, grads_only=True, dtype="f32", backward="auto")
+    assert torch.equal(p0, p1) and torch.equal(s0, s1) and torch.equal(g0, g1), "parity mode, backward='auto': two identical runs differ"

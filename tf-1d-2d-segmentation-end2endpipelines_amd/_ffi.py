@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SEG_LIB") or os.path.join(_HERE, "libseg_hip.so")
 
 MAX_SEG, MAX_TAPS, MAX_CLS = 8, 32, 4
 SEG_VARIANT_A_HI = SEG_VARIANT_IN_HI = 0x1000          # include/seg_hip.h
-SEG_VARIANT_DZ_HI = 0x2000
+SEG_VARIANT_DZ_HI = SEG_VARIANT_B_HI = 0x2000
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "leaky_relu": 2, "sigmoid": 3, "softmax": 4}
 LOSS = {"mse": 0, "bce": 1, "cce": 2, "mae": 3, "mape": 4, "msle": 5, "huber": 6, "logcosh": 7, "poisson": 8, "hinge": 9,
         "squared_hinge": 10, "binary_focal": 11, "kld": 12, "categorical_hinge": 13, "cosine": 14, "sparse_cce": 15}

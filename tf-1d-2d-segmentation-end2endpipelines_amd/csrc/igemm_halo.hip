@@ -18,14 +18,19 @@ namespace {
 // BN = 32 (parity mode, layers of at most 32 output channels - MultiResUNet's 8 / 17 / 26-filter convs at full resolution): the
 // weight stage keeps its 64 rows (the upper 32 are out of range and cost no memory traffic), a wave owns 64 px x ONE 32-channel
 // tile - half the MFMAs and B-fragment reads of the 64-channel tile, whose upper half would multiply zeros.
-// AHI (parity mode, data gradients only - variant bit SEG_VARIANT_A_HI): the A operand - the incoming gradient dz - is read as its hi
-// half alone: a b ~= ah bh + ah bl / 2048.  The `al` fragment reads and the `al bh` MFMA go (a third of both); every product keeps the
-// whole weight operand and loses 2^-11 of dz, elementwise and unbiased.  NOT the forward pass.
-template <int PW, int BN, int NT, int TG, int NPL, bool SPLIT = false, bool AHI = false>
+// HI (parity mode, data gradients only): two MFMAs per product instead of three.
+//   HI = 1 (variant bit SEG_VARIANT_A_HI): the A operand - the incoming gradient dz - is read as its hi half alone,
+//           a b ~= ah bh + ah bl / 2048: the `al` fragment reads and the `al bh` MFMA go (a third of both).  dz spans the whole fp16 range
+//           below the loss scale: elements under 2^-14 lose bits in their hi half, under 2^-24 everything.
+//   HI = 2 (SEG_VARIANT_B_HI): the B operand - the transposed weights, O(1) numbers in fp16's normal range - as its hi half,
+//           a b ~= ah bh + al bh / 2048: the `bl` reads and the `ah bl` MFMA go; dz keeps its 22 bits and its range.
+// NOT the forward pass.
+template <int PW, int BN, int NT, int TG, int NPL, bool SPLIT = false, int HI = 0>
 __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(SPLIT ? (BN == 64 || BN == 32) : (BN == 64 || BN == 128), "parity mode: 64 x 64 (or 64 x 32) accumulators per wave, twice");
-  static_assert(SPLIT || !AHI, "the hi-only A operand is a parity-mode form");
+  static_assert(SPLIT || HI == 0, "the hi-only operands are parity-mode forms");
+  constexpr bool AHI = HI == 1, BHI = HI == 2;
   typedef std::conditional_t<SPLIT, split_t, half_t> TO;
   constexpr int PH = 256 / PW, HC = PW + 2, HROWS = (PH + 2) * HC;
   constexpr int NI_A = (HROWS + 15) / 16;                  // LDS-DMA wave instructions per halo tile (16 rows of 64 B)
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
         o0[a] = (row << 6) + (((SPLIT ? 2 * fh : fh) ^ ((row >> 2) & 3)) << 4);
       }
       if constexpr (SPLIT) {
-        h8 ah[TMw], al[AHI ? 1 : TMw], bh[TNw], bl[TNw];
+        h8 ah[TMw], al[AHI ? 1 : TMw], bh[TNw], bl[BHI ? 1 : TNw];
 #pragma unroll
         for (int a = 0; a < TMw; ++a) {
           ah[a] = *reinterpret_cast<const h8*>(A + o0[a]);
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
 #pragma unroll
         for (int b = 0; b < TNw; ++b) {
           bh[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][0]);
-          bl[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][1]);
+          if constexpr (!BHI) bl[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][1]);
         }
 #pragma unroll
         for (int a = 0; a < TMw; ++a)
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
           for (int b = 0; b < TNw; ++b) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
             if constexpr (!AHI) accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], accl[a][b], 0, 0, 0);
-            accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
+            if constexpr (!BHI) accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
           }
       } else {
 #pragma unroll
@@ -336,14 +341,22 @@ template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 1, true>(const seg_igem
 template __global__ void igemm_fwd3_kernel<32, 32, 4, 2, 4, true>(const seg_igemm_fwd_args);
 template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 4, true>(const seg_igemm_fwd_args);
 // parity mode, data gradients with the hi-only A operand (two MFMAs per product): the 3x3 layers and the transposed conv's planes form
-template __global__ void igemm_fwd3_kernel<32, 64, 9, 3, 1, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 64, 9, 3, 1, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<32, 32, 9, 3, 1, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 32, 9, 3, 1, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<32, 32, 4, 2, 4, true, true>(const seg_igemm_fwd_args);
-template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 4, true, true>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 9, 3, 1, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 9, 3, 1, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 9, 3, 1, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 9, 3, 1, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 4, 2, 4, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 4, true, 1>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 9, 3, 1, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 9, 3, 1, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 64, 4, 2, 4, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 64, 4, 2, 4, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 9, 3, 1, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 9, 3, 1, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<32, 32, 4, 2, 4, true, 2>(const seg_igemm_fwd_args);
+template __global__ void igemm_fwd3_kernel<16, 32, 4, 2, 4, true, 2>(const seg_igemm_fwd_args);
 
 }  // namespace
 
@@ -434,7 +447,7 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
 }
 
 // ---- parity mode: `v` is the split view of the arguments (igemm_common.h: the loaders' pseudo-channels); 256 x 64 and 256 x 32 tiles
-template <int NT, int TG, int NPL, bool AHI = false>
+template <int NT, int TG, int NPL, int AHI = 0>
 static void launch_fwd3_split_nt(const seg_igemm_fwd_args& v, int pw, dim3 grid, hipStream_t st) {
   const int ni_a = pw == 32 ? 22 : 21;
   const size_t lds = (size_t)2 * ni_a * 1024 + 3 * (TG * 4096);
@@ -456,10 +469,12 @@ int seg_launch_fwd3_split(const seg_igemm_fwd_args& v, hipStream_t st) {
   const int npatch = (int)((long)v.g.N * v.g.Hl * v.g.Wl / 256);
   const int nblocks = (v.n_rows + v.tile_n - 1) / v.tile_n;
   dim3 grid((unsigned)(npatch * nblocks), (unsigned)v.g.ncls, 1);
-  const bool ahi = (v.variant & SEG_VARIANT_A_HI) != 0;      // data gradients: the A operand (dz) as its hi half, two MFMAs per product
-  SEG_CHECK_ARG(!ahi || v.g.ntaps != 4, "seg_igemm_fwd_f32: SEG_VARIANT_A_HI is a data-gradient form (3x3 layers, the transposed conv's planes), not the transposed conv's forward pass");
-  if (v.g.ntaps == 16) { if (ahi) launch_fwd3_split_nt<4, 2, 4, true>(v, pw, grid, st); else launch_fwd3_split_nt<4, 2, 4>(v, pw, grid, st); }
-  else if (v.g.ntaps == 9) { if (ahi) launch_fwd3_split_nt<9, 3, 1, true>(v, pw, grid, st); else launch_fwd3_split_nt<9, 3, 1>(v, pw, grid, st); }
+  // data gradients: the A operand (dz) or the B operand (the transposed weights) as its hi half - two MFMAs per product
+  const int hi = (v.variant & SEG_VARIANT_A_HI) ? 1 : (v.variant & SEG_VARIANT_B_HI) ? 2 : 0;
+  SEG_CHECK_ARG(!((v.variant & SEG_VARIANT_A_HI) && (v.variant & SEG_VARIANT_B_HI)), "seg_igemm_fwd_f32: SEG_VARIANT_A_HI and SEG_VARIANT_B_HI exclude each other");
+  SEG_CHECK_ARG(hi == 0 || v.g.ntaps != 4, "seg_igemm_fwd_f32: SEG_VARIANT_A_HI / _B_HI are data-gradient forms (3x3 layers, the transposed conv's planes), not the transposed conv's forward pass");
+  if (v.g.ntaps == 16) { if (hi == 1) launch_fwd3_split_nt<4, 2, 4, 1>(v, pw, grid, st); else if (hi == 2) launch_fwd3_split_nt<4, 2, 4, 2>(v, pw, grid, st); else launch_fwd3_split_nt<4, 2, 4>(v, pw, grid, st); }
+  else if (v.g.ntaps == 9) { if (hi == 1) launch_fwd3_split_nt<9, 3, 1, 1>(v, pw, grid, st); else if (hi == 2) launch_fwd3_split_nt<9, 3, 1, 2>(v, pw, grid, st); else launch_fwd3_split_nt<9, 3, 1>(v, pw, grid, st); }
   else launch_fwd3_split_nt<4, 2, 1>(v, pw, grid, st);
   SEG_CHECK_LAUNCH("seg_igemm_fwd_f32 (halo tiles)");
   return SEG_OK;

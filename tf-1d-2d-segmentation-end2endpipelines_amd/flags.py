@@ -55,8 +55,15 @@ HEAD_INJECT = os.environ.get("SEG_HEAD_INJECT", "1") != "0"            # ... and
 WGRAD_BLOCKS = 1536       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = 256   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
-# parity mode, the BACKWARD GEMMs only: "3mfma" = every product a b ~= ah bh + (al bh + ah bl) / 2048 like the forward pass; "2mfma" = the data
-# gradients read the incoming gradient dz as its hi half (ah bh + ah bl / 2048), the weight gradients the layer INPUT as its hi half
-# (ah bh + al bh / 2048) - a third of the MFMAs and of the LDS fragment reads go, the rounded operand loses 2^-12 rms, elementwise and
-# unbiased; the forward pass, `predict` and the masks are the same bits in both modes (SegModel.build(backward=)).
-BACKWARD = os.environ.get("SEG_BACKWARD", "3mfma")
+# parity mode, the BACKWARD GEMMs only (SegModel.build(backward=)): how many fp16 MFMAs a product costs there.  The forward
+# pass - outputs, masks, `predict` - is the same bits in every mode.  "<d|b><D>w<W>": D = 3 | 2 MFMAs per product in the data gradients
+# (d2: the incoming gradient dz read as its fp16 hi half; b2: the transposed WEIGHTS read as theirs - O(1) numbers in fp16's normal
+# range, where dz spans everything below the loss scale), W = 3 | 2 | 1 in the weight gradients (2: the layer input as its hi half; 1: dz as
+# well).  "3mfma" = d3w3: every product a b ~= ah bh + (al bh + ah bl) / 2048 as in the forward pass; "2mfma" = b2w2.
+# "auto" (the default): b2w2 when the model's longest chain of convolutions (Graph.longest_conv_chain) is at most BACKWARD_AUTO_CHAIN
+# layers, else d3w2.  A weight gradient's rounding lands once, in dW; a data gradient's is inherited by every layer below it and grows
+# with the chain.  Measured at the BASELINE geometries, per parameter tensor, relative L2 against the oracle with the decisions imposed
+# (tests/test_gpu_fullsize.py, tolerance 1e-3): b2w2 6.3e-4 / 4.8e-4 / 6.8e-4 on C2 / C3 / C5 (chains of 19 - 20), 1.5e-3 on C4 (52);
+# d3w2 3.8e-4 / 3.1e-4 / 3.8e-4 and 2.8e-4 on C4; d3w3 7e-6 / 3e-6 / 7e-6 and 9e-5.
+BACKWARD = os.environ.get("SEG_BACKWARD", "auto")
+BACKWARD_AUTO_CHAIN = 32

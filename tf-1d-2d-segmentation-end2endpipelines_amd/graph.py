@@ -256,6 +256,15 @@ class Graph:
                 tot += n.shape[0] * n.shape[1] * kh * kw * cin * convlstm_gates * n.attrs["filters"]
         return tot
 
+    def longest_conv_chain(self) -> int:
+        """Convolution-type layers (conv, transposed conv, ConvLSTM, the Dense bottleneck) on the longest path from the input to an
+        output: how many data-gradient GEMMs the gradient of the first layer has passed through (SegModel.build(backward="auto"))."""
+        depth: Dict[int, int] = {}
+        for i in self.live_nodes():
+            n = self.nodes[i]
+            depth[i] = max((depth[j] for j in n.inputs), default=0) + (1 if n.kind in ("conv", "convT", "convlstm", "dense_ae") else 0)
+        return max((depth[o] for o in self.outputs), default=0)
+
     def conv_io_elements(self) -> Tuple[int, int]:
         """(activation elements read + written by the conv / convT / ConvLSTM layers per sample, weight elements):
         the algorithmic HBM traffic of a fully fused forward pass (the HBM-bound configurations)."""

@@ -137,7 +137,7 @@ class SegModel:
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
-        self.backward_mode, self.bwd_d, self.bwd_w = None, 3, 3       # build(backward=): MFMAs per product of the backward GEMMs (parity mode)
+        self.backward_mode, self.backward_spec, self.bwd_d, self.bwd_w = None, "d3w3", 3, 3       # build(backward=): MFMAs per product of the backward GEMMs (parity mode)
         if batch_size is not None:
             self.build(batch_size)
 
@@ -267,14 +267,15 @@ class SegModel:
 
     def build(self, batch_size: int, dtype: Optional[str] = None, backward: Optional[str] = None):
         """backward (parity mode only; the throughput mode has one MFMA per product everywhere): how many fp16 MFMAs a product of the
-        BACKWARD GEMMs costs - "d<D>w<W>" with D in {3, 2} for the data gradients and W in {3, 2, 1} for the weight gradients;
-        "3mfma" = "d3w3" (every product as in the forward pass), "2mfma" = "d2w2" (flags.BACKWARD is the default).  The forward
-        pass is the same bits in every mode."""
+        BACKWARD GEMMs costs - "auto" (flags.BACKWARD: the default), "3mfma", "2mfma" or an explicit "<d|b><3|2>w<3|2|1>"; see flags.py.
+        The forward pass is the same bits in every mode.  `backward_mode` keeps what was asked for, `backward_spec` what it resolved to."""
         backward = backward or self.backward_mode or F.BACKWARD
-        spec = {"3mfma": "d3w3", "2mfma": "d2w2"}.get(backward, backward)
-        if spec not in ("d3w3", "d3w2", "d3w1", "d2w3", "d2w2", "d2w1"):
-            raise ValueError("backward must be '3mfma', '2mfma' or 'd<3|2>w<3|2|1>'")
-        self.backward_mode = backward
+        spec = {"3mfma": "d3w3", "2mfma": "b2w2"}.get(backward, backward)
+        if spec == "auto":
+            spec = "b2w2" if self.graph.longest_conv_chain() <= F.BACKWARD_AUTO_CHAIN else "d3w2"
+        if spec not in ("d3w3", "d3w2", "d3w1", "d2w3", "d2w2", "d2w1", "b2w3", "b2w2", "b2w1"):
+            raise ValueError("backward must be 'auto', '3mfma', '2mfma' or '<d|b><3|2>w<3|2|1>'")
+        self.backward_mode, self.backward_spec = backward, spec
         if dtype is not None:
             if dtype not in ("f16", "f32"):
                 raise ValueError("dtype must be 'f16' or 'f32'")
@@ -282,7 +283,9 @@ class SegModel:
                 self.grad_target = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.grad_target_max = F.GRAD_TARGET_F32 if dtype == "f32" else F.GRAD_TARGET
             self.dtype = dtype
-        self.bwd_d, self.bwd_w = (int(spec[1]), int(spec[3])) if self.dtype == "f32" else (1, 1)     # MFMAs per product: data / weight gradients
+        # MFMAs per product of the parity mode's data / weight gradients (3 = no operand halved; the throughput mode has no split operands to halve)
+        self.bwd_d, self.bwd_w = (int(spec[1]), int(spec[3])) if self.dtype == "f32" else (3, 3)
+        self.bwd_d_flag = 0 if self.bwd_d != 2 else (_ffi.SEG_VARIANT_B_HI if spec[0] == "b" else _ffi.SEG_VARIANT_A_HI)     # which operand a two-MFMA data gradient halves
         self._enter()
         DevTensor.dtype = torch.float16 if self.dtype == "f16" else torch.float32
         if not _DryRun.on:

@@ -565,7 +565,7 @@ class ConvOp(Op):
             a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16",
                                                                [a.seg_cs[j] for j in range(a.nseg)], width * self.g_dgrad.T_total * self.rows_pad)
             if self.m.bwd_d == 2 and (a.variant & 255) == 3 and self.g_dgrad.ntaps != 4:
-                a.variant |= _ffi.SEG_VARIANT_A_HI          # (dz as its hi half: two MFMAs per product in the data gradients)
+                a.variant |= self.m.bwd_d_flag              # (one operand as its hi half: two MFMAs per product in the data gradients)
             self.m.fwd_ws_users.append(a)
             self.dg_args.append((a, zero_first, fl))
             self.dg_bytes.append(float(nb + self.esz * self.out_pix * self.cout))          # ... and dz read once
@@ -685,7 +685,7 @@ class GatherDgrad:
         a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16",
                                                            [a.seg_cs[j] for j in range(a.nseg)], self.t.cs * op0.g_dgrad.T_total * self.Kg)
         if self.m.bwd_d == 2 and (a.variant & 255) == 3 and op0.g_dgrad.ntaps != 4:
-            a.variant |= _ffi.SEG_VARIANT_A_HI
+            a.variant |= self.m.bwd_d_flag
         self.m.fwd_ws_users.append(a)
         self.args = a
         self.flops = sum(op.flops_seg[si] for op, si in self.members)
