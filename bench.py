@@ -45,16 +45,75 @@ PKG = "tf-1d-2d-segmentation-end2endpipelines_amd"
 PEAK_TFLOPS_F16 = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters): the peak every fraction is quoted against
 MFMA_PER_PRODUCT = {"f16": 1, "f32": 3}      # parity mode: every product is three fp16 MFMAs on split operands
 PEAK_HBM_GBS = 8000.0
-DTYPE_DETAIL = {"f32": "parity mode: tensors stored as split fp16 pairs (hi + lo / 2048, ~22 bits), 3 fp16 MFMAs per product, fp32 accumulate",
+DTYPE_DETAIL = {"f32": "parity mode: tensors stored as split fp16 pairs (hi + lo / 2048, ~22 bits), fp32 accumulate; 3 fp16 MFMAs per product in the forward "
+                       "pass, 2 or 3 in the backward GEMMs (key `backward`)",
                 "f16": "throughput mode: fp16 storage, 1 fp16 MFMA per product, fp32 accumulate (does not meet the 1e-3 tolerance)"}
 
 
-def mfma_view(tflops, dtype):
+def mfma_view(tflops, dtype, k=None):
     """The three readings of a GEMM rate: algorithmic TFLOP/s against the fp16 datasheet peak (the contract's `frac`), the MFMA
-    work actually issued, and the fraction of the peak this mode can reach at all (peak / MFMAs per product)."""
-    k = MFMA_PER_PRODUCT[dtype]
-    return {"frac": tflops / PEAK_TFLOPS_F16, "mfma_per_product": k, "mfma_issued_tflops": tflops * k,
+    work actually issued, and the fraction of the peak this mode can reach at all (peak / MFMAs per product).  k: FLOP-weighted
+    mean of the MFMAs per product over the launches the rate is quoted on (launch_mfma) - 3 for a forward launch of the parity mode,
+    2 or 3 for a backward one (SegModel.build(backward=)); default: the mode's forward figure."""
+    k = MFMA_PER_PRODUCT[dtype] if k is None else k
+    return {"frac": tflops / PEAK_TFLOPS_F16, "mfma_per_product": round(k, 3), "mfma_issued_tflops": tflops * k,
             "frac_of_peak_over_mfma_per_product": tflops * k / PEAK_TFLOPS_F16}
+
+
+def launch_mfma(tag, dtype):
+    """fp16 MFMAs per product of one profiled GEMM launch: ops.mfma_tag appends "|m<k>" to its tag."""
+    if "|m" in tag:
+        return int(tag.rsplit("|m", 1)[1])
+    return MFMA_PER_PRODUCT[dtype]
+
+
+def mean_mfma(KP, dtype, pick):
+    """FLOP-weighted MFMAs per product over the profiled GEMM launches `pick(name, tag)` selects."""
+    num = den = 0.0
+    for name, tag, flops, _b, _e0, _e1 in KP.records:
+        if name.replace("_f32", "") in ("seg_igemm_fwd", "seg_igemm_wgrad") and pick(name.replace("_f32", ""), tag):
+            num += flops * launch_mfma(tag, dtype)
+            den += flops
+    return num / den if den else float(MFMA_PER_PRODUCT[dtype])
+
+
+def pass_mfma(KP, dtype):
+    """{pass: FLOP-weighted MFMAs per product} for the forward, data-gradient and weight-gradient launches of the profiled step."""
+    return {"forward": round(mean_mfma(KP, dtype, lambda n, t: t.startswith("fwd:")), 3),
+            "data_gradient": round(mean_mfma(KP, dtype, lambda n, t: t.startswith("dgrad:")), 3),
+            "weight_gradient": round(mean_mfma(KP, dtype, lambda n, t: t.startswith("wgrad:")), 3)}
+
+
+def pmc_mfma_busy(workload, dtype):
+    """MFMA-busy share of the dominant GEMM kernel from the newest committed SQ counter summary of this workload and mode
+    (profiles/*_<workload>_<dtype>_pmc_sq2.csv, tools/profile_run.sh full): SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's 1 024 SIMDs)
+    / (1 024 x launch duration x clock).  The duration comes from the kernel-stats summary of the same profile tag and the clock is
+    taken as 2.4 GHz (the counter has no clock of its own), so this is a LOWER bound: under an MFMA-dense load the part runs at
+    1.5 - 1.95 GHz (MI355X guide)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload.lower()}_{dtype}_pmc_sq2.csv")))
+    if not files:
+        return None
+    f = files[-1]
+    stats = f.replace("_pmc_sq2.csv", "_kernel_stats_single_stream.csv")
+    if not os.path.exists(stats):
+        return None
+    try:
+        dur = {r["kernel"]: (float(r["avg_us"]), float(r["total_ms"])) for r in csv.DictReader(open(stats))}
+        best = None
+        for r in csv.DictReader(open(f)):
+            k = r.get("kernel")
+            if k in dur and "igemm" in k and (best is None or dur[k][1] > dur[best["kernel"]][1]):
+                best = r
+        if best is None:
+            return None
+        cyc = float(best["SQ_VALU_MFMA_BUSY_CYCLES"])
+        us = dur[best["kernel"]][0]
+        return {"kernel": best["kernel"], "avg_launch_us": us, "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": cyc,
+                "mfma_busy": round(cyc / (1024 * us * 1e-6 * 2.4e9), 4), "clock_assumed_ghz": 2.4, "source": os.path.relpath(f, ROOT)}
+    except Exception as e:          # informational only
+        return {"error": repr(e), "source": os.path.relpath(f, ROOT)}
 
 WORKLOADS = {
     # name: (builder kwargs, H, W, Cin, batch/GPU, loss, description)
@@ -98,16 +157,28 @@ def make_batch(model, N, H, W, Cin, loss, rank):
     return x.cuda(), [t.cuda() for t in targets]
 
 
-def build_model(workload, dtype, bs=0):
+def build_model(workload, dtype, bs=0, backward=None):
     pkg = importlib.import_module(PKG)
     kw, H, W, Cin, bs0, loss, _desc = WORKLOADS[workload]
     if kw.get("one_d"):
         model = pkg.UNet1D(W, kw["model_depth"], Cin, kw["model_width"], kw["kernel_size"], kw["problem_type"], output_nums=kw["output_nums"], ds=kw["ds"]).UNet()
     else:
         model = pkg.unet_model_builder(length=H, width=W, num_channels=Cin, train_mode="from_scratch", **kw).ResNet50()
-    model.build(bs or bs0, dtype=dtype)
+    model.build(bs or bs0, dtype=dtype, backward=backward)       # backward=None: the package default (flags.BACKWARD = "auto")
     model.compile(loss=loss, lr=2e-4)
     return model
+
+
+def backward_info(model, KP=None):
+    """What SegModel.build(backward=) was asked for and resolved to, and - from a profiled step - the MFMAs per product of each pass."""
+    d = {"mode": model.backward_mode, "resolved": model.backward_spec if model.dtype == "f32" else None,
+         "what": ("parity mode, BACKWARD GEMMs only: '<d|b><D>w<W>' = D fp16 MFMAs per product in the data gradients (b: the transposed weights "
+                  "read as their fp16 hi half), W in the weight gradients (the layer input as its hi half); the forward pass, predict and the "
+                  "masks are the same bits in every mode; every parameter gradient within 1e-3 relative L2 of the oracle with the decisions "
+                  "imposed (tests/test_gpu_fullsize.py)") if model.dtype == "f32" else "throughput mode: one MFMA per product everywhere"}
+    if KP is not None:
+        d["mfma_per_product_by_pass"] = pass_mfma(KP, model.dtype)
+    return d
 
 
 def flops_per_image(model, Cin):
@@ -213,12 +284,12 @@ def time_loop(fn, warmup, steps, barrier):
     return time.perf_counter() - t0
 
 
-def short_run(workload, dtype, steps, warmup, profile=True, batch=0, graph=False):
+def short_run(workload, dtype, steps, warmup, profile=True, batch=0, graph=False, backward=None):
     """A short single-GPU run of another configuration / mode (or another batch): ms per step, images/s, its roofline figure.
     graph: the step replayed as one captured hipGraph (launch-bound small models)."""
     kw, H, W, Cin, bs, loss, desc = WORKLOADS[workload]
     bs = batch or bs
-    model = build_model(workload, dtype, bs)
+    model = build_model(workload, dtype, bs, backward)
     x, targets = make_batch(model, bs, H, W, Cin, loss, 0)
     step = model.graphed_train_step(x, targets) if graph else model.train_step
     dt = time_loop(lambda: step(x, targets), warmup, steps, torch.cuda.synchronize)
@@ -229,6 +300,7 @@ def short_run(workload, dtype, steps, warmup, profile=True, batch=0, graph=False
            "images_per_s": round(bs * steps / dt, 2), "gflop_per_image_fwd_bwd": round(fl / 1e9, 2),
            "whole_step_tflops": round(fl * bs / (ms * 1e-3) / 1e12, 1), "hbm_resident_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
            "final_loss": float(model.loss_buf.cpu())}
+    res["backward"] = backward_info(model)
     res["whole_step_frac_of_mfma_peak"] = round(res["whole_step_tflops"] / peak, 4)
     if workload in HBM_BOUND:
         act, wts = model.graph.conv_io_elements()
@@ -244,10 +316,12 @@ def short_run(workload, dtype, steps, warmup, profile=True, batch=0, graph=False
         gs = gemm_summary(KP, peak)
         summ = KP.summary()
         res["gemm"] = gs
+        res["backward"] = backward_info(model, KP)
         res["kernel_ms_per_step"] = {k: round(v["seconds"] * 1e3, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:8]}
         if workload not in HBM_BOUND and "conv_stack" in gs:
             res["roofline"] = {"bound": "mfma", "kernel": "3x3 conv stack (forward, data and weight gradients)", "achieved": gs["conv_stack"]["tflops"],
-                               "peak": peak, "unit": "TFLOP/s", **mfma_view(gs["conv_stack"]["tflops"], dtype)}
+                               "peak": peak, "unit": "TFLOP/s",
+                               **mfma_view(gs["conv_stack"]["tflops"], dtype, mean_mfma(KP, dtype, lambda n, t: "tconv" not in t))}
     del model, x, targets
     gc.collect()
     torch.cuda.empty_cache()
@@ -380,6 +454,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=("f32", "f16"),
                     help="f32 (default): the parity mode - split fp16 pairs, 3 MFMAs per product, outputs within 1e-3 of the fp32 oracle; "
                          "f16: fp16 storage, 1 MFMA per product (throughput mode, misses the 1e-3 tolerance)")
+    ap.add_argument("--backward", default=None,
+                    help="parity mode: MFMAs per product of the backward GEMMs - auto (default: b2w2 where the model's depth allows it), 3mfma, 2mfma, "
+                         "<d|b><3|2>w<3|2|1> (SegModel.build(backward=), flags.py)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity-mode / inference / other-configuration legs")
@@ -420,7 +497,7 @@ def main():
     kw, H, W, Cin, bs, loss, desc = WORKLOADS[args.workload]
     if args.batch:
         bs = args.batch
-    model = build_model(args.workload, args.dtype, bs)
+    model = build_model(args.workload, args.dtype, bs, args.backward)
     dpm = dp.DataParallel(model, force_exchange=args.force_exchange)
     x, targets = make_batch(model, bs, H, W, Cin, loss, rank)
 
@@ -471,7 +548,9 @@ def main():
         traffic, traffic_src = pmc_traffic(dom, args.workload, args.dtype)
         gemm_s = sum(v["seconds"] for v in gemm.values())
         roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    **mfma_view(ach, args.dtype), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                    **mfma_view(ach, args.dtype, mean_mfma(KP, args.dtype, lambda n, t: n == dom)),
+                    "mfma_per_product_by_pass": pass_mfma(KP, args.dtype),
+                    "mfma_busy": pmc_mfma_busy(args.workload, args.dtype), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                     "traffic_source": traffic_src, "launches": d_["launches"],
                     "avg_launch_us": d_["seconds"] / d_["launches"] * 1e6,
                     "algorithmic_flops_per_launch": d_["flops"] / d_["launches"],
@@ -515,7 +594,8 @@ def main():
     except Exception as e:          # informational only
         rccl["version"] = f"unavailable: {e!r}"
 
-    inference = parity = None
+    inference = parity = strict = None
+    bwd_line = backward_info(model, KP if (not args.no_profile and rank == 0) else None)
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras and args.workload != "tiny":
         # ---- forward-only (inference-mode BN) on the same model
@@ -535,6 +615,19 @@ def main():
             parity["what"] = DTYPE_DETAIL[other]
         except Exception as e:
             parity = {"error": repr(e)}
+        # ---- the north star's literal figure - fp16 MFMA fraction of the UNet (C2) 3x3 conv stack - in the throughput mode
+        if other == "f16" and args.workload != "C2":
+            try:
+                parity["extra_workloads"] = {"C2": short_run("C2", "f16", 20, 3, profile=True)}
+            except Exception as e:
+                parity["extra_workloads"] = {"C2": {"error": repr(e)}}
+        # ---- the same workload with the STRICT backward pass (three MFMAs per product there too), when the headline run did not use it
+        if args.dtype == "f32" and bwd_line.get("resolved") != "d3w3":
+            try:
+                strict = short_run(args.workload, "f32", max(10, args.steps // 2), 5, profile=True, backward="3mfma")
+                strict["what"] = "the same workload with backward='3mfma': every product of the backward GEMMs three MFMAs, like the forward pass"
+            except Exception as e:
+                strict = {"error": repr(e)}
         # ---- the other BASELINE configurations (same code path, short runs)
         for wl in ("C2", "C5", "C4", "C4w64"):
             if wl == args.workload:
@@ -570,7 +663,7 @@ def main():
         line = {"metric": "images/sec fwd+bwd, UNet++ depth-5 256x256 bs=16/GPU" if args.workload == "C3" else f"images/sec fwd+bwd ({args.workload})",
                 "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-                "dtype_detail": DTYPE_DETAIL[args.dtype],
+                "dtype_detail": DTYPE_DETAIL[args.dtype], "backward": bwd_line,
                 "tolerance": ("every output within 1e-3 of the fp32 oracle, masks equal: asserted at this configuration's own geometry in "
                               "tests/test_gpu_fullsize.py" if args.dtype == "f32" else
                               "NOT the 1e-3 mode: measured 1.6e-3 .. 1.1e-1 at the BASELINE geometries (tests/test_gpu_fullsize.py); the parity "
@@ -582,7 +675,7 @@ def main():
                                                "first_loss": first_loss, "final_loss": loss_val,
                                                "loss_decreased": (first_loss is not None and loss_val < first_loss)},
                 "roofline": roofline, "cpu_baseline": cpu, ("throughput_mode" if args.dtype == "f32" else "parity_mode"): parity,
-                "inference": inference, "rccl": rccl,
+                "strict_backward": strict, "inference": inference, "rccl": rccl,
                 "extra_workloads": extras}
         result = json.dumps(line)
     # the JSON line is the LAST thing on stdout: tear the process group down and flush what C libraries (RCCL's version banner)

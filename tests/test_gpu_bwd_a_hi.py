@@ -115,7 +115,7 @@ def test_the_backward_mode_changes_the_backward_pass_only():
     o3, l3, g3, _w, _t, n3 = res["3mfma"]
     o2, l2, g2, _w, _t, n2 = res["2mfma"]
     assert n3 == 0 and n2 > 0
-    assert l3 == l2 and all(torch.equal(a, b) for a, b in zip(o3, o2))
+    assert all(torch.equal(a, b) for a, b in zip(o3, o2)) and abs(l3 - l2) < 1e-6 * abs(l3)       # (the loss is summed with float atomics: order)
     gn = max(float(np.linalg.norm(v)) for v in g3.values())
     worst = max(float(np.linalg.norm(g2[k] - g3[k])) / (float(np.linalg.norm(g3[k])) + 1e-3 * gn) for k in g3)
     assert 1e-7 < worst < 1e-3, worst

@@ -55,6 +55,15 @@ class _Mode:
     sfx = ""
 
 
+def mfma_tag(m, variant: int, wgrad: bool = False) -> str:
+    """"|m<k>" for a GEMM launch's profile tag: fp16 MFMAs per product (bench.py's roofline object states the MFMA work issued)."""
+    if m.dtype == "f16":
+        return "|m1"
+    if wgrad:
+        return "|m1" if variant & _ffi.SEG_VARIANT_DZ_HI else "|m2" if variant & _ffi.SEG_VARIANT_IN_HI else "|m3"
+    return "|m2" if variant & (_ffi.SEG_VARIANT_A_HI | _ffi.SEG_VARIANT_B_HI) else "|m3"
+
+
 def call(name, *args, flops=0.0, nbytes=0.0, tag=""):
     if name in _ffi.DUAL:
         name = name + _Mode.sfx
@@ -449,7 +458,7 @@ class ConvOp(Op):
                      st.ptr(bn + "/moving_variance"), self.eps, st.ptr(self.bname, "P") if self.bname else None, self.n_rows,
                      _p(self.inf_scale), _p(self.inf_shift), s)
                 self._infer_valid = True
-            call("seg_igemm_fwd", C.byref(self.fwd_args_infer), s, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="fwd:" + self.node.name)
+            call("seg_igemm_fwd", C.byref(self.fwd_args_infer), s, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="fwd:" + self.node.name + mfma_tag(self.m, 0))
             if self.pooled is not None:
                 call("seg_maxpool_fwd", _p(self.out.buf), _p(self.pooled.buf), self.out.N, self.out.H, self.out.W, self.out.cs,
                      self.pool_size[0], self.pool_size[1], s)
@@ -457,7 +466,7 @@ class ConvOp(Op):
         a = self.fwd_args if (training and self.has_bn) else self.fwd_args_eval
         if training and self.has_bn:
             self._infer_valid = False      # (this pass updates the moving statistics)
-        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="fwd:" + self.node.name)
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="fwd:" + self.node.name + mfma_tag(self.m, 0))
         if self.has_bn:
             bn = self.bn_name
             call("seg_bn_finalize", _p(self.stats), self.nparts, self.n_rows, self.z.npix, st.ptr(bn + "/gamma"),
@@ -611,7 +620,7 @@ class ConvOp(Op):
             self._bias_grad(dz, s, gs_inv)
         self.wg_args.dz = dz.data_ptr()
         def wgrad(stream):
-            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="wgrad:" + self.node.name)
+            call("seg_igemm_wgrad", C.byref(self.wg_args), stream, flops=self.flops_fwd, nbytes=self.bytes_fwd, tag="wgrad:" + self.node.name + mfma_tag(self.m, self.wg_args.variant, True))
             if self.bias_from_wgrad:
                 call("seg_bn_bwd_finalize", _p(self.wg_bpart), self.wg_bias_parts, self.n_rows, self.z.npix, None, st.ptr(self.bname, "G"),
                      1.0, gs_inv, _p(self.c1), _p(self.c2), stream)
@@ -629,7 +638,7 @@ class ConvOp(Op):
             for t in zero_first:
                 t.grad.zero_()
             a.seg_ptr[0] = dz.data_ptr()
-            call("seg_igemm_fwd", C.byref(a), s, flops=fl, nbytes=nb, tag="dgrad:" + self.node.name)
+            call("seg_igemm_fwd", C.byref(a), s, flops=fl, nbytes=nb, tag="dgrad:" + self.node.name + mfma_tag(self.m, a.variant))
         self.dz_ptr = dz.data_ptr()
         for grp in self.gather_launch:
             grp.launch(s)
@@ -696,7 +705,7 @@ class GatherDgrad:
         a = self.args
         for j, (op, _si) in enumerate(self.members):
             a.seg_ptr[j] = op.dz_ptr
-        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops, nbytes=self.nbytes, tag="dgrad:gather:" + self.t.name)
+        call("seg_igemm_fwd", C.byref(a), s, flops=self.flops, nbytes=self.nbytes, tag="dgrad:gather:" + self.t.name + mfma_tag(self.m, a.variant))
 
 
 def plan_gathers(m, ops) -> List[GatherDgrad]:
