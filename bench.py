@@ -43,7 +43,7 @@ import torch
 
 PKG = "tf-1d-2d-segmentation-end2endpipelines_amd"
 PEAK_TFLOPS_F16 = 2500.0     # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters): the peak every fraction is quoted against
-MFMA_PER_PRODUCT = {"f16": 1, "f32": 3}      # parity mode: every product is three fp16 MFMAs on split operands
+MFMA_PER_PRODUCT = {"f16": 1, "f32": 3}      # parity mode: every product is three fp16 MFMAs on split operands (docs/experiments.md section 3)
 PEAK_HBM_GBS = 8000.0
 DTYPE_DETAIL = {"f32": "parity mode: tensors stored as split fp16 pairs (hi + lo / 2048, ~22 bits), fp32 accumulate; 3 fp16 MFMAs per product in the forward "
                        "pass, 2 or 3 in the backward GEMMs (key `backward`)",

@@ -4,7 +4,7 @@
 These are REGRESSION vectors produced by the oracle (oracle/keras_ref.py, oracle/models_ref.py, oracle/train_ref.py)
 - a CPU restatement of the reference's Keras-2.x semantics - on fixed seeded inputs.  They are NOT outputs of the
 reference: TensorFlow cannot be installed here and the reference ships no tests or golden vectors, so parity stays
-"unpinned" (DESIGN.md section 3).  What the file pins is the oracle itself: a later edit of the oracle (or of the
+"unpinned" (docs/experiments.md section 3).  What the file pins is the oracle itself: a later edit of the oracle (or of the
 product) that changes any of these numbers is caught by tests/test_golden.py, on the CPU (oracle vs file) and on the
 GPU (HIP path in exact-fp32 mode vs file).
 

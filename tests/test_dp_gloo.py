@@ -169,7 +169,7 @@ def test_bucket_holds_follow_the_queue_model():
 def test_c3_exchange_plan_at_eight_ranks():
     """Planner only (dry run, no process group): the bucket plan of the headline model - UNet++ d5 w64 +DS, 256 x 256, 16 images per
     rank, parity mode - at the world sizes of the scaling run, and the order in which a backward sweep hands the slices to RCCL
-    (DESIGN section 6).  At 8 ranks: the early-closing urgent slice (the encoder's first levels, ~25 MB) and the two bottleneck slices
+    (DESIGN.md section 7).  At 8 ranks: the early-closing urgent slice (the encoder's first levels, ~25 MB) and the two bottleneck slices
     behind it (227 + 151 MB) become final in the last few percent of the sweep - their ring all-reduce could not finish before it ends,
     so they are held back; the decoder's three slices go out as they complete (reverse order), then the held ones in FORWARD order, the
     urgent slice first: the next forward pass needs it first."""
@@ -194,7 +194,7 @@ def test_c3_exchange_plan_at_eight_ranks():
             assert abs(sum(mb) - 795.4) < 1.0                                  # 198.85 M parameters in fp32: what every rank sends per step
             assert holds[0] and not holds[-1] and holds == sorted(holds, reverse=True)     # held slices are a prefix (the sweep ends there)
             plans[w] = holds
-        assert plans[8] == [True, True, True, False, False, False]            # DESIGN section 6: "C3, 8 ranks: slices 0-2 held"
+        assert plans[8] == [True, True, True, False, False, False]            # DESIGN.md section 7: "C3, 8 ranks: slices 0-2 held"
         assert sum(plans[2]) <= sum(plans[4]) <= sum(plans[8])                  # 2 (w - 1) / w grows with the world: never fewer holds
         # the issue order of one sweep at 8 ranks, as backward() produces it
         bk = m.grad_buckets()

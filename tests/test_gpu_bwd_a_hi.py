@@ -1,4 +1,4 @@
-"""MI355X: the two-MFMA forms of the parity-mode BACKWARD GEMMs (SegModel.build(backward="2mfma"), DESIGN section 4).
+"""MI355X: the two-MFMA forms of the parity-mode BACKWARD GEMMs (SegModel.build(backward="2mfma"), DESIGN.md section 3).
 A data-gradient launch reads its A operand - the incoming gradient dz - as the fp16 hi half of the split pair
 (SEG_VARIANT_A_HI: a b ~= ah bh + ah bl / 2048), a weight-gradient launch its INPUT operand (SEG_VARIANT_IN_HI: ah bh + al bh / 2048).
 What defines them exactly: the result IS the three-MFMA launch on that operand rounded to fp16 (a pair whose lo half is zero) - bit for

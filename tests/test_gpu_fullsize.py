@@ -21,7 +21,7 @@ Asserted per config, with the oracle computed ONCE and shared by both modes:
             branch) to GRAD_L2 (1e-2; C4 5e-2), with the differing decisions counted and held below 1e-3 of all of them
   f16 mode  fp16 operands carry a 2^-12 relative rounding per stored activation and weight; through a random-initialised
             network the relative error grows ~1.2x per ReLU layer (measured and reproduced by the rounding-emulating oracle,
-            DESIGN.md section 3), so this mode is NOT the north-star mode.  Asserted: the RMS output error (F16_RMS), the
+            docs/experiments.md section 3), so this mode is NOT the north-star mode.  Asserted: the RMS output error (F16_RMS), the
             maximum (F16_TOL x max(1, |ref|)), masks identical on every pixel whose margin exceeds that maximum and on >= 99 %
             of all pixels, the 8x8 / 16x16 level (K up to 18 432) in line with the other nodes, gradient direction per tensor
   both      channel padding of every stored tensor exactly zero
@@ -404,7 +404,7 @@ def test_training_is_bit_reproducible_at_the_headline_config():
     """Two runs of three optimiser steps of C3 at its BASELINE batch leave bit-identical parameters: the pixel-split weight
     gradients go through per-layer partial tiles and an ordered reduce instead of float atomics (SEG_WGRAD_DETERMINISTIC).
     Checked on the single-stream schedule (`use_side_stream = False`, what SEG_WGRAD_STREAM=0 selects) and on the default
-    two-stream one.  History: until the end of round 2 1-10 % of the two-stream runs differed in one
+    two-stream one.  History (docs/experiments.md section 3): until the end of round 2 1-10 % of the two-stream runs differed in one
     32 x 32 tile of a deep-level data gradient - a write-after-read hazard on an LDS ring slot across s_barrier (fragment reads
     issued but not returned when the slot was refilled), visible only with the other stream's kernels backing up the LDS; every
     ring kernel now waits for its own LDS reads in front of the slot-releasing barrier (tools/repro_probe.py)."""

@@ -30,7 +30,7 @@ from oracle.train_ref import KerasOptimizer, KerasAdam, loss_and_grads
 OUT_TOL = 1e-2
 # MultiRes models stack BatchNormalization on BatchNormalization over 5..16-channel tensors; channels whose batch
 # mean is large against their standard deviation amplify the fp16 rounding of the stored pre-BN value by mean/sigma
-# (DESIGN.md section 3), so the f16-mode bound is looser there.  The parity mode (test_gpu_fp32.py) is unaffected.
+# (docs/experiments.md section 3), so the f16-mode bound is looser there.  The parity mode (test_gpu_fp32.py) is unaffected.
 OUT_TOL_CASE = {"multiresunet_ag_bce": 3e-2, "multiresunet_alpha167_ds_mse": 3e-2, "multiresunet1d_mse": 3e-2, "multiresunet_40x24_ag_bce": 3e-2}
 
 

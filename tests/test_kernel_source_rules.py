@@ -5,11 +5,11 @@ kernels hands an LDS slot back to whoever refills it; gfx950 puts no implicit wa
 compiler may leave the last MFMAs of a step (with the wait for their fragment reads) behind it.  Without an explicit
 `s_waitcnt lgkmcnt(0)` in front of the barrier a queued read can return the next step's bytes when the LDS is backed up by
 a co-resident kernel - one 32 x 32 tile a K step off in 1-10 % of the C3 training steps until the end of round 2
-(DESIGN.md section 3).  The wait and the barrier are ONE helper (igemm_common.h: ring_release_barrier); pure loader waves
+(docs/experiments.md section 3).  The wait and the barrier are ONE helper (igemm_common.h: ring_release_barrier); pure loader waves
 have their own (loader_barrier).
 
 Rule 2 - the library is built without compiler-formed packed fp32 arithmetic (`-fno-slp-vectorize`): the BN sum of squares
-of the conv epilogue went wrong through it."""
+of the conv epilogue went wrong through it (docs/experiments.md section 3)."""
 import glob
 import importlib
 import os

@@ -1,6 +1,6 @@
 """Reference-produced golden vectors (tests/golden/tf_*.npz, written on a TensorFlow box by tools/tf_capture_spec.py).
 
-While no fixture is present every test here SKIPS - and the oracle stays "parity unpinned" (DESIGN.md section 3): this
+While no fixture is present every test here SKIPS - and the oracle stays "parity unpinned" (docs/experiments.md section 3): this
 container has no TensorFlow.  With fixtures present:
   * CPU  the oracle (oracle/models_ref.py) must reproduce the Keras outputs (predict: inference-mode BN; train_fwd:
          training-mode BN) within 1e-4, the BatchNormalization moving statistics a training-mode call leaves (momentum 0.99,

@@ -126,7 +126,7 @@ __device__ __forceinline__ void lds_dma16(i4v rsrc, unsigned lds_addr, unsigned 
 // implicit wait in front of s_barrier and hipcc is free to leave the last MFMAs of a step - with the wait for their fragment reads -
 // behind it, so the wave's own LDS reads must have RETURNED (s_waitcnt lgkmcnt(0)), not just been issued: with the LDS backed up
 // by a co-resident kernel a queued read otherwise returns the next step's bytes (one 32 x 32 tile a K step off in 1-10 % of the
-// C3 training steps until the end of round 2).  The waits for the wave's LDS-DMA (counted vmcnt) stay with
+// C3 training steps until the end of round 2; docs/experiments.md section 3).  The waits for the wave's LDS-DMA (counted vmcnt) stay with
 // the caller, in front of this call.  with_barrier = false: timing experiments only (tools/op_bench.py --dbg).
 __device__ __forceinline__ void ring_release_barrier(bool with_barrier = true) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -432,7 +432,7 @@ int seg_launch_fwd3(const seg_igemm_fwd_args& a, hipStream_t st) {
   // transposed conv forward 4-6 % faster (its blocks run class-fastest, so the four classes of a patch share the halo tile
   // in L2) and its data gradient 0-3 %; the 3x3 layers 1-3 % SLOWER on the 128-channel tile and equal on the 64-channel
   // tile - reading fragments ahead does not pay there: the in-order issue stream (LDS-DMA, ds_read, address VALU) is what
-  // bounds the kernel, not the exposed ds_read latency (ablations in DESIGN.md section 4).
+  // bounds the kernel, not the exposed ds_read latency (ablations in docs/experiments.md section 4).
   const bool pipe = a.g.ntaps != 9;
   if (pipe || (a.variant >> 8) != 0) {
     seg_launch_fwd4(a, pw, grid, st);

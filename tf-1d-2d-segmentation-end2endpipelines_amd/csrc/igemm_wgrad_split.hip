@@ -26,7 +26,7 @@ __device__ __forceinline__ h8 trfrag(const unsigned char* ad, int rstride4) {
 
 // EXPERIMENT (SEG_VARIANT_IN_HI, never validated): the INPUT operand of the weight gradient read as its hi half - a b ~= ah bh + al bh / 2048
 // with a = dz whole, b = the activations' hi half.  The lo fragment of every tap's halo read goes (5 of the 12 fragment reads per K
-// block of the 3x3 kernel) and a third of the MFMAs; the activations lose 2^-11, elementwise.
+// block of the 3x3 kernel) and a third of the MFMAs; the activations lose 2^-11, elementwise (docs/experiments.md section 7, item 0).
 #define SEG_MMA_SPLIT_BHI(ACC, ACCL, AH, AL, BH)                                  \
   do {                                                                            \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);           \

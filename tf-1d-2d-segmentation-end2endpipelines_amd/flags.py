@@ -1,6 +1,6 @@
 """Switches and measured constants of the engine (model.py / ops.py / planning.py read them as `F.<NAME>` at call time, so a test or an
 A/B run can flip one: `monkeypatch.setattr(flags, "FUSE_BN_TAILS", False)`).  Environment variables are kept only where an
-alternative path is needed for bisecting or for same-box A/Bs; tuning numbers whose sweeps are recorded in DESIGN.md are plain
+alternative path is needed for bisecting or for same-box A/Bs; tuning numbers whose sweeps are recorded in docs/experiments.md are plain
 constants (round 4 removed SEG_BN_PARTS_BWD, SEG_WGRAD_OVERWRITE, SEG_BIAS_FROM_WGRAD, SEG_ADAM_SLICE_ELEMS, SEG_ADAM_URGENT_FIRST,
 SEG_DP_URGENT_ELEMS, SEG_FWD_HALO_MIN_BLOCKS(_F32), SEG_FWD_SPLITK_{MAX_BLOCKS,TARGET,MIN_K}, SEG_HEAD_DW_SIDE, SEG_WGRAD_BLOCKS,
 SEG_HALO_BLOCKS_TC and, in the library, SEG_FWD_PIPE, SEG_FWD4_TG2 / TG3, SEG_WGRAD_WS / TS / V1, SEG_IGEMM_V1, SEG_ADAM_BLOCKS,
@@ -55,7 +55,7 @@ HEAD_INJECT = os.environ.get("SEG_HEAD_INJECT", "1") != "0"            # ... and
 WGRAD_BLOCKS = 1536       # block target of the split-K of the per-tap weight-gradient kernels
 HALO_BLOCKS_TC = 256   # the same for the transposed-conv class-pair kernel
 HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks per round of the variant-2 kernel: ONE per CU - it shares the GPU with the main stream (measured: 512 = 2 per CU is faster alone, slower in the step)
-# parity mode, the BACKWARD GEMMs only (SegModel.build(backward=), DESIGN section 4): how many fp16 MFMAs a product costs there.  The forward
+# parity mode, the BACKWARD GEMMs only (SegModel.build(backward=), DESIGN.md section 3): how many fp16 MFMAs a product costs there.  The forward
 # pass - outputs, masks, `predict` - is the same bits in every mode.  "<d|b><D>w<W>": D = 3 | 2 MFMAs per product in the data gradients
 # (d2: the incoming gradient dz read as its fp16 hi half; b2: the transposed WEIGHTS read as theirs - O(1) numbers in fp16's normal
 # range, where dz spans everything below the loss scale), W = 3 | 2 | 1 in the weight gradients (2: the layer input as its hi half; 1: dz as

@@ -761,7 +761,7 @@ class SegModel:
         if n:
             self.input_overflow.zero_()
             raise ValueError(f"{n} input element(s) are NaN / Inf or outside |x| < 65504, the range of this engine's fp16 / split-pair storage "
-                             "(DESIGN.md section 2); normalise the input (the reference's loaders divide images by 255)")
+                             "(docs/experiments.md section 2); normalise the input (the reference's loaders divide images by 255)")
 
     def _refresh_copies(self):
         st = self.store

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What two MFMAs per product in the BACKWARD GEMMs would cost in gradient accuracy, emulated in the oracle
+"""What two MFMAs per product in the BACKWARD GEMMs would cost in gradient accuracy (docs/experiments.md section 7, item 0), emulated in the oracle
 on the CPU: the data gradient sees the incoming gradient rounded to fp16 in the loss-scaled domain (its hi half), the weight gradient
 the activations rounded to fp16 (or, second variant, the incoming gradient again); everything else fp32.  Prints the worst and the
 median parameter-gradient error (relative L2 with the fuzzer's floor of 1e-3 of the largest gradient norm) for three small models at
