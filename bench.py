@@ -329,6 +329,20 @@ def short_run(workload, dtype, steps, warmup, profile=True, batch=0, graph=False
     return res
 
 
+def short_run_child(workload, dtype, steps, warmup, **kw):
+    """short_run() in a fresh child process (started, never exec'ed; this process has released its device memory by then): a
+    configuration timed behind six other models of one process inherits that process's fragmented device address space - C4, which is
+    HBM-bound and 43 GB resident, measured 45.0 ms there against 40.5 ms in a process of its own (round 6) - and every entry of
+    `extra_workloads` is meant to be what `bench.py --workload X` gives."""
+    import subprocess
+    spec = dict(workload=workload, dtype=dtype, steps=steps, warmup=warmup, **kw)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--short-run", json.dumps(spec)], capture_output=True, text=True, timeout=1800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"child run of {workload} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-400:]}")
+    return json.loads(lines[-1])
+
+
 def cpu_baseline(workload, gpu_batch):
     """The oracle (torch-CPU fp32 restatement of the reference graph, kind 'port') timed on the host cores: forward + backward +
     Keras Adam.  SURVEY.md 8d asks for the GPU line's batch: it is used when the host has the memory for it (the oracle keeps
@@ -465,7 +479,14 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: run the data-parallel exchange path (RCCL all-reduce per gradient slice, Adam per slice) even with one rank")
     ap.add_argument("--dump-launches", default="", help="write the per-launch event timings of the profiled step to this JSON file")
+    ap.add_argument("--short-run", default="", help="(internal) JSON keyword arguments of short_run(): run it in THIS process and print its result as one JSON line")
     args = ap.parse_args()
+    if args.short_run:                 # a child of short_run_child(): one configuration in a process of its own
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(0)
+        print(json.dumps(short_run(**json.loads(args.short_run))), flush=True)
+        return
 
     # --gpus N is the job size.  N > 1 without torchrun's environment: this process becomes the launcher of N ranks (before any
     # torch.cuda call); with it, WORLD_SIZE must agree - a scaling run must never silently measure another job.
@@ -611,20 +632,20 @@ def main():
         # ---- the same workload, same steps and warm-up, in the other numeric mode
         other = "f16" if args.dtype == "f32" else "f32"
         try:
-            parity = short_run(args.workload, other, args.steps, args.warmup, profile=True)
+            parity = short_run_child(args.workload, other, args.steps, args.warmup, profile=True)
             parity["what"] = DTYPE_DETAIL[other]
         except Exception as e:
             parity = {"error": repr(e)}
         # ---- the north star's literal figure - fp16 MFMA fraction of the UNet (C2) 3x3 conv stack - in the throughput mode
         if other == "f16" and args.workload != "C2":
             try:
-                parity["extra_workloads"] = {"C2": short_run("C2", "f16", 20, 3, profile=True)}
+                parity["extra_workloads"] = {"C2": short_run_child("C2", "f16", 20, 3, profile=True)}
             except Exception as e:
                 parity["extra_workloads"] = {"C2": {"error": repr(e)}}
         # ---- the same workload with the STRICT backward pass (three MFMAs per product there too), when the headline run did not use it
         if args.dtype == "f32" and bwd_line.get("resolved") != "d3w3":
             try:
-                strict = short_run(args.workload, "f32", max(10, args.steps // 2), 5, profile=True, backward="3mfma")
+                strict = short_run_child(args.workload, "f32", max(10, args.steps // 2), 5, profile=True, backward="3mfma")
                 strict["what"] = "the same workload with backward='3mfma': every product of the backward GEMMs three MFMAs, like the forward pass"
             except Exception as e:
                 strict = {"error": repr(e)}
@@ -633,20 +654,20 @@ def main():
             if wl == args.workload:
                 continue
             try:
-                extras[wl] = short_run(wl, args.dtype, 10 if wl.startswith("C4") else 20, 3, profile=True)
+                extras[wl] = short_run_child(wl, args.dtype, 10 if wl.startswith("C4") else 20, 3, profile=True)
             except Exception as e:
                 extras[wl] = {"error": repr(e)}
         # ---- the same workload at four times the batch (not the metric's configuration: what the 288 GB of HBM allow; since round 4
         # the LDS-DMA kernels address operands up to 1.875 GiB, i.e. this model up to batch 119)
         if args.workload == "C3" and not args.batch:
             try:
-                extras["C3_batch64"] = short_run("C3", args.dtype, 5, 2, profile=False, batch=64)
+                extras["C3_batch64"] = short_run_child("C3", args.dtype, 5, 2, profile=False, batch=64)
             except Exception as e:
                 extras["C3_batch64"] = {"error": repr(e)}
         # ---- the reference's CPU-runnable 1D case (about 150 dependent launches of 5 - 10 us each: 1.53 ms per step launch by launch,
         # 1.54 ms replayed as one captured hipGraph - it is bound by the kernels' own latency, not by their launches)
         try:
-            extras["C1"] = short_run("C1", args.dtype, 200, 20, profile=False)
+            extras["C1"] = short_run_child("C1", args.dtype, 200, 20, profile=False)
         except Exception as e:
             extras["C1"] = {"error": repr(e)}
     else:

@@ -45,12 +45,13 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BY
 // 2 fh, its lo fragment chunk 2 fh + 1.  Products of fp16 values are exact in the fp32 accumulator:
 // a b ~= ah bh + (al bh + ah bl) / 2048 (al bl, 2^-22 relative, is dropped): three MFMAs per product, the two sums in separate
 // accumulators that are combined once at the end (split_combine).
-template <int TM, int TN>
+// BHI (data gradients, SEG_VARIANT_B_HI): the B operand - the transposed weights - as its hi half: the `bl` reads and the `ah bl` MFMA go.
+template <int TM, int TN, bool BHI = false>
 __device__ __forceinline__ void mma_step_split(const unsigned char* A, const unsigned char* B, int a_row0, int b_row0, int fr, int fh,
                                                f16v (&acc)[TM][TN], f16v (&accl)[TM][TN]) {
   const int fswz = (fr >> 2) & 3;
   const int ch = ((2 * fh) ^ fswz) << 4, cl = ((2 * fh + 1) ^ fswz) << 4;
-  h8 ah[TM], al[TM], bh[TN], bl[TN];
+  h8 ah[TM], al[TM], bh[TN], bl[BHI ? 1 : TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const unsigned char* r = A + (a_row0 + a * 32 + fr) * ROW_BYTES;
@@ -61,7 +62,7 @@ __device__ __forceinline__ void mma_step_split(const unsigned char* A, const uns
   for (int b = 0; b < TN; ++b) {
     const unsigned char* r = B + (b_row0 + b * 32 + fr) * ROW_BYTES;
     bh[b] = *reinterpret_cast<const h8*>(r + ch);
-    bl[b] = *reinterpret_cast<const h8*>(r + cl);
+    if constexpr (!BHI) bl[b] = *reinterpret_cast<const h8*>(r + cl);
   }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -69,7 +70,7 @@ __device__ __forceinline__ void mma_step_split(const unsigned char* A, const uns
     for (int b = 0; b < TN; ++b) {
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
       accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], accl[a][b], 0, 0, 0);
-      accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
+      if constexpr (!BHI) accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], accl[a][b], 0, 0, 0);
     }
 }
 template <int TM, int TN>

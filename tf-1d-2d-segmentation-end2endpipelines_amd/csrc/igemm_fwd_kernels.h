@@ -178,7 +178,9 @@ struct ChunkDesc {      // one (segment, 32-channel chunk) of the K loop
   unsigned vbase[AL];   // per-lane byte offset of (centre pixel, this lane's 16-B chunk), OOB_OFF when masked
 };
 
-template <int BM, int BN, int NT, int BKE, int NSTAGE, bool SPLIT = false>
+// BHI (parity mode, data gradients: SEG_VARIANT_B_HI): the weight operand as its hi half - two MFMAs per product, and the lo chunks of
+// the weight rows are not fetched (their lanes load out of range: zeros, no memory traffic).
+template <int BM, int BN, int NT, int BKE, int NSTAGE, bool SPLIT = false, bool BHI = false>
 __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 64)) ? 3 : 2)) void igemm_fwd2_kernel(const seg_igemm_fwd_args p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type only exists for the gfx950 pass; the host pass needs just the stub
   constexpr int WMv = BM / 64, WNv = 4 / WMv;     // waves along M / N; every wave owns 64 rows x (BN / WNv) columns
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
   static_assert(WMv * WNv == 4 && TNw >= 1 && TNw * 32 * WNv == BN, "tile / wave layout");
   static_assert(BKE == 32 || BKE == 64, "K step of 32 or 64 channels");
   static_assert(!SPLIT || BKE == 32, "parity mode: one 64-B row = 16 real K values as hi / lo chunks");
+  static_assert(SPLIT || !BHI, "the hi-only weight operand is a parity-mode form");
   typedef std::conditional_t<SPLIT, split_t, half_t> TO;
   constexpr int ROWB = BKE * 2;                  // bytes per LDS row (one K step of one pixel / one output channel)
   constexpr int CPR = ROWB / 16;                 // 16-B chunks per row
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
     const int row = (wave * BL + i) * RPI + lrow;
     const int nrow = n0 + row;
     const int chs = lch ^ swz(row);
-    b_voff[i] = nrow < p.n_rows ? (unsigned)((nrow * g.T_total * p.Kpad + chs * 8) * 2) : OOB_OFF;
+    b_voff[i] = (nrow < p.n_rows && !(BHI && (chs & 1))) ? (unsigned)((nrow * g.T_total * p.Kpad + chs * 8) * 2) : OOB_OFF;
   }
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.n_rows * g.T_total * p.Kpad * 2, 0x00020000);
 
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, ((!SPLIT && BM == 128 && (BKE == 32 || BN == 6
       if (st2 >= NSTAGE) st2 -= NSTAGE;
       issue(std::integral_constant<int, t2>{}, D[k2], st2);
       const unsigned char* A = smem + stage * STAGE;
-      if constexpr (SPLIT) mma_step_split<2, TNw>(A, A + A_BYTES, wm * 64, wn * (32 * TNw), fr, fh, acc, accl);
+      if constexpr (SPLIT) mma_step_split<2, TNw, BHI>(A, A + A_BYTES, wm * 64, wn * (32 * TNw), fr, fh, acc, accl);
       else if constexpr (BKE == 32) mma_step<2, TNw>(A, A + A_BYTES, wm * 64, wn * (32 * TNw), fr, fh, acc);
       else mma_step64<2, TNw>(A, A + A_BYTES, wm * 64, wn * (32 * TNw), fr, fh, acc);
       stage = stage == NSTAGE - 1 ? 0 : stage + 1;

@@ -16,6 +16,18 @@ static void launch_fwd2_split_nt(const seg_igemm_fwd_args& v, dim3 grid, size_t 
   }
 }
 
+// data gradients with the weight operand as its hi half (SEG_VARIANT_B_HI): the tap counts data gradients come with - 3x3 (9), the
+// parity planes of a transposed conv (16), 1x1 (1)
+template <int BM, int BN>
+static bool launch_fwd2_split_bhi(const seg_igemm_fwd_args& v, dim3 grid, size_t lds, hipStream_t st) {
+  switch (v.g.ntaps) {
+    case 1: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 1, 32, 3, true, true>), grid, dim3(256), lds, st, v); return true;
+    case 9: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 9, 32, 3, true, true>), grid, dim3(256), lds, st, v); return true;
+    case 16: hipLaunchKernelGGL((igemm_fwd2_kernel<BM, BN, 16, 32, 3, true, true>), grid, dim3(256), lds, st, v); return true;
+    default: return false;
+  }
+}
+
 extern "C" int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t stream) {
   if (const int rc = check_fwd_args(a)) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -28,7 +40,14 @@ extern "C" int seg_igemm_fwd_f32(const seg_igemm_fwd_args* a, seg_stream_t strea
   if (fwd2_eligible(*a, 4)) {
     const size_t lds = (size_t)3 * (a->tile_m + a->tile_n) * 64;          // >= the epilogue's staging (20.5 KB)
     if (a->splitk > 1) grid.z = (unsigned)a->splitk;
-    if (a->tile_m == 128 && a->tile_n == 128) launch_fwd2_split_nt<128, 128>(v, grid, lds, st);
+    bool done = false;
+    if (a->variant & SEG_VARIANT_B_HI) {         // (tap counts without a hi-only instance take the three-MFMA kernel: more exact, never wrong)
+      if (a->tile_m == 128 && a->tile_n == 128) done = launch_fwd2_split_bhi<128, 128>(v, grid, lds, st);
+      else if (a->tile_m == 128) done = launch_fwd2_split_bhi<128, 64>(v, grid, lds, st);
+      else done = launch_fwd2_split_bhi<256, 64>(v, grid, lds, st);
+    }
+    if (done) { /* launched */ }
+    else if (a->tile_m == 128 && a->tile_n == 128) launch_fwd2_split_nt<128, 128>(v, grid, lds, st);
     else if (a->tile_m == 128) launch_fwd2_split_nt<128, 64>(v, grid, lds, st);
     else launch_fwd2_split_nt<256, 64>(v, grid, lds, st);
     SEG_CHECK_LAUNCH("seg_igemm_fwd_f32 (LDS-DMA)");

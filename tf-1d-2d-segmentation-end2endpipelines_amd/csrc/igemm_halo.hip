@@ -1,6 +1,9 @@
 // Halo-tile forward / data-gradient kernel (variant 3 of seg_igemm_fwd) for gfx950: 3x3 / stride-1 convolutions, the four
 // sub-pixel classes of the 4x4 / stride-2 transposed convolution and its data gradient.  See igemm_fwd.hip for the entry point.
 #include "igemm_common.h"
+#ifndef SEG_BHI_FETCH_LO
+#define SEG_BHI_FETCH_LO 0
+#endif
 
 namespace {
 
@@ -109,7 +112,10 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
       const int tt = r / BROWS, row = r - tt * BROWS;
       b_tap[j] = __builtin_amdgcn_readfirstlane(tt);
       const int gch = lch ^ ((row >> 2) & 3);
-      b_voff[j] = (row < BN && n0 + row < p.n_rows) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
+      // (BHI: the lo chunks of the weight rows - odd chunk indices of the [hi | lo | hi | lo] row - are never read: their lanes fetch out
+      // of range, zeros arrive without memory traffic; SEG_BHI_FETCH_LO=1 at build time keeps the fetch for A/B timing)
+      const bool skip_lo = BHI && (gch & 1) && !SEG_BHI_FETCH_LO;
+      b_voff[j] = (row < BN && n0 + row < p.n_rows && !skip_lo) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
     }
   }
   auto uniform_ptr = [](const void* q) -> void* {

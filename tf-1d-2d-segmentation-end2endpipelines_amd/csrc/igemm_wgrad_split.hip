@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_kernel(const se
       const int yy = row / HC, xx = row - yy * HC;
       in_dy[k] = yy - 1;
       in_dx[k] = xx - 1;
-      in_cb[k] = (i < NI_IN && row < HROWS && c0 + (gch >> 1) * 8 < sc) ? c0 * 4 + gch * 16 : -1;
+      // (BHI: the lo chunks of the input rows - odd chunk indices - are never read: no fetch)
+      in_cb[k] = (i < NI_IN && row < HROWS && c0 + (gch >> 1) * 8 < sc && !(BHI != 0 && (gch & 1))) ? c0 * 4 + gch * 16 : -1;
     }
   }
   int pn_ = __builtin_amdgcn_readfirstlane(q0 / (PH * PW));
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_halo_split_tc2_kernel(cons
       const int yy = row / HC, xx = row - yy * HC;
       in_dy[k] = yy - 1 + py;
       in_dx[k] = xx - 1;
-      in_cb[k] = (i < NI_IN && row < HROWS && c0 + (gch >> 1) * 8 < sc) ? c0 * 4 + gch * 16 : -1;
+      // (BHI: the lo chunks of the input rows - odd chunk indices - are never read: no fetch)
+      in_cb[k] = (i < NI_IN && row < HROWS && c0 + (gch >> 1) * 8 < sc && !(BHI != 0 && (gch & 1))) ? c0 * 4 + gch * 16 : -1;
     }
   }
   int pn_ = __builtin_amdgcn_readfirstlane(q0 / (PH * PW));

@@ -67,3 +67,4 @@ HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks pe
 # d3w2 3.8e-4 / 3.1e-4 / 3.8e-4 and 2.8e-4 on C4; d3w3 7e-6 / 3e-6 / 7e-6 and 9e-5.
 BACKWARD = os.environ.get("SEG_BACKWARD", "auto")
 BACKWARD_AUTO_CHAIN = 32
+BWD_B2_PER_TAP = os.environ.get("SEG_BWD_B2_PER_TAP", "1") != "0"       # b2 modes: also the data gradients on the per-tap LDS-DMA kernel (deep levels, 1x1 convs)

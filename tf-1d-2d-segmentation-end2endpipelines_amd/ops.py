@@ -573,7 +573,8 @@ class ConvOp(Op):
             Md = self.N * self.g_dgrad.Hl * self.g_dgrad.Wl
             a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, width, self.g_dgrad, self.g_dgrad.ntaps * self.rows_pad, self.m.dtype == "f16",
                                                                [a.seg_cs[j] for j in range(a.nseg)], width * self.g_dgrad.T_total * self.rows_pad)
-            if self.m.bwd_d == 2 and (a.variant & 255) == 3 and self.g_dgrad.ntaps != 4:
+            if self.m.bwd_d == 2 and (((a.variant & 255) == 3 and self.g_dgrad.ntaps != 4) or
+                                      ((a.variant & 255) == 0 and self.m.bwd_d_flag == _ffi.SEG_VARIANT_B_HI and F.BWD_B2_PER_TAP)):
                 a.variant |= self.m.bwd_d_flag              # (one operand as its hi half: two MFMAs per product in the data gradients)
             self.m.fwd_ws_users.append(a)
             self.dg_args.append((a, zero_first, fl))
@@ -693,7 +694,8 @@ class GatherDgrad:
         Md = op0.N * op0.g_dgrad.Hl * op0.g_dgrad.Wl
         a.tile_m, a.tile_n, a.variant, a.splitk = plan_fwd(Md, self.t.cs, op0.g_dgrad, op0.g_dgrad.ntaps * self.Kg, self.m.dtype == "f16",
                                                            [a.seg_cs[j] for j in range(a.nseg)], self.t.cs * op0.g_dgrad.T_total * self.Kg)
-        if self.m.bwd_d == 2 and (a.variant & 255) == 3 and op0.g_dgrad.ntaps != 4:
+        if self.m.bwd_d == 2 and (((a.variant & 255) == 3 and op0.g_dgrad.ntaps != 4) or
+                                  ((a.variant & 255) == 0 and self.m.bwd_d_flag == _ffi.SEG_VARIANT_B_HI and F.BWD_B2_PER_TAP)):
             a.variant |= self.m.bwd_d_flag
         self.m.fwd_ws_users.append(a)
         self.args = a
