@@ -71,8 +71,8 @@ def test_spawn_relays_output_and_keeps_the_json_line_last(tmp_path):
 
 
 def test_bench_gpus_4_starts_four_ranks_that_refuse_to_run_without_a_gpu():
-    """The real bench.py as the launcher of a 4-rank job (gloo, as the one-GPU box shares its device): here, without a GPU, every one
-    of the four ranks must stop with the "no CPU fallback" message and the launcher must hand the failure on - the product path never
+    """The real bench.py as the launcher of a 4-rank job (gloo, as the one-GPU box shares its device): here, without a GPU, every
+    rank that gets to run must stop with the "no CPU fallback" message and the launcher must hand the failure on - the product path never
     degrades to a CPU run.  (The same command on the GPU box runs four ranks on the shared device: tests/test_gpu_dp.py.)"""
     import torch
     if torch.cuda.is_available():
@@ -84,5 +84,7 @@ def test_bench_gpus_4_starts_four_ranks_that_refuse_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "tiny", "--steps", "1", "--warmup", "0",
                         "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
-    assert (r.stderr + r.stdout).count("bench.py needs an MI355X (no CPU fallback)") == 4
+    # (torchrun tears the other workers down as soon as the first one has failed: between one and four of them get to say it)
+    assert 1 <= (r.stderr + r.stdout).count("bench.py needs an MI355X (no CPU fallback)") <= 4
+    assert "--nproc-per-node=4" in " ".join(_bench().launch_plan(4, {}, ["--gpus", "4"])[1])
     assert '"metric"' not in r.stdout

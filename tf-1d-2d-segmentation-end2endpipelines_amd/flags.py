@@ -67,4 +67,7 @@ HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks pe
 # d3w2 3.8e-4 / 3.1e-4 / 3.8e-4 and 2.8e-4 on C4; d3w3 7e-6 / 3e-6 / 7e-6 and 9e-5.
 BACKWARD = os.environ.get("SEG_BACKWARD", "auto")
 BACKWARD_AUTO_CHAIN = 32
-BWD_B2_PER_TAP = os.environ.get("SEG_BWD_B2_PER_TAP", "1") != "0"       # b2 modes: also the data gradients on the per-tap LDS-DMA kernel (deep levels, 1x1 convs)
+# b2 modes: also the data gradients on the per-tap LDS-DMA kernel (deep levels, 1x1 convs)?  Measured (round 6, same box): C3 41.64 -> 41.50 ms,
+# worst parameter gradient C2 6.3e-4 -> 7.9e-4, C5 6.8e-4 -> 8.4e-4 (the 8x8 / 16x16 levels are where the chain is longest) - 0.3 % of the
+# step for a quarter of the margin to 1e-3: off.
+BWD_B2_PER_TAP = os.environ.get("SEG_BWD_B2_PER_TAP", "0") != "0"
