@@ -61,10 +61,16 @@ HALO_BLOCKS = int(os.environ.get("SEG_HALO_BLOCKS", "256"))          # blocks pe
 # range, where dz spans everything below the loss scale), W = 3 | 2 | 1 in the weight gradients (2: the layer input as its hi half; 1: dz as
 # well).  "3mfma" = d3w3: every product a b ~= ah bh + (al bh + ah bl) / 2048 as in the forward pass; "2mfma" = b2w2.
 # "auto" (the default): b2w2 when the model's longest chain of convolutions (Graph.longest_conv_chain) is at most BACKWARD_AUTO_CHAIN
-# layers, else d3w2.  A weight gradient's rounding lands once, in dW; a data gradient's is inherited by every layer below it and grows
-# with the chain.  Measured at the BASELINE geometries, per parameter tensor, relative L2 against the oracle with the decisions imposed
-# (tests/test_gpu_fullsize.py, tolerance 1e-3): b2w2 6.3e-4 / 4.8e-4 / 6.8e-4 on C2 / C3 / C5 (chains of 19 - 20), 1.5e-3 on C4 (52);
-# d3w2 3.8e-4 / 3.1e-4 / 3.8e-4 and 2.8e-4 on C4; d3w3 7e-6 / 3e-6 / 7e-6 and 9e-5.
+# layers AND the graph is a plain Conv_Block stack (Graph.plain_conv_bn_stack: no attention gate, every BatchNormalization directly
+# behind a convolution), else d3w2.  A weight gradient's rounding lands once, in dW, and leaves dz - hence every bias / gamma / beta
+# gradient - exact; a data gradient's is inherited by every layer below it, grows with the chain, and is amplified where a
+# normalisation follows a normalisation or a gate multiplies.  Measured, relative L2 per parameter tensor against the oracle with the
+# decisions imposed (tolerance 1e-3): at the BASELINE geometries (tests/test_gpu_fullsize.py) b2w2 6.3e-4 / 4.8e-4 / 6.8e-4 on C2 / C3 /
+# C5 (chains of 19 - 20, plain stacks), 1.5e-3 on C4 (52, MultiRes tails + gates); d3w2 3.8e-4 / 3.1e-4 / 3.8e-4 and 2.8e-4 on C4;
+# d3w3 7e-6 / 3e-6 / 7e-6 and 9e-5.  Over random builder calls at 64 - 256 pixels (tools/fuzz_models.py --big, seed 62): with b2w2 for
+# every chain <= 32, 10 of 133 configurations exceed 1e-3 - eight with attention gates (the gate's one-channel transposed-conv bias,
+# a scalar sum of cancelling terms: 1.0e-3 .. 3.1e-3), two MultiResUNets (BatchNormalization gammas 3.7e-3, 2.9e-2); the rule above
+# sends exactly those to d3w2 (profiles/r06_fuzz_campaigns.txt).
 BACKWARD = os.environ.get("SEG_BACKWARD", "auto")
 BACKWARD_AUTO_CHAIN = 32
 # b2 modes: also the data gradients on the per-tap LDS-DMA kernel (deep levels, 1x1 convs)?  Measured (round 6, same box): C3 41.64 -> 41.50 ms,

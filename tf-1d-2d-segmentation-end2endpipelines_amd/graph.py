@@ -265,6 +265,20 @@ class Graph:
             depth[i] = max((depth[j] for j in n.inputs), default=0) + (1 if n.kind in ("conv", "convT", "convlstm", "dense_ae") else 0)
         return max((depth[o] for o in self.outputs), default=0)
 
+    def plain_conv_bn_stack(self) -> bool:
+        """True when the graph is a plain Conv_Block stack: no multiplicative gate (`mul`: attention gates) and every BatchNormalization
+        directly behind a convolution - not behind an add, a concatenation, an activation or another normalisation, as in the tails
+        of MultiResBlock / ResPath (unet_variants.py:85-122).  SegModel.build(backward="auto") halves an operand of the data gradients
+        only for such graphs: the rounding of a data gradient is inherited by everything below it, and normalisation-on-normalisation
+        and gating amplify it (measured, flags.py)."""
+        for i in self.live_nodes():
+            n = self.nodes[i]
+            if n.kind == "mul":
+                return False
+            if n.kind == "bn" and self.nodes[n.inputs[0]].kind not in ("conv", "convT"):
+                return False
+        return True
+
     def conv_io_elements(self) -> Tuple[int, int]:
         """(activation elements read + written by the conv / convT / ConvLSTM layers per sample, weight elements):
         the algorithmic HBM traffic of a fully fused forward pass (the HBM-bound configurations)."""

@@ -272,7 +272,7 @@ class SegModel:
         backward = backward or self.backward_mode or F.BACKWARD
         spec = {"3mfma": "d3w3", "2mfma": "b2w2"}.get(backward, backward)
         if spec == "auto":
-            spec = "b2w2" if self.graph.longest_conv_chain() <= F.BACKWARD_AUTO_CHAIN else "d3w2"
+            spec = "b2w2" if (self.graph.longest_conv_chain() <= F.BACKWARD_AUTO_CHAIN and self.graph.plain_conv_bn_stack()) else "d3w2"
         if spec not in ("d3w3", "d3w2", "d3w1", "d2w3", "d2w2", "d2w1", "b2w3", "b2w2", "b2w1"):
             raise ValueError("backward must be 'auto', '3mfma', '2mfma' or '<d|b><3|2>w<3|2|1>'")
         self.backward_mode, self.backward_spec = backward, spec
