@@ -280,3 +280,47 @@ def test_under_filled_grids_split_the_reduction():
     split = [a for a in m.fwd_ws_users if a.splitk > 1]
     assert split and all(a.variant == 0 and a.tile_m == 128 for a in split)
     assert max(M.fwd_workspace_bytes(a) for a in split) > 0
+
+
+def test_the_backward_mode_auto_resolves_by_chain_length_and_structure():
+    """SegModel.build(backward="auto") (flags.py): two MFMAs per product in the data gradients (b2) only for a plain Conv_Block stack of
+    at most 32 convolutions in a chain; attention gates, MultiResBlock / ResPath tails (a normalisation behind an add / a concatenation)
+    and deep chains keep their data gradients at three MFMAs (d3w2).  The launches carry the matching variant bits."""
+    ffi = importlib.import_module("tf-1d-2d-segmentation-end2endpipelines_amd._ffi")
+    cases = [
+        (B("UNetPP", 64, 64, 16, 3, num_channels=3, ds=1), True, "b2w2"),
+        (B("UNet", 64, 64, 16, 3, num_channels=1, lstm=1), True, "b2w2"),
+        (B("UNet3P", 64, 64, 16, 3, num_channels=1), True, "b2w2"),
+        (B("UNet", 64, 64, 16, 3, num_channels=1, ag=1), False, "d3w2"),               # multiplicative gate
+        (B("MultiResUNet", 64, 64, 16, 3, num_channels=1), False, "d3w2"),           # BN(ReLU(a + b)), BN(cat)
+    ]
+    for m, plain, want in cases:
+        assert m.graph.plain_conv_bn_stack() == plain and m.graph.longest_conv_chain() <= 32
+        m.build(2, dtype="f32", backward="auto")
+        assert m.backward_mode == "auto" and m.backward_spec == want
+        convs = [op for op in m.ops if isinstance(op, M.ConvOp)]
+        halo_w = [op for op in convs if (op.wg_args.variant & 255) == 2 and op.n_rows > 32]
+        assert all(op.wg_args.variant & ffi.SEG_VARIANT_IN_HI and not op.wg_args.variant & ffi.SEG_VARIANT_DZ_HI for op in halo_w)
+        dg = [a for op in convs for a, _z, _f in op.dg_args] + [g.args for g in m.gathers]
+        assert all(not (a.variant & ffi.SEG_VARIANT_A_HI) for a in dg)                # dz is never the halved operand of the default
+        if want == "d3w2":
+            assert all(not (a.variant & ffi.SEG_VARIANT_B_HI) for a in dg)
+    # a chain longer than the limit (a UNet of depth 8 has 28 convolutions in a row: lower the limit below that for the check)
+    deep = B("UNet", 256, 256, 4, 8, num_channels=1)
+    assert deep.graph.plain_conv_bn_stack() and deep.graph.longest_conv_chain() == 28
+    keep = M.F.BACKWARD_AUTO_CHAIN
+    try:
+        M.F.BACKWARD_AUTO_CHAIN = 27
+        deep.build(1, dtype="f32", backward="auto")
+        assert deep.backward_spec == "d3w2"
+    finally:
+        M.F.BACKWARD_AUTO_CHAIN = keep
+    # explicit modes and the throughput mode
+    m = B("UNetPP", 64, 64, 16, 3, num_channels=3, ds=1)
+    m.build(2, dtype="f32", backward="3mfma")
+    assert m.backward_spec == "d3w3" and (m.bwd_d, m.bwd_w) == (3, 3)
+    m = B("UNetPP", 64, 64, 16, 3, num_channels=3, ds=1)
+    m.build(2, dtype="f16", backward="auto")
+    assert (m.bwd_d, m.bwd_w) == (3, 3)                                                # nothing to halve: one MFMA per product anyway
+    with pytest.raises(ValueError):
+        B("UNetPP", 64, 64, 16, 3, num_channels=3, ds=1).build(2, dtype="f32", backward="fast")
