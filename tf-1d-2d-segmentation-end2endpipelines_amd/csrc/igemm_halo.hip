@@ -1,9 +1,6 @@
 // Halo-tile forward / data-gradient kernel (variant 3 of seg_igemm_fwd) for gfx950: 3x3 / stride-1 convolutions, the four
 // sub-pixel classes of the 4x4 / stride-2 transposed convolution and its data gradient.  See igemm_fwd.hip for the entry point.
 #include "igemm_common.h"
-#ifndef SEG_BHI_FETCH_LO
-#define SEG_BHI_FETCH_LO 0
-#endif
 
 namespace {
 
@@ -40,11 +37,18 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   constexpr int NA_HI = (NI_A + 3) / 4, NA_REM = NI_A % 4;  // per wave: NA_HI for waves < NA_REM (all when NA_REM == 0), else NA_HI - 1
   constexpr int A_BYTES = NI_A * 1024;
   constexpr int BROWS = BN < 64 ? 64 : BN;                 // rows of a weight stage
-  constexpr int B_BYTES = TG * BROWS * 64, NB_W = B_BYTES / 4096;  // weight stage, wave instructions per wave and stage
+  // BHI: the stage holds the hi chunks only - rows of 32 B (chunk 0 = channels 0-7, chunk 1 = channels 8-15 of the K chunk), an LDS-DMA
+  // instruction fills 32 rows instead of 16: half the weight instructions of the stream that bounds these kernels (the masked-lane
+  // form - same instructions, lo lanes out of range - measured neutral: the stream is bound by instructions, not bytes).  A stage whose
+  // instructions do not divide by the four waves is padded with fully masked ones (3x3: 6 real of 8, against 12).
+  constexpr int BROWB = BHI ? 32 : 64;                     // bytes per weight row in LDS
+  constexpr int B_REAL = TG * BROWS * BROWB;               // bytes of a stage that are read
+  constexpr int NB_W = (B_REAL + 4095) / 4096;             // LDS-DMA wave instructions per wave and stage
+  constexpr int B_BYTES = NB_W * 4096;                     // ... and the LDS a stage occupies
   constexpr int NSTEP = NT / TG;
   constexpr int WMv = BN <= 64 ? 4 : 2, WNv = 4 / WMv, TMw = 8 / WMv;   // A tiles (32 px) per wave
   constexpr int TNw = BN == 32 ? 1 : 2;                    // B tiles (32 channels) per wave
-  static_assert(TG * NSTEP == NT && NSTEP >= 2 && NB_W * 4096 == B_BYTES, "tap groups / weight stage");
+  static_assert(TG * NSTEP == NT && NSTEP >= 2 && (BHI || B_REAL == B_BYTES), "tap groups / weight stage");
   static_assert(NPL == 1 || (NPL == 4 && NT == 4), "parity planes: the data gradient of the 4x4 / stride-2 transposed conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -105,17 +109,17 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   unsigned b_voff[NB_W];
   int b_tap[NB_W];
   {
-    const int lrow = lane >> 2, lch = lane & 3;
+    const int lrow = BHI ? lane >> 1 : lane >> 2, lch = BHI ? lane & 1 : lane & 3;
+    constexpr int RPI = BHI ? 32 : 16;                     // rows per instruction
 #pragma unroll
     for (int j = 0; j < NB_W; ++j) {
-      const int r = (j * 4 + wave) * 16 + lrow;            // row inside the stage: tap-in-group * BN + channel row
+      const int r = (j * 4 + wave) * RPI + lrow;           // row inside the stage: tap-in-group * BN + channel row
       const int tt = r / BROWS, row = r - tt * BROWS;
-      b_tap[j] = __builtin_amdgcn_readfirstlane(tt);
-      const int gch = lch ^ ((row >> 2) & 3);
-      // (BHI: the lo chunks of the weight rows - odd chunk indices of the [hi | lo | hi | lo] row - are never read: their lanes fetch out
-      // of range, zeros arrive without memory traffic; SEG_BHI_FETCH_LO=1 at build time keeps the fetch for A/B timing)
-      const bool skip_lo = BHI && (gch & 1) && !SEG_BHI_FETCH_LO;
-      b_voff[j] = (row < BN && n0 + row < p.n_rows && !skip_lo) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
+      b_tap[j] = __builtin_amdgcn_readfirstlane(tt < TG ? tt : 0);
+      // the 16-B chunk this lane fetches: [hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15] of the row's K chunk; BHI: the hi chunks, unswizzled
+      // (64 lanes then read a contiguous KiB of fragments: conflict-free as it lies)
+      const int gch = BHI ? 2 * lch : lch ^ ((row >> 2) & 3);
+      b_voff[j] = (tt < TG && row < BN && n0 + row < p.n_rows) ? (unsigned)(((n0 + row) * g.T_total * p.Kpad + gch * 8) * 2) : OOB_OFF;
     }
   }
   auto uniform_ptr = [](const void* q) -> void* {
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
 #pragma unroll
   for (int b = 0; b < TNw; ++b)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) boff[b][ks] = lds_off(wn * 64 + b * 32 + fr, SPLIT ? 2 * fh + ks : ks * 2 + fh);      // (split: ks = 0 hi, 1 lo)
+    for (int ks = 0; ks < 2; ++ks)
+      boff[b][ks] = BHI ? (wn * 64 + b * 32 + fr) * 32 + fh * 16 : lds_off(wn * 64 + b * 32 + fr, SPLIT ? 2 * fh + ks : ks * 2 + fh);      // (split: ks = 0 hi, 1 lo)
 
   auto compute = [&](auto tgc, int abuf, int slot) {
     constexpr int tg = decltype(tgc)::value;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
         }
 #pragma unroll
         for (int b = 0; b < TNw; ++b) {
-          bh[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][0]);
+          bh[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * BROWB) + boff[b][0]);
           if constexpr (!BHI) bl[b] = *reinterpret_cast<const h8*>(B + tt * (BROWS * 64) + boff[b][1]);
         }
 #pragma unroll
