@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 # in the backward GEMMs where the model's depth allows it; flags.BACKWARD), is tested against ITS specification - forward pass
 # bit-identical to the strict mode's, every parameter gradient within 1e-3 - by the tests that ask for it by name:
 # test_gpu_fullsize.py (all five BASELINE configurations, the loss-decrease and bit-reproducibility tests), test_gpu_fuzz.py (a fixed
-# fuzz sample), test_gpu_bwd_a_hi.py (the launches themselves), test_gpu_dp.py.
+# fuzz sample), test_gpu_bwd_a_hi.py (the launches themselves), test_lowering.py (how "auto" resolves, on the CPU).
 os.environ.setdefault("SEG_BACKWARD", "3mfma")
 
 
