@@ -298,6 +298,25 @@ def test_c3_forward_and_backward_at_the_benched_batch_match_the_oracle():
     assert max(imposed.values()) < ARITH_L2_DEFAULT, max(imposed, key=imposed.get)
     assert nflip <= 1e-3 * ndec
     assert max(own.values()) < GRAD_L2.get("C3", 1e-2), max(own, key=own.get)
+    # ... and as bench.py runs it: backward="auto" (b2w2 for this model) on the same weights - the forward pass the same bits (the strict
+    # leg's imposed-decision oracle pass serves again), every parameter gradient within 1e-3 at the benched batch too
+    strict_outs = [got for got, _ref in r["out_tensors"]]
+    imposed_oracle, w = r["imposed_oracle"], model.get_weights()
+    del model, r
+    torch.cuda.empty_cache()
+    torch.manual_seed(21)
+    model2, _x, _t, _l = CONFIGS["C3"](16)
+    model2.build(16, dtype="f32", backward="auto")
+    assert model2.backward_spec == "b2w2"
+    model2.set_weights(w)
+    r = U.compare_model(model2, x, targets, loss, oracle=imposed_oracle[0], impose_decisions=True, imposed_oracle=imposed_oracle)
+    assert all(torch.equal(got, want) for (got, _ref), want in zip(r["out_tensors"], strict_outs))
+    gn = max(nrm for _e, nrm in r["gl2_imposed"].values())
+    imposed2 = {k: e / (ARITH_L2_2MFMA * nrm + NOISE_FLOOR * gn) * ARITH_L2_2MFMA for k, (e, nrm) in r["gl2_imposed"].items() if k not in r["zero_grad_params"]}
+    _record("C3", "f32_batch16_backward_auto", {"resolved_to": model2.backward_spec, "grad_rel_l2_decisions_imposed_worst": max(imposed2.values()),
+                                                "grad_rel_l2_decisions_imposed_worst_tensor": max(imposed2, key=imposed2.get),
+                                                "grad_rel_l2_decisions_imposed_median": float(np.median(list(imposed2.values())))})
+    assert max(imposed2.values()) < ARITH_L2_2MFMA, max(imposed2, key=imposed2.get)
 
 
 def test_c3_at_batch_64_matches_the_register_staged_route(monkeypatch):
