@@ -607,6 +607,7 @@ def main():
     rccl = {"backend": (dist.get_backend() if dist.is_initialized() else None), "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
             "version": None, "gradient_bytes_per_step": int(model.store.n_train * (2 if getattr(dpm, "grad_dtype", "f32") == "bf16" else 4)),
             "gradient_dtype": getattr(dpm, "grad_dtype", "f32"),
+            "busbw_gbs_measured": getattr(model, "dp_busbw_gbs", None),
             "exposed_comm_ms_per_step_by_rank": exposed,
             "exposed_comm_what": "time the optimiser's stream waited for gradient slices (HIP events around each wait), mean of 5 extra steps"}
     try:

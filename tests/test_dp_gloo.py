@@ -100,6 +100,11 @@ def _worker(rank, world, port, q):
         m4.build(2, dtype="f32")
         d4 = dp.DataParallel(m4, bucket_elems=20000)
         ok6 = d4.grad_dtype == "f32" and m4.grad_dtype == "f32" and m4.store.G16 is None
+        # 6. the fabric is measured, not assumed: one timed all-reduce at construction, the minimum over the ranks - every rank holds the
+        #    same number (the hold-back schedule, hence the ORDER of the collectives, is decided from it)
+        bws = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(bws, torch.tensor([m4.dp_busbw_gbs or -1.0], dtype=torch.float64))
+        ok6 = ok6 and m4.dp_busbw_gbs is not None and m4.dp_busbw_gbs > 0 and all(float(b) == float(bws[0]) for b in bws)
         q.put((rank, ok1, ok2, ok3 and ok4 and ok5 and ok6, None))
         dist.destroy_process_group()
     except Exception as e:      # pragma: no cover

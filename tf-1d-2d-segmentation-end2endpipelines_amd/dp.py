@@ -117,6 +117,10 @@ class DataParallel:
             model.bucket_waits = self._take_pending
         elif exchange:
             model.allreduce = self._allreduce       # (a single rank keeps the model's own single-GPU optimiser path)
+        if self.world_size > 1 and exchange:
+            from . import flags as _F
+            if _F.DP_BUSBW_MEASURE:
+                model.dp_busbw_gbs = self.measure_busbw(model.store.G.device, group)
         if self.world_size > 1:
             # identical replicas: weights, BN moving statistics AND the optimiser's view of the run (state buffers, step
             # count, Nadam's momentum product, learning rate) come from rank 0 - a model that has already taken steps, or
@@ -129,6 +133,30 @@ class DataParallel:
             broadcast_flat(scal, 0, group)
             model.adam_t, model._u_product, model.lr = int(scal[0].item()), float(scal[1].item()), float(scal[2].item())
             model._refresh_copies()
+
+    @staticmethod
+    def measure_busbw(device, group=None) -> float:
+        """Bus bandwidth (GB/s, nccl-tests' definition: 2 (w - 1) / w x bytes / time) of ONE timed fp32 all-reduce on this job's fabric -
+        64 MB on a GPU backend, 4 MB on gloo -, the MINIMUM over the ranks: the hold-back schedule (SegModel.bucket_holds) decides from
+        it which gradient slices wait for the end of the backward sweep, and every rank must decide the same (the collectives are
+        issued in that order).  Replaces the assumed 300 GB/s unless SEG_DP_BUSBW_GBS pins a value."""
+        import time
+        w = dist.get_world_size(group)
+        on_gpu = device.type == "cuda"
+        n = (16 << 20) if on_gpu else (1 << 20)
+        buf = torch.zeros(n, dtype=torch.float32, device=device)
+        dist.all_reduce(buf[: n // 16], group=group)                 # warm-up: connections, RCCL's channel set-up
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        dist.barrier(group)
+        t0 = time.perf_counter()
+        dist.all_reduce(buf, group=group)
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        dt = max(time.perf_counter() - t0, 1e-6)
+        bw = torch.tensor([2.0 * (w - 1) / w * n * 4 / dt / 1e9], dtype=torch.float64, device=device)
+        dist.all_reduce(bw, op=dist.ReduceOp.MIN, group=group)
+        return float(bw.item())
 
     @staticmethod
     def _bf16_allreduce_works(device, group) -> bool:

@@ -37,7 +37,8 @@ BIAS_FROM_WGRAD = True
 ADAM_ASYNC = os.environ.get("SEG_ADAM_ASYNC", "1") != "0"
 DP_ASYNC = os.environ.get("SEG_DP_ASYNC", "1") != "0"           # data parallel: exchanged slices are awaited + updated on the side stream under the next forward
 DP_URGENT_ELEMS = 4 << 20     # size at which the first (most urgent) gradient slice closes
-DP_BUSBW_GBS = float(os.environ.get("SEG_DP_BUSBW_GBS", "300"))                 # all-reduce bus bandwidth the hold-back estimate assumes
+DP_BUSBW_GBS = float(os.environ.get("SEG_DP_BUSBW_GBS", "300"))                 # all-reduce bus bandwidth the hold-back estimate assumes ...
+DP_BUSBW_MEASURE = os.environ.get("SEG_DP_BUSBW_GBS") is None                   # ... unless dp.DataParallel measured the fabric (one timed all-reduce at construction, the minimum over the ranks)
 ADAM_SLICE_ELEMS = 4 << 20
 ADAM_URGENT_FIRST = True
 FWD_HALO = os.environ.get("SEG_FWD_HALO", "1") != "0"       # variant 3 (halo tiles) for the 3x3 stride-1 layers

@@ -137,6 +137,7 @@ class SegModel:
         self.side_stream = None        # second HIP stream for the weight-gradient kernels (created in build())
         self.use_side_stream = os.environ.get("SEG_WGRAD_STREAM", "1") != "0"
         self.bucket_elems = 32 << 20
+        self.dp_busbw_gbs = None       # all-reduce bus bandwidth dp.DataParallel measured on this job's fabric (None: flags.DP_BUSBW_GBS)
         self.backward_mode, self.backward_spec, self.bwd_d, self.bwd_w = None, "d3w3", 3, 3       # build(backward=): MFMAs per product of the backward GEMMs (parity mode)
         if batch_size is not None:
             self.build(batch_size)
@@ -911,7 +912,7 @@ class SegModel:
         cannot finish before the sweep does would still be on the (in-order) RCCL stream when the more urgent slices - the
         encoder's, needed first by the next forward pass, finished last by this sweep - become ready, and delay them.  Held
         slices are issued after the sweep in forward order.  Estimate: ring all-reduce time 2 (w-1)/w x bytes / bus bandwidth
-        (SEG_DP_BUSBW_GBS, default 300: xGMI rings are per-link bound), collectives queued one after the other, against the
+        (measured once by dp.DataParallel on the job's own fabric - `dp_busbw_gbs` -, else SEG_DP_BUSBW_GBS, default 300: xGMI rings are per-link bound), collectives queued one after the other, against the
         remaining GEMM work of the sweep at 600 TFLOP/s (fwd-shaped data gradient + weight gradient = 4 x MACs)."""
         bk = self.grad_buckets()
         w = self.world_size
@@ -925,7 +926,7 @@ class SegModel:
         for j in range(len(bk) - 1, -1, -1):                     # the order in which the sweep completes the slices
             lo, hi, oi = bk[j]
             start = max(-remaining[oi], busy_until)              # collectives run one after the other
-            end = start + 2.0 * (w - 1) / w * (hi - lo) * 4 / (F.DP_BUSBW_GBS * 1e9)
+            end = start + 2.0 * (w - 1) / w * (hi - lo) * 4 / ((self.dp_busbw_gbs or F.DP_BUSBW_GBS) * 1e9)
             if end > 0.0:
                 holds[j] = True
             else:
