@@ -24,9 +24,9 @@ __device__ __forceinline__ h8 trfrag(const unsigned char* ad, int rstride4) {
     ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACCL, 0, 0, 0);         \
   } while (0)
 
-// EXPERIMENT (SEG_VARIANT_IN_HI, never validated): the INPUT operand of the weight gradient read as its hi half - a b ~= ah bh + al bh / 2048
+// SEG_VARIANT_IN_HI (SegModel.build(backward="...w2"): the default's weight gradients): the INPUT operand read as its hi half - a b ~= ah bh + al bh / 2048
 // with a = dz whole, b = the activations' hi half.  The lo fragment of every tap's halo read goes (5 of the 12 fragment reads per K
-// block of the 3x3 kernel) and a third of the MFMAs; the activations lose 2^-11, elementwise (docs/experiments.md section 7, item 0).
+// block of the 3x3 kernel) and a third of the MFMAs; the activations lose 2^-11, elementwise (measured 3.8e-4 on the worst parameter tensor of C2 / C5, 2.8e-4 on C4).
 #define SEG_MMA_SPLIT_BHI(ACC, ACCL, AH, AL, BH)                                  \
   do {                                                                            \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);           \
@@ -556,7 +556,7 @@ template __global__ void igemm_wgrad_halo_split_kernel<8, false, true>(const seg
 template __global__ void igemm_wgrad_halo_split_kernel<32, true, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<16, true, true>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<8, true, true>(const seg_igemm_wgrad_args);
-// input operand as its hi half (experiment): the 3x3 layers and the per-class transposed-conv form, 64-channel tiles
+// input operand as its hi half: the 3x3 layers and the per-class transposed-conv form, 64-channel tiles
 template __global__ void igemm_wgrad_halo_split_kernel<32, false, false, 1>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<16, false, false, 1>(const seg_igemm_wgrad_args);
 template __global__ void igemm_wgrad_halo_split_kernel<8, false, false, 1>(const seg_igemm_wgrad_args);
