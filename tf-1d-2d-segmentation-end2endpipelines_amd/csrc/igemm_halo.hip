@@ -15,9 +15,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 // Parity mode (SPLIT, BN = 64 or 32): the tensors are split pairs and the loaders see twice the channels (igemm_common.h), so a
 // "32-channel chunk" is 16 real channels as hi / lo 16-B chunks; per tap and tile pair three MFMAs into two accumulator sets.
-// BN = 32 (parity mode, layers of at most 32 output channels - MultiResUNet's 8 / 17 / 26-filter convs at full resolution): the
-// weight stage keeps its 64 rows (the upper 32 are out of range and cost no memory traffic), a wave owns 64 px x ONE 32-channel
-// tile - half the MFMAs and B-fragment reads of the 64-channel tile, whose upper half would multiply zeros.
+// BN = 32 (parity mode, layers of at most 32 output channels - MultiResUNet's 8 / 17 / 26-filter convs at full resolution): a wave owns
+// 64 px x ONE 32-channel tile - half the MFMAs and B-fragment reads of the 64-channel tile, whose upper half would multiply zeros - and
+// the weight stage has 32 rows per tap (round 6; until then 64 with the upper half out of range: no memory traffic, but the LDS-DMA
+// stream is bound by instructions issued - 8 per stage now, 6 of them real, against 12).
 // HI (parity mode, data gradients only): two MFMAs per product instead of three.
 //   HI = 1 (variant bit SEG_VARIANT_A_HI): the A operand - the incoming gradient dz - is read as its hi half alone,
 //           a b ~= ah bh + ah bl / 2048: the `al` fragment reads and the `al bh` MFMA go (a third of both).  dz spans the whole fp16 range
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   constexpr int NI_A = (HROWS + 15) / 16;                  // LDS-DMA wave instructions per halo tile (16 rows of 64 B)
   constexpr int NA_HI = (NI_A + 3) / 4, NA_REM = NI_A % 4;  // per wave: NA_HI for waves < NA_REM (all when NA_REM == 0), else NA_HI - 1
   constexpr int A_BYTES = NI_A * 1024;
-  constexpr int BROWS = BN < 64 ? 64 : BN;                 // rows of a weight stage
+  constexpr int BROWS = BN;                                // rows of a weight stage per tap (BN = 32: a stage is padded with masked LDS-DMA instructions, below)
   // BHI: the stage holds the hi chunks only - rows of 32 B (chunk 0 = channels 0-7, chunk 1 = channels 8-15 of the K chunk), an LDS-DMA
   // instruction fills 32 rows instead of 16: half the weight instructions of the stream that bounds these kernels (the masked-lane
   // form - same instructions, lo lanes out of range - measured neutral: the stream is bound by instructions, not bytes).  A stage whose
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void igemm_fwd3_kernel(const seg_igemm_fwd_
   constexpr int NSTEP = NT / TG;
   constexpr int WMv = BN <= 64 ? 4 : 2, WNv = 4 / WMv, TMw = 8 / WMv;   // A tiles (32 px) per wave
   constexpr int TNw = BN == 32 ? 1 : 2;                    // B tiles (32 channels) per wave
-  static_assert(TG * NSTEP == NT && NSTEP >= 2 && (BHI || B_REAL == B_BYTES), "tap groups / weight stage");
+  static_assert(TG * NSTEP == NT && NSTEP >= 2 && (BHI || BN == 32 || B_REAL == B_BYTES), "tap groups / weight stage");
   static_assert(NPL == 1 || (NPL == 4 && NT == 4), "parity planes: the data gradient of the 4x4 / stride-2 transposed conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
