@@ -119,3 +119,25 @@ def test_the_backward_mode_changes_the_backward_pass_only():
     gn = max(float(np.linalg.norm(v)) for v in g3.values())
     worst = max(float(np.linalg.norm(g2[k] - g3[k])) / (float(np.linalg.norm(g3[k])) + 1e-3 * gn) for k in g3)
     assert 1e-7 < worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("N,H,W,cins,cout,k,tile", [
+    (2, 8, 16, [256, 160], 136, 3, (128, 64)),      # a deep level: M = 256 pixels, K = 3 744
+    (2, 16, 16, [96, 40], 64, 1, (256, 64)),        # 1x1
+    (1, 16, 16, [192], 128, 3, (128, 128)),
+])
+def test_hi_only_weight_operand_on_the_per_tap_kernel(N, H, W, cins, cout, k, tile):
+    """SEG_VARIANT_B_HI on variant 0 (the per-tap LDS-DMA kernel: deep levels, 1x1 convs; what SEG_BWD_B2_PER_TAP=1 adds to the b2 modes -
+    off by default, flags.py): the three-MFMA launch on the weights' hi halves, bit for bit."""
+    torch.manual_seed(2)
+    rng = np.random.default_rng(2)
+    xs = [torch.randn(N, H, W, c) for c in cins]
+    cin = sum(cins)
+    kern = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    kern_hi = U.h16(torch.from_numpy(kern)).numpy()
+    full, _s, _p = U.igemm_conv(xs, kern, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=0)
+    half, _s, pad = U.igemm_conv(xs, kern, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=0 | ffi.SEG_VARIANT_B_HI)
+    want, _s, _p = U.igemm_conv(xs, kern_hi, None, "conv", (1, 1), None, 0.0, False, tile, f32=True, variant=0)
+    assert pad == 0.0 and torch.equal(half, want)
+    e = rel(half, full)
+    assert 1e-6 < e < 5e-4
